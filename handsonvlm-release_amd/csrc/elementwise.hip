@@ -1,0 +1,300 @@
+// HBM-bound elementwise / data-movement kernels: SwiGLU, RoPE, add, casts, transpose, column sums.
+// All bf16 traffic is 16 bytes per lane; grids are capped and grid-strided.
+#include "common.h"
+
+namespace hvlm {
+namespace {
+
+constexpr int EW_THREADS = 256;
+static inline int ew_grid(long items) {
+  long g = (items + EW_THREADS - 1) / EW_THREADS;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// ---- SwiGLU: act = bf16(bf16(silu(g)) * u)  (transformers LlamaMLP, bf16 op-by-op) ------------
+__global__ __launch_bounds__(EW_THREADS) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
+                                                                bf16_t* __restrict__ act, long M,
+                                                                int F) {
+  const int fv = F / 8;
+  const long total = M * fv;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * EW_THREADS) {
+    const long m = i / fv;
+    const int c = (int)(i - m * fv) * 8;
+    const bf16_t* row = gu + m * (2L * F);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(row + c);
+    const u32x4 u = *reinterpret_cast<const u32x4*>(row + F + c);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
+      const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
+      o[e] = pack_bf2(s0 * bf_lo(u[e]), s1 * bf_hi(u[e]));
+    }
+    *reinterpret_cast<u32x4*>(act + m * (long)F + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu,
+                                                                const bf16_t* __restrict__ dact,
+                                                                bf16_t* __restrict__ dgu, long M,
+                                                                int F) {
+  const int fv = F / 8;
+  const long total = M * fv;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * EW_THREADS) {
+    const long m = i / fv;
+    const int c = (int)(i - m * fv) * 8;
+    const bf16_t* row = gu + m * (2L * F);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(row + c);
+    const u32x4 u = *reinterpret_cast<const u32x4*>(row + F + c);
+    const u32x4 d = *reinterpret_cast<const u32x4*>(dact + m * (long)F + c);
+    u32x4 og, ou;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg[2] = {bf_lo(g[e]), bf_hi(g[e])};
+      float uu[2] = {bf_lo(u[e]), bf_hi(u[e])};
+      float dd[2] = {bf_lo(d[e]), bf_hi(d[e])};
+      float rg[2], ru[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float s = sigmoidf_(gg[k]);
+        const float silu = gg[k] * s;
+        ru[k] = dd[k] * silu;
+        rg[k] = dd[k] * uu[k] * (s * (1.f + gg[k] * (1.f - s)));
+      }
+      og[e] = pack_bf2(rg[0], rg[1]);
+      ou[e] = pack_bf2(ru[0], ru[1]);
+    }
+    bf16_t* orow = dgu + m * (2L * F);
+    *reinterpret_cast<u32x4*>(orow + c) = og;
+    *reinterpret_cast<u32x4*>(orow + F + c) = ou;
+  }
+}
+
+// ---- RoPE (half-split): o1 = bf16(bf16(x1*c) + bf16(-x2*s)), o2 = bf16(bf16(x2*c) + bf16(x1*s))
+// one work item = 8 rotation pairs of one (token, q|k, head).
+__global__ __launch_bounds__(EW_THREADS) void rope_kernel(bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ cos_tab,
+                                                          const bf16_t* __restrict__ sin_tab,
+                                                          const int32_t* __restrict__ pos, long M,
+                                                          int H, int dh, int ld, int inverse) {
+  const int half = dh / 2;
+  const int pv = half / 8;               // items per head
+  const long per_row = 2L * H * pv;      // q heads then k heads
+  const long total = M * per_row;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+       i += (long)gridDim.x * EW_THREADS) {
+    const long m = i / per_row;
+    const int r = (int)(i - m * per_row);
+    const int hh = r / pv;               // 0..2H-1 (q heads, then k heads: contiguous in qkv)
+    const int c = (r - hh * pv) * 8;
+    bf16_t* base = qkv + m * (long)ld + (long)hh * dh + c;
+    const int p = pos[m];
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(cos_tab + (long)p * half + c);
+    const u32x4 sv = *reinterpret_cast<const u32x4*>(sin_tab + (long)p * half + c);
+    const u32x4 x1 = *reinterpret_cast<const u32x4*>(base);
+    const u32x4 x2 = *reinterpret_cast<const u32x4*>(base + half);
+    u32x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a[2] = {bf_lo(x1[e]), bf_hi(x1[e])};
+      float b[2] = {bf_lo(x2[e]), bf_hi(x2[e])};
+      float cc[2] = {bf_lo(cv[e]), bf_hi(cv[e])};
+      float ss[2] = {bf_lo(sv[e]), bf_hi(sv[e])};
+      float r1[2], r2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float s = inverse ? -ss[k] : ss[k];
+        r1[k] = bf2f(f2bf(a[k] * cc[k])) + bf2f(f2bf(-b[k] * s));
+        r2[k] = bf2f(f2bf(b[k] * cc[k])) + bf2f(f2bf(a[k] * s));
+      }
+      o1[e] = pack_bf2(r1[0], r1[1]);
+      o2[e] = pack_bf2(r2[0], r2[1]);
+    }
+    *reinterpret_cast<u32x4*>(base) = o1;
+    *reinterpret_cast<u32x4*>(base + half) = o2;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void add_kernel(const bf16_t* __restrict__ a,
+                                                         const bf16_t* __restrict__ b,
+                                                         bf16_t* __restrict__ y, long n8) {
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n8;
+       i += (long)gridDim.x * EW_THREADS) {
+    const u32x4 x = reinterpret_cast<const u32x4*>(a)[i];
+    const u32x4 z = reinterpret_cast<const u32x4*>(b)[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bf_lo(x[e]) + bf_lo(z[e]), bf_hi(x[e]) + bf_hi(z[e]));
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+}
+__global__ void add_tail_kernel(const bf16_t* a, const bf16_t* b, bf16_t* y, long start, long n) {
+  const long i = start + threadIdx.x;
+  if (i < n) y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
+__global__ __launch_bounds__(EW_THREADS) void cast_f2b_kernel(const float* __restrict__ in,
+                                                              bf16_t* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * EW_THREADS + threadIdx.x) * 4; i < n;
+       i += (long)gridDim.x * EW_THREADS * 4) {
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+      u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(out + i) = o;
+    } else {
+      for (long k = i; k < n; ++k) out[k] = f2bf(in[k]);
+    }
+  }
+}
+__global__ __launch_bounds__(EW_THREADS) void cast_b2f_kernel(const bf16_t* __restrict__ in,
+                                                              float* __restrict__ out, long n) {
+  for (long i = ((long)blockIdx.x * EW_THREADS + threadIdx.x) * 4; i < n;
+       i += (long)gridDim.x * EW_THREADS * 4) {
+    if (i + 3 < n) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(in + i);
+      f32x4 o = {bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
+      *reinterpret_cast<f32x4*>(out + i) = o;
+    } else {
+      for (long k = i; k < n; ++k) out[k] = bf2f(in[k]);
+    }
+  }
+}
+
+// ---- transpose: out[C, R_pad] = in[R, C]^T, 64x64 tiles through LDS ----------------------------
+// LDS tile stored [64 rows][64+2 cols] of bf16 so that the column gather hits distinct banks.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in,
+                                                        bf16_t* __restrict__ out, int R, int C,
+                                                        int ld_in, int R_pad) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  // load: 64 rows x 8 chunks of 8 elements = 512 chunks, 2 per thread
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = t + k * 256;
+    const int r = idx >> 3, c = (idx & 7) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + r < R) {
+      if (c0 + c + 7 < C) {
+        v = *reinterpret_cast<const u32x4*>(in + (size_t)(r0 + r) * ld_in + c0 + c);
+      } else {
+        bf16_t tmp[8];
+        for (int e = 0; e < 8; ++e) tmp[e] = (c0 + c + e < C) ? in[(size_t)(r0 + r) * ld_in + c0 + c + e] : (bf16_t)0;
+        v[0] = tmp[0] | ((unsigned)tmp[1] << 16); v[1] = tmp[2] | ((unsigned)tmp[3] << 16);
+        v[2] = tmp[4] | ((unsigned)tmp[5] << 16); v[3] = tmp[6] | ((unsigned)tmp[7] << 16);
+      }
+    }
+    unsigned* dst = reinterpret_cast<unsigned*>(&tile[r][c]);  // 66*2 B rows: 4-byte aligned
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = t + k * 256;
+    const int c = idx >> 3, r = (idx & 7) * 8;   // output row c (input col), 8 input rows r..r+7
+    if (c0 + c >= C) continue;
+    if (r0 + r >= R_pad) continue;
+    bf16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = tile[r + j][c];
+    bf16_t* op = out + (size_t)(c0 + c) * R_pad + r0 + r;
+    if (r0 + r + 7 < R_pad) {
+      u32x4 o = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                 e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+      *reinterpret_cast<u32x4*>(op) = o;
+    } else {
+      for (int j = 0; j < 8; ++j) if (r0 + r + j < R_pad) op[j] = e[j];
+    }
+  }
+}
+
+// ---- column sums: out[c] += sum_r in[r][c]; grid (cdiv(C,256), slabs), out pre-zeroed -----------
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in,
+                                                     float* __restrict__ out, int R, int C,
+                                                     int ld_in) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = blockIdx.y; r < R; r += gridDim.y) s += bf2f(in[(size_t)r * ld_in + c]);
+  atomicAdd(out + c, s);
+}
+
+}  // namespace
+}  // namespace hvlm
+
+using namespace hvlm;
+
+extern "C" int hvlm_swiglu_fwd(const void* gu, void* act, int M, int F, void* stream) {
+  HVLM_REQUIRE(gu && act && M > 0 && F > 0 && F % 8 == 0, "swiglu_fwd: bad args (F %% 8)");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid((long)M * F / 8)), dim3(EW_THREADS), 0,
+                     as_stream(stream), (const bf16_t*)gu, (bf16_t*)act, (long)M, F);
+  return check_launch("swiglu_fwd");
+}
+
+extern "C" int hvlm_swiglu_bwd(const void* gu, const void* dact, void* dgu, int M, int F, void* stream) {
+  HVLM_REQUIRE(gu && dact && dgu && M > 0 && F > 0 && F % 8 == 0, "swiglu_bwd: bad args (F %% 8)");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid((long)M * F / 8)), dim3(EW_THREADS), 0,
+                     as_stream(stream), (const bf16_t*)gu, (const bf16_t*)dact, (bf16_t*)dgu, (long)M, F);
+  return check_launch("swiglu_bwd");
+}
+
+extern "C" int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int32_t* pos,
+                            int M, int H, int dh, int ld, int inverse, void* stream) {
+  HVLM_REQUIRE(qkv && cos_tab && sin_tab && pos, "rope: null pointer");
+  HVLM_REQUIRE(M > 0 && H > 0 && dh % 16 == 0 && ld % 8 == 0 && ld >= 2 * H * dh, "rope: bad shape");
+  const long items = (long)M * 2 * H * (dh / 16);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(items)), dim3(EW_THREADS), 0, as_stream(stream),
+                     (bf16_t*)qkv, (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, pos, (long)M, H, dh,
+                     ld, inverse);
+  return check_launch("rope_qk");
+}
+
+extern "C" int hvlm_add_bf16(const void* a, const void* b, void* y, long n, void* stream) {
+  HVLM_REQUIRE(a && b && y && n > 0, "add: bad args");
+  const long n8 = n / 8;
+  if (n8 > 0)
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n8)), dim3(EW_THREADS), 0, as_stream(stream),
+                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n8);
+  if (n8 * 8 < n)
+    hipLaunchKernelGGL(add_tail_kernel, dim3(1), dim3(8), 0, as_stream(stream), (const bf16_t*)a,
+                       (const bf16_t*)b, (bf16_t*)y, n8 * 8, n);
+  return check_launch("add_bf16");
+}
+
+extern "C" int hvlm_cast_f32_to_bf16(const float* in, void* out, long n, void* stream) {
+  HVLM_REQUIRE(in && out && n > 0, "cast: bad args");
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, as_stream(stream),
+                     in, (bf16_t*)out, n);
+  return check_launch("cast_f32_to_bf16");
+}
+
+extern "C" int hvlm_cast_bf16_to_f32(const void* in, float* out, long n, void* stream) {
+  HVLM_REQUIRE(in && out && n > 0, "cast: bad args");
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, as_stream(stream),
+                     (const bf16_t*)in, out, n);
+  return check_launch("cast_bf16_to_f32");
+}
+
+extern "C" int hvlm_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int R_pad,
+                                   void* stream) {
+  HVLM_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C && R_pad >= R, "transpose: bad args");
+  HVLM_REQUIRE(ld_in % 8 == 0 && R_pad % 8 == 0, "transpose: ld_in, R_pad must be multiples of 8");
+  dim3 grid(cdiv(C, 64), cdiv(R_pad, 64));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)in,
+                     (bf16_t*)out, R, C, ld_in, R_pad);
+  return check_launch("transpose_bf16");
+}
+
+extern "C" int hvlm_colsum_bf16(const void* in, float* out, int R, int C, int ld_in, void* stream) {
+  HVLM_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C, "colsum: bad args");
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, as_stream(stream));
+  if (e != hipSuccess) { set_error("colsum: memset: %s", hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
+  int slabs = R < 64 ? R : 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), slabs), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)in, out, R, C, ld_in);
+  return check_launch("colsum_bf16");
+}

@@ -1,0 +1,239 @@
+// bf16 GEMM on MFMA for gfx950:  C[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.
+//
+// Structure (one workgroup = one 256x256 output tile, 8 waves as 2(M) x 4(N), wave tile 128x64):
+//   * K is walked in 64-wide tiles; both operand tiles (256 rows x 128 B) are copied HBM -> LDS by
+//     LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction, no VGPR round trip) into a
+//     2-deep ring, so tile t+1 is in flight while tile t feeds the matrix pipe.
+//   * LDS image: row-major 128-B rows, 16-B chunk c of row r stored at chunk position
+//     c ^ ((r>>1)&7).  LDS-DMA writes lane-linear, so the permutation is applied to the per-lane
+//     SOURCE address and again on the fragment read; with it every ds_read_b128 lane group of a
+//     32-row fragment touches 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+//   * v_mfma_f32_32x32x16_bf16 with the operands SWAPPED (weight-tile rows as the MFMA "A"):
+//     the accumulator then holds, per lane, one output row m and 4 consecutive output columns per
+//     register quad, so the epilogue (bias, QuickGELU, residual, bf16 pack) stores 8 contiguous
+//     bytes per lane without an LDS transpose.
+//   * blockIdx -> tile map is XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous
+//     range of a grouped (GM row-panels x all column-panels) ordering so the 32 tiles resident on
+//     one XCD share operand panels in that XCD's private L2.
+//
+// Reference arithmetic replaced: every nn.Linear on the path (see include/hvlm.h).
+#include "common.h"
+
+namespace hvlm {
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NT = 512;                       // 8 waves
+constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // 128 KiB, 2-deep ring
+constexpr int GROUP_M = 4;
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const bf16_t* bias;
+  const bf16_t* res;
+  int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_off, char* smem) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(smem + lds_off), 16, 0, 0);
+}
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = l & 31, hi = l >> 5;
+
+  // ---- XCD-aware, grouped tile mapping ---------------------------------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  int swz;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm, tn;
+  {
+    const int gsz = GROUP_M * p.tiles_n;
+    const int gid = swz / gsz;
+    const int first_m = gid * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int in = swz - gid * gsz;
+    tm = first_m + in % gm;
+    tn = in / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane LDS-DMA source pointers (4 A pieces + 4 B pieces per wave per K-tile) ----
+  const bf16_t* ga[4];
+  const bf16_t* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = w * 32 + i * 8 + (l >> 3);           // tile row this lane feeds
+    const int c = (l & 7) ^ ((row >> 1) & 7);            // source chunk for chunk position l&7
+    const int ra = min(m0 + row, p.M - 1);
+    const int rb = min(n0 + row, p.N - 1);
+    ga[i] = p.A + (size_t)ra * p.lda + c * 8;
+    gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
+  }
+  const unsigned dma_off = (unsigned)(w * 4) * 1024u;    // + i*1024 ; wave-uniform
+
+  auto stage = [&](int buf, int kt) {
+    const unsigned base = (unsigned)buf * STAGE_BYTES + dma_off;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(ga[i] + k0, base + i * 1024u, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(gb[i] + k0, base + TILE_BYTES + i * 1024u, smem);
+  };
+
+  // ---- fragment read offsets ----------------------------------------------------------------
+  const int wm = w >> 2, wn = w & 3;
+  const int sw = (l31 >> 1) & 7;
+  unsigned koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(((ks * 2 + hi) ^ sw) << 4);
+  const unsigned a_base = (unsigned)(wm * 128 + l31) * 128u;
+  const unsigned b_base = (unsigned)TILE_BYTES + (unsigned)(wn * 64 + l31) * 128u;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of tile kt landed
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + i * 4096u + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds row m, 4 consecutive columns per register quad ----------------
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 128 + i * 32 + l31;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+        if (nb >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+        const bool full = (nb + 3 < p.N);
+        if (p.bias) {
+          if (full) {
+            const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + nb);
+            v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+          } else {
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(p.bias[nb + e]);
+          }
+        }
+        if (p.act == HVLM_ACT_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+        }
+        if (p.res) {
+          const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
+          if (full) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+            v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
+          } else {
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(rp[e]);
+          }
+        }
+        if (p.out_f32) {
+          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb;
+          if (full) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(cp) = o;
+          } else {
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = v[e];
+          }
+        } else {
+          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
+          if (full) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(cp) = o;
+          } else {
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = f2bf(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+}  // namespace hvlm
+
+using namespace hvlm;
+
+extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                                 int ldb, int ldc, const void* bias, const void* residual, int ldr,
+                                 int act, int out_f32, void* stream) {
+  HVLM_REQUIRE(A && B && C, "gemm: null operand");
+  HVLM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  HVLM_REQUIRE(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
+  HVLM_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm: leading dimension too small");
+  HVLM_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm: lda/ldb %% 8, ldc %% 4 required");
+  HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0,
+               "gemm: operands must be 16-byte aligned");
+  HVLM_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0),
+               "gemm: bad residual");
+  HVLM_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0, "gemm: bias must be 8-byte aligned");
+  HVLM_REQUIRE(act == HVLM_ACT_NONE || act == HVLM_ACT_QUICK_GELU, "gemm: unknown act %d", act);
+  GemmArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+  p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+  p.act = act; p.out_f32 = out_f32;
+  p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return HVLM_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  const int grid = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(grid), dim3(NT), LDS_BYTES, as_stream(stream), p);
+  return check_launch("gemm_bf16_nt");
+}

@@ -1,0 +1,271 @@
+// RMSNorm (fwd/bwd) and LayerNorm (fwd) for gfx950.  HBM-bound: every row is read once with
+// 16-byte loads (8 bf16 per lane), kept in registers, reduced with wave shuffles, written once.
+//
+// Reference arithmetic: transformers LlamaRMSNorm.forward (fp32 variance, cast back to the
+// activation dtype, then multiply by the bf16 weight) and torch LayerNorm inside
+// CLIPEncoderLayer / CLIPVisionTransformer.pre_layrnorm (fp32 statistics, one rounding).
+#include "common.h"
+
+namespace hvlm {
+namespace {
+
+constexpr int MAXC = 4;  // register chunks of 8 elements per thread: D <= TPR*8*MAXC
+
+// TPR = threads per row (64 -> one wave per row, 256 -> one block per row).
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* red) {
+  if constexpr (TPR == 64) return wave_sum(v);
+  else return block_sum<TPR / 64>(v, red);
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          bf16_t* __restrict__ y,
+                                                          float* __restrict__ rstd_out, int rows,
+                                                          int D, float eps) {
+  __shared__ float red[4];
+  constexpr int RPB = 256 / TPR;
+  const int t = threadIdx.x % TPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+  const bool active = row < rows;
+  const bf16_t* xr = x + (size_t)(active ? row : 0) * D;
+  u32x4 v[MAXC];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * TPR + t) * 8;
+    if (i < D) {
+      v[c] = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bf_lo(v[c][e]), b = bf_hi(v[c][e]);
+        ss += a * a + b * b;
+      }
+    }
+  }
+  ss = row_sum<TPR>(ss, red);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  if (!active) return;
+  if (rstd_out && t == 0) rstd_out[row] = rstd;
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * TPR + t) * 8;
+    if (i < D) {
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // bf16(x*rstd) first (the reference casts back before the weight multiply)
+        const float a = bf2f(f2bf(bf_lo(v[c][e]) * rstd)) * bf_lo(wv[e]);
+        const float b = bf2f(f2bf(bf_hi(v[c][e]) * rstd)) * bf_hi(wv[e]);
+        o[e] = pack_bf2(a, b);
+      }
+      *reinterpret_cast<u32x4*>(yr + i) = o;
+    }
+  }
+}
+
+// grid = HVLM_NORM_BWD_BLOCKS blocks of 256 threads; block b walks rows b, b+grid, ...
+// dx = add + rstd * (g - xhat * mean(g * xhat)),  g = dy * w ; dw_partial[b] = sum dy * xhat.
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          const float* __restrict__ rstd_in,
+                                                          const bf16_t* __restrict__ add,
+                                                          bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw_partial, int rows,
+                                                          int D) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  float wreg[MAXC][8];
+  float dwacc[MAXC][8];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 256 + t) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dwacc[c][e] = 0.f; wreg[c][e] = 0.f; }
+    if (i < D) {
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { wreg[c][2 * e] = bf_lo(wv[e]); wreg[c][2 * e + 1] = bf_hi(wv[e]); }
+    }
+  }
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const size_t off = (size_t)row * D;
+    const float rstd = rstd_in[row];
+    float xh[MAXC][8], g[MAXC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 256 + t) * 8;
+      if (i < D) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off + i);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = bf_lo(xv[e]) * rstd, x1 = bf_hi(xv[e]) * rstd;
+          const float d0 = bf_lo(gv[e]), d1 = bf_hi(gv[e]);
+          xh[c][2 * e] = x0; xh[c][2 * e + 1] = x1;
+          dwacc[c][2 * e] += d0 * x0; dwacc[c][2 * e + 1] += d1 * x1;
+          g[c][2 * e] = d0 * wreg[c][2 * e]; g[c][2 * e + 1] = d1 * wreg[c][2 * e + 1];
+          dot += g[c][2 * e] * x0 + g[c][2 * e + 1] * x1;
+        }
+      }
+    }
+    dot = block_sum<4>(dot, red);
+    const float mean = dot / (float)D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * 256 + t) * 8;
+      if (i < D) {
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (add) av = *reinterpret_cast<const u32x4*>(add + off + i);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = rstd * (g[c][2 * e] - xh[c][2 * e] * mean) + bf_lo(av[e]);
+          const float r1 = rstd * (g[c][2 * e + 1] - xh[c][2 * e + 1] * mean) + bf_hi(av[e]);
+          o[e] = pack_bf2(r0, r1);
+        }
+        *reinterpret_cast<u32x4*>(dx + off + i) = o;
+      }
+    }
+  }
+  float* dwp = dw_partial + (size_t)blockIdx.x * D;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 256 + t) * 8;
+    if (i < D) {
+      f32x4 a = {dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
+      f32x4 b = {dwacc[c][4], dwacc[c][5], dwacc[c][6], dwacc[c][7]};
+      *reinterpret_cast<f32x4*>(dwp + i) = a;
+      *reinterpret_cast<f32x4*>(dwp + i + 4) = b;
+    }
+  }
+}
+
+// out[d] = sum_r in[r][d]; one thread per column, rows strided over blockIdx.y slabs is not
+// needed here (rows <= 256): thread = column, loop rows.
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in,
+                                                          void* __restrict__ out, int rows, int D,
+                                                          int out_bf16) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += in[(size_t)r * D + d];
+  if (out_bf16) reinterpret_cast<bf16_t*>(out)[d] = f2bf(s);
+  else reinterpret_cast<float*>(out)[d] = s;
+}
+
+template <int TPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w,
+                                                            const bf16_t* __restrict__ b,
+                                                            bf16_t* __restrict__ y, int rows, int D,
+                                                            float eps) {
+  __shared__ float red[4];
+  constexpr int RPB = 256 / TPR;
+  const int t = threadIdx.x % TPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / TPR;
+  const bool active = row < rows;
+  const bf16_t* xr = x + (size_t)(active ? row : 0) * D;
+  float v[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * TPR + t) * 8;
+    if (i < D) {
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[c][2 * e] = bf_lo(xv[e]); v[c][2 * e + 1] = bf_hi(xv[e]);
+        s += v[c][2 * e] + v[c][2 * e + 1];
+      }
+    }
+  }
+  s = row_sum<TPR>(s, red);
+  const float mean = s / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * TPR + t) * 8;
+    if (i < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; ss += d * d; }
+    }
+  }
+  ss = row_sum<TPR>(ss, red);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  if (!active) return;
+  bf16_t* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * TPR + t) * 8;
+    if (i < D) {
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
+      const u32x4 bv = *reinterpret_cast<const u32x4*>(b + i);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float r0 = (v[c][2 * e] - mean) * rstd * bf_lo(wv[e]) + bf_lo(bv[e]);
+        const float r1 = (v[c][2 * e + 1] - mean) * rstd * bf_hi(wv[e]) + bf_hi(bv[e]);
+        o[e] = pack_bf2(r0, r1);
+      }
+      *reinterpret_cast<u32x4*>(yr + i) = o;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace hvlm
+
+using namespace hvlm;
+
+extern "C" int hvlm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int D,
+                                float eps, void* stream) {
+  HVLM_REQUIRE(x && w && y, "rmsnorm_fwd: null pointer");
+  HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "rmsnorm_fwd: bad D=%d", D);
+  if (D <= 64 * 8 * MAXC && D <= 2048) {
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, D, eps);
+  } else {
+    hipLaunchKernelGGL((rmsnorm_fwd_kernel<256>), dim3(rows), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rstd, rows, D, eps);
+  }
+  return check_launch("rmsnorm_fwd");
+}
+
+extern "C" int hvlm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+                                const void* add, void* dx, float* dw_partial, int rows, int D,
+                                void* stream) {
+  HVLM_REQUIRE(dy && x && w && rstd && dx && dw_partial, "rmsnorm_bwd: null pointer");
+  HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "rmsnorm_bwd: bad D=%d", D);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(HVLM_NORM_BWD_BLOCKS), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)add,
+                     (bf16_t*)dx, dw_partial, rows, D);
+  return check_launch("rmsnorm_bwd");
+}
+
+extern "C" int hvlm_reduce_rows_f32(const float* in, void* out, int rows, int D, int out_bf16,
+                                    void* stream) {
+  HVLM_REQUIRE(in && out && rows > 0 && D > 0, "reduce_rows: bad args");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(D, 256)), dim3(256), 0, as_stream(stream), in, out,
+                     rows, D, out_bf16);
+  return check_launch("reduce_rows_f32");
+}
+
+extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows,
+                                  int D, float eps, void* stream) {
+  HVLM_REQUIRE(x && w && b && y, "layernorm_fwd: null pointer");
+  HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "layernorm_fwd: bad D=%d", D);
+  if (D <= 2048) {
+    hipLaunchKernelGGL((layernorm_fwd_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, D, eps);
+  } else {
+    hipLaunchKernelGGL((layernorm_fwd_kernel<256>), dim3(rows), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, D, eps);
+  }
+  return check_launch("layernorm_fwd");
+}

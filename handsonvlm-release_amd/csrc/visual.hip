@@ -1,0 +1,346 @@
+// Visual-token pipeline kernels (all HBM-bound): CLIP patch im2col + embedding assembly,
+// temporal/spatial pooling, multimodal splice with the <hand_traj> sinusoidal encoding, and the
+// hand-token gather.  Reference: hoi_forecast/model/visual_to_tokens.py:252-284 and
+// handsonvlm/model/language_model/handsonvlm.py:146-187,212-451.
+#include "common.h"
+
+namespace hvlm {
+namespace {
+
+// patches[(n*G*G + gy*G + gx), k] = images[n, c, gy*P+py, gx*P+px], k = c*P*P + py*P + px
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ img,
+                                                     bf16_t* __restrict__ out, int N, int HW, int P,
+                                                     int Kpad) {
+  const int G = HW / P;
+  const int K = 3 * P * P;
+  const long total = (long)N * G * G * Kpad;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    const long row = i / Kpad;
+    bf16_t v = 0;
+    if (k < K) {
+      const int gx = (int)(row % G);
+      const int gy = (int)((row / G) % G);
+      const long n = row / ((long)G * G);
+      const int c = k / (P * P);
+      const int rem = k - c * P * P;
+      const int py = rem / P, px = rem - py * P;
+      v = img[((n * 3 + c) * HW + (gy * P + py)) * (long)HW + gx * P + px];
+    }
+    out[i] = v;
+  }
+}
+
+// tokens[n, 0] = cls + pos[0]; tokens[n, 1+p] = patch_out[n*NP+p] + pos[1+p]
+__global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restrict__ patch_out,
+                                                         const bf16_t* __restrict__ cls,
+                                                         const bf16_t* __restrict__ pos,
+                                                         bf16_t* __restrict__ tokens, long N, int NP,
+                                                         int D) {
+  const int dv = D / 8;
+  const long total = N * (NP + 1) * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const long tokrow = i / dv;
+    const int t = (int)(tokrow % (NP + 1));
+    const long n = tokrow / (NP + 1);
+    const bf16_t* src = (t == 0) ? cls + c : patch_out + (n * NP + (t - 1)) * (long)D + c;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(src);
+    const u32x4 b = *reinterpret_cast<const u32x4*>(pos + (long)t * D + c);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
+    *reinterpret_cast<u32x4*>(tokens + tokrow * (long)D + c) = o;
+  }
+}
+
+__device__ __forceinline__ int sel_frame(int k, int T) {
+  // np.round(np.linspace(0, T-1, 4)) : round-half-to-even on k*(T-1)/3
+  return (int)rintf((float)k * (float)(T - 1) / 3.0f);
+}
+
+// One work item = 8 channels of one output row.  grid-strided.
+//   out row r < T     : mean over the 256 patches of frame r
+//   out row r >= T    : j = r-T; frame sel(j/64); (oy,ox) = ((j%64)/8, j%8); mean of the 2x2 patches
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ tok,
+                                                       bf16_t* __restrict__ out, int B, int T, int D,
+                                                       int tpf /*tokens per frame incl. cls*/,
+                                                       int skip /*1 if cls is dropped*/) {
+  const int dv = D / 8;
+  const int rows = T + 256;
+  const long total = (long)B * rows * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const long rr = i / dv;
+    const int r = (int)(rr % rows);
+    const long b = rr / rows;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    float scale;
+    if (r < T) {
+      const bf16_t* base = tok + ((b * T + r) * (long)tpf + skip) * D + c;
+      for (int p = 0; p < 256; ++p) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+      }
+      scale = 1.f / 256.f;
+    } else {
+      const int j = r - T;
+      const int f = sel_frame(j >> 6, T);
+      const int oy = (j & 63) >> 3, ox = j & 7;
+      const bf16_t* base = tok + ((b * T + f) * (long)tpf + skip) * D + c;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int p = (2 * oy + dy) * 16 + 2 * ox + dx;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+        }
+      scale = 0.25f;
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
+    *reinterpret_cast<u32x4*>(out + rr * (long)D + c) = o;
+  }
+}
+
+// dtokens[b,t,p,:] = dout[b,t,:]/256 + sum_{k: sel(k)==t} dout[b, T + k*64 + (py/2)*8 + px/2, :]/4
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const bf16_t* __restrict__ dout,
+                                                       bf16_t* __restrict__ dtok, int B, int T, int D) {
+  const int dv = D / 8;
+  const int rows = T + 256;
+  const long total = (long)B * T * 256 * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const long rr = i / dv;
+    const int p = (int)(rr & 255);
+    const long bt = rr >> 8;
+    const int t = (int)(bt % T);
+    const long b = bt / T;
+    float acc[8];
+    {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dout + (b * rows + t) * (long)D + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] = bf_lo(v[e]) * (1.f / 256.f); acc[2 * e + 1] = bf_hi(v[e]) * (1.f / 256.f); }
+    }
+    const int py = p >> 4, px = p & 15;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (sel_frame(k, T) == t) {
+        const int j = k * 64 + (py >> 1) * 8 + (px >> 1);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(dout + (b * rows + T + j) * (long)D + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]) * 0.25f; acc[2 * e + 1] += bf_hi(v[e]) * 0.25f; }
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(dtok + rr * (long)D + c) = o;
+  }
+}
+
+// ---- multimodal splice + <hand_traj> positional encoding -------------------------------------
+// channel ch of a hand row: hand = ch & 1, cc = ch >> 1 in [0, D/2); quarter q = cc / (D/8),
+// i = cc % (D/8); inv_freq_i = 10000^(-(2i)/(D/4)); q even: sin(x*f) ; q odd: cos(y*f).
+__global__ __launch_bounds__(256) void splice_fwd_kernel(
+    const bf16_t* __restrict__ embed, const bf16_t* __restrict__ visual,
+    const int32_t* __restrict__ src, const int32_t* __restrict__ hand_slot,
+    const float* __restrict__ hands, const float* __restrict__ hand_scale, bf16_t* __restrict__ out,
+    int B, int S, int D, int NV, int NH) {
+  const int dv = D / 8;
+  const long total = (long)B * S * dv;
+  const int D8 = D / 8;
+  const float lg = -logf(10000.f) * 2.f / (float)(D / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const long row = i / dv;
+    const long b = row / S;
+    const int sidx = src[row];
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (sidx >= 0) v = *reinterpret_cast<const u32x4*>(embed + (long)sidx * D + c);
+    else if (sidx <= -2) v = *reinterpret_cast<const u32x4*>(visual + (b * NV + (-2 - sidx)) * (long)D + c);
+    const int slot = hand_slot ? hand_slot[row] : -1;
+    if (slot >= 0) {
+      const float sc = hand_scale[b];
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = c + e;
+        const int hand = ch & 1, cc = ch >> 1;
+        const int q = cc / D8, fi = cc - q * D8;
+        const float* hp = hands + ((b * 2 + hand) * NH + slot) * 2L;
+        const float f = __expf(lg * (float)fi);
+        r[e] = (q & 1) ? cosf(hp[1] * f) : sinf(hp[0] * f);
+        r[e] *= sc;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pack_bf2(bf_lo(v[e]) + r[2 * e], bf_hi(v[e]) + r[2 * e + 1]);
+    }
+    *reinterpret_cast<u32x4*>(out + row * (long)D + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void splice_bwd_kernel(const bf16_t* __restrict__ dx,
+                                                         const int32_t* __restrict__ src,
+                                                         float* __restrict__ dembed,
+                                                         bf16_t* __restrict__ dvisual, int B, int S,
+                                                         int D, int NV) {
+  const int dv = D / 8;
+  const long total = (long)B * S * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const long row = i / dv;
+    const long b = row / S;
+    const int sidx = src[row];
+    if (sidx == -1) continue;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(dx + row * (long)D + c);
+    if (sidx >= 0) {
+      if (dembed) {
+        float* dp = dembed + (long)sidx * D + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(dp + 2 * e, bf_lo(v[e])); atomicAdd(dp + 2 * e + 1, bf_hi(v[e])); }
+      }
+    } else if (dvisual) {
+      *reinterpret_cast<u32x4*>(dvisual + (b * NV + (-2 - sidx)) * (long)D + c) = v;
+    }
+  }
+}
+
+// out[b, hand, j, c] = hidden[rows[b*4+j], 2c+hand]
+template <typename OutT>
+__global__ __launch_bounds__(256) void hand_gather_fwd_kernel(const bf16_t* __restrict__ hidden,
+                                                              const int32_t* __restrict__ rows,
+                                                              OutT* __restrict__ out, int B, int D) {
+  const int half = D / 2;
+  const long total = (long)B * 2 * 4 * half;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % half);
+    const int j = (int)((i / half) & 3);
+    const int hand = (int)((i / (half * 4L)) & 1);
+    const long b = i / (half * 8L);
+    const int row = rows[b * 4 + j];
+    const float v = row >= 0 ? bf2f(hidden[(long)row * D + 2 * c + hand]) : 0.f;
+    if constexpr (sizeof(OutT) == 4) out[i] = v; else out[i] = f2bf(v);
+  }
+}
+
+template <typename InT>
+__global__ __launch_bounds__(256) void hand_gather_bwd_kernel(const InT* __restrict__ dout,
+                                                              const int32_t* __restrict__ rows,
+                                                              bf16_t* __restrict__ dhidden, int B, int D) {
+  const int half = D / 2;
+  const long total = (long)B * 2 * 4 * half;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % half);
+    const int j = (int)((i / half) & 3);
+    const int hand = (int)((i / (half * 4L)) & 1);
+    const long b = i / (half * 8L);
+    const int row = rows[b * 4 + j];
+    if (row < 0) continue;
+    float g;
+    if constexpr (sizeof(InT) == 4) g = dout[i]; else g = bf2f(dout[i]);
+    bf16_t* p = dhidden + (long)row * D + 2 * c + hand;
+    *p = f2bf(bf2f(*p) + g);
+  }
+}
+
+static inline int grid_for(long items) {
+  long g = (items + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+}  // namespace hvlm
+
+using namespace hvlm;
+
+extern "C" int hvlm_patch_im2col(const void* images, void* patches, int N, int HW, int P, int Kpad,
+                                 void* stream) {
+  HVLM_REQUIRE(images && patches && N > 0 && HW % P == 0 && Kpad >= 3 * P * P, "im2col: bad args");
+  const long total = (long)N * (HW / P) * (HW / P) * Kpad;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)images, (bf16_t*)patches, N, HW, P, Kpad);
+  return check_launch("patch_im2col");
+}
+
+extern "C" int hvlm_clip_embed(const void* patch_out, const void* cls, const void* pos, void* tokens,
+                               int N, int NP, int D, void* stream) {
+  HVLM_REQUIRE(patch_out && cls && pos && tokens && N > 0 && NP > 0 && D % 8 == 0, "clip_embed: bad args");
+  const long total = (long)N * (NP + 1) * (D / 8);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)patch_out, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)tokens,
+                     (long)N, NP, D);
+  return check_launch("clip_embed");
+}
+
+extern "C" int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,
+                                              int drop_cls, void* stream) {
+  HVLM_REQUIRE(tokens && out && B > 0 && T >= 1 && D % 8 == 0, "pool_fwd: bad args");
+  const long total = (long)B * (T + 256) * (D / 8);
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, drop_cls ? 257 : 256, drop_cls ? 1 : 0);
+  return check_launch("temporal_spatial_pool_fwd");
+}
+
+extern "C" int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D,
+                                              void* stream) {
+  HVLM_REQUIRE(dout && dtokens && B > 0 && T >= 1 && D % 8 == 0, "pool_bwd: bad args");
+  const long total = (long)B * T * 256 * (D / 8);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)dout, (bf16_t*)dtokens, B, T, D);
+  return check_launch("temporal_spatial_pool_bwd");
+}
+
+extern "C" int hvlm_embed_splice_fwd(const void* embed, const void* visual, const int32_t* src,
+                                     const int32_t* hand_slot, const float* hands,
+                                     const float* hand_scale, void* out, int B, int S, int D, int NV,
+                                     int NH, void* stream) {
+  HVLM_REQUIRE(embed && src && out && B > 0 && S > 0 && D % 8 == 0, "splice_fwd: bad args");
+  HVLM_REQUIRE(!hand_slot || (hands && hand_scale && NH > 0), "splice_fwd: hand_slot needs hands/scale");
+  const long total = (long)B * S * (D / 8);
+  hipLaunchKernelGGL(splice_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)embed, (const bf16_t*)visual, src, hand_slot, hands, hand_scale,
+                     (bf16_t*)out, B, S, D, NV, NH);
+  return check_launch("embed_splice_fwd");
+}
+
+extern "C" int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* dembed, void* dvisual,
+                                     int B, int S, int D, int NV, void* stream) {
+  HVLM_REQUIRE(dx && src && B > 0 && S > 0 && D % 8 == 0, "splice_bwd: bad args");
+  const long total = (long)B * S * (D / 8);
+  hipLaunchKernelGGL(splice_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)dx, src, dembed, (bf16_t*)dvisual, B, S, D, NV);
+  return check_launch("embed_splice_bwd");
+}
+
+extern "C" int hvlm_hand_gather_fwd(const void* hidden, const int32_t* rows, void* out, int B, int D,
+                                    int out_f32, void* stream) {
+  HVLM_REQUIRE(hidden && rows && out && B > 0 && D % 2 == 0, "hand_gather_fwd: bad args");
+  const long total = (long)B * 4 * D;
+  if (out_f32)
+    hipLaunchKernelGGL((hand_gather_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0,
+                       as_stream(stream), (const bf16_t*)hidden, rows, (float*)out, B, D);
+  else
+    hipLaunchKernelGGL((hand_gather_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0,
+                       as_stream(stream), (const bf16_t*)hidden, rows, (bf16_t*)out, B, D);
+  return check_launch("hand_gather_fwd");
+}
+
+extern "C" int hvlm_hand_gather_bwd(const void* dout, const int32_t* rows, void* dhidden, int B, int D,
+                                    int dout_f32, void* stream) {
+  HVLM_REQUIRE(dout && rows && dhidden && B > 0 && D % 2 == 0, "hand_gather_bwd: bad args");
+  const long total = (long)B * 4 * D;
+  if (dout_f32)
+    hipLaunchKernelGGL((hand_gather_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0,
+                       as_stream(stream), (const float*)dout, rows, (bf16_t*)dhidden, B, D);
+  else
+    hipLaunchKernelGGL((hand_gather_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0,
+                       as_stream(stream), (const bf16_t*)dout, rows, (bf16_t*)dhidden, B, D);
+  return check_launch("hand_gather_bwd");
+}

@@ -1,0 +1,105 @@
+"""ctypes binding of libhvlm_hip.so (the C ABI declared in include/hvlm.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, importing
+the ops raises.  Signatures are parsed from include/hvlm.h so the header stays the single source of
+truth (tests check that every declared symbol is exported).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parent.parent          # handsonvlm-release_amd/
+REPO_ROOT = _PKG_ROOT.parent
+LIB_PATH = _PKG_ROOT / "lib" / "libhvlm_hip.so"
+HEADER_PATH = REPO_ROOT / "include" / "hvlm.h"
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "long": ctypes.c_long,
+    "float": ctypes.c_float,
+    "size_t": ctypes.c_size_t,
+    "void": None,
+}
+
+
+def _ctype_of(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        if decl.startswith("const char") or decl.startswith("char"):
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    decl = decl.replace("const ", "").strip()
+    base = decl.split()[0]
+    return _CTYPES[base]
+
+
+def parse_header(path: Path = HEADER_PATH):
+    """Returns {name: (restype, [argtypes])} for every `hvlm_*` prototype in the header."""
+    text = path.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"^\s*#[^\n]*$", "", text, flags=re.M)          # preprocessor lines
+    text = text.replace('extern "C" {', "")
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(hvlm_\w+)\s*\(([^;{]*?)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("const char"):
+            restype = ctypes.c_char_p
+        else:
+            restype = _ctype_of(ret)
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                # strip the parameter name
+                if "*" in a:
+                    argtypes.append(_ctype_of(a))
+                else:
+                    argtypes.append(_ctype_of(" ".join(a.split()[:-1]) or a))
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class HvlmError(RuntimeError):
+    pass
+
+
+_lib = None
+_protos = None
+
+
+def load(path: os.PathLike | None = None) -> ctypes.CDLL:
+    """Loads the library (once) and attaches prototypes.  Raises if it is missing."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise HvlmError(
+            f"{p} not found: build it with `make -C {_PKG_ROOT}` (or __graft_entry__.build()). "
+            "There is no CPU/PyTorch fallback for the HIP path.")
+    lib = ctypes.CDLL(str(p))
+    protos = parse_header()
+    for name, (restype, argtypes) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HvlmError(f"{p} does not export {name} declared in {HEADER_PATH}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.hvlm_abi_version() != 1:
+        raise HvlmError("ABI version mismatch between include/hvlm.h and libhvlm_hip.so")
+    _lib, _protos = lib, protos
+    return lib
+
+
+def last_error() -> str:
+    return load().hvlm_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise HvlmError(f"{what}: rc={rc}: {last_error()}")

@@ -1,0 +1,293 @@
+"""Tensor-level wrappers over the C ABI (include/hvlm.h).
+
+PyTorch is used only for device memory and streams: every function takes CUDA(ROCm) tensors, passes
+raw device pointers + sizes + the current HIP stream through ctypes, and returns torch tensors that
+own the output memory.  No function here computes anything with torch kernels; if the library is
+missing, `_lib.load()` raises (there is no fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_NONE = 0
+ACT_QUICK_GELU = 1
+NORM_BWD_BLOCKS = 256
+IGNORE_INDEX = -100
+BF16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.HvlmError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.HvlmError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def device_info(device: int = 0):
+    cu, lds = ctypes.c_int(0), ctypes.c_int(0)
+    arch = ctypes.create_string_buffer(64)
+    check(_lib.load().hvlm_device_info(device, ctypes.byref(cu), ctypes.byref(lds), arch, 64), "device_info")
+    return {"cu_count": cu.value, "lds_bytes": lds.value, "arch": arch.value.decode()}
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+            out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
+    """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) + residual.  a/b may be row-strided 2-D views."""
+    _chk(a, BF16, "gemm.a"); _chk(b, BF16, "gemm.b")
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1], (a.shape, b.shape)
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ldr = 0
+    if residual is not None:
+        _chk(residual, BF16, "gemm.residual")
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    if bias is not None:
+        _chk(bias, BF16, "gemm.bias")
+        assert bias.numel() == N and bias.is_contiguous()
+    check(_lib.load().hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
+                                        out.stride(0), _p(bias), _p(residual), ldr, act,
+                                        1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")
+    return out
+
+
+def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
+    _chk(x, BF16, "transpose.x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, C = x.shape
+    r_pad = R if r_pad is None else r_pad
+    if out is None:
+        out = torch.empty((C, r_pad), dtype=BF16, device=x.device)
+    assert out.shape == (C, r_pad) and out.is_contiguous()
+    check(_lib.load().hvlm_transpose_bf16(_p(x), _p(out), R, C, x.stride(0), r_pad, _stream()), "transpose")
+    return out
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, BF16, "colsum.x")
+    R, C = x.shape
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvlm_colsum_bf16(_p(x), _p(out), R, C, x.stride(0), _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, save_rstd: bool = True,
+                out: Optional[torch.Tensor] = None):
+    _chk(x, BF16, "rmsnorm.x"); _chk(w, BF16, "rmsnorm.w")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x) if out is None else out
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if save_rstd else None
+    check(_lib.load().hvlm_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, D, eps, _stream()), "rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None):
+    """Returns (dx [like x], dw [D] bf16)."""
+    _chk(dy, BF16, "rmsnorm_bwd.dy")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x) if out is None else out
+    part = torch.empty((NORM_BWD_BLOCKS, D), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    check(lib.hvlm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(add), _p(dx), _p(part), rows, D, _stream()),
+          "rmsnorm_bwd")
+    dw = torch.empty((D,), dtype=BF16, device=x.device)
+    check(lib.hvlm_reduce_rows_f32(_p(part), _p(dw), NORM_BWD_BLOCKS, D, 1, _stream()), "reduce_rows")
+    return dx, dw
+
+
+def layernorm_fwd(x, w, b, eps: float, out=None):
+    _chk(x, BF16, "layernorm.x")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().hvlm_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), rows, D, eps, _stream()), "layernorm_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# rope / attention / swiglu
+# ------------------------------------------------------------------------------------------------
+def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch.Tensor, H: int, dh: int,
+             inverse: bool = False) -> torch.Tensor:
+    """In place on the q,k sections of qkv [M, ld]."""
+    _chk(qkv, BF16, "rope.qkv"); _chk(cos, BF16, "rope.cos"); _chk(sin, BF16, "rope.sin")
+    _chk(pos, torch.int32, "rope.pos")
+    assert qkv.dim() == 2 and qkv.stride(1) == 1
+    M = qkv.shape[0]
+    check(_lib.load().hvlm_rope_qk(_p(qkv), _p(cos), _p(sin), _p(pos), M, H, dh, qkv.stride(0),
+                                   1 if inverse else 0, _stream()), "rope_qk")
+    return qkv
+
+
+def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, dh: int, causal: bool, scale: float,
+             need_lse: bool = True, out: Optional[torch.Tensor] = None):
+    _chk(qkv, BF16, "attn.qkv")
+    assert qkv.dim() == 2 and qkv.shape[0] == B * S and qkv.stride(1) == 1
+    lib = _lib.load()
+    o = torch.empty((B * S, H * dh), dtype=BF16, device=qkv.device) if out is None else out
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device) if need_lse else None
+    ws = torch.empty((lib.hvlm_attn_fwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
+    check(lib.hvlm_attn_fwd(_p(qkv), _p(o), _p(lse), _p(ws), B, S, H, dh, qkv.stride(0), 1 if causal else 0,
+                            scale, _stream()), "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=None):
+    _chk(dout, BF16, "attn_bwd.dout")
+    assert dout.is_contiguous() and out.is_contiguous()
+    lib = _lib.load()
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    ws = torch.empty((lib.hvlm_attn_bwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
+    check(lib.hvlm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), B, S, H, dh, qkv.stride(0),
+                            1 if causal else 0, scale, _stream()), "attn_bwd")
+    return dqkv
+
+
+def swiglu_fwd(gu: torch.Tensor, out=None) -> torch.Tensor:
+    _chk(gu, BF16, "swiglu.gu")
+    assert gu.is_contiguous()
+    M, F2 = gu.shape
+    act = torch.empty((M, F2 // 2), dtype=BF16, device=gu.device) if out is None else out
+    check(_lib.load().hvlm_swiglu_fwd(_p(gu), _p(act), M, F2 // 2, _stream()), "swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(gu, dact, out=None):
+    M, F2 = gu.shape
+    dgu = torch.empty_like(gu) if out is None else out
+    check(_lib.load().hvlm_swiglu_bwd(_p(gu), _p(dact), _p(dgu), M, F2 // 2, _stream()), "swiglu_bwd")
+    return dgu
+
+
+# ------------------------------------------------------------------------------------------------
+# visual pipeline
+# ------------------------------------------------------------------------------------------------
+def patch_im2col(images: torch.Tensor, P: int, kpad: int) -> torch.Tensor:
+    _chk(images, BF16, "im2col.images")
+    assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
+    N, _, HW, _ = images.shape
+    G = HW // P
+    out = torch.empty((N * G * G, kpad), dtype=BF16, device=images.device)
+    check(_lib.load().hvlm_patch_im2col(_p(images), _p(out), N, HW, P, kpad, _stream()), "patch_im2col")
+    return out
+
+
+def clip_embed(patch_out, cls, pos, N: int, NP: int, D: int) -> torch.Tensor:
+    tokens = torch.empty((N, NP + 1, D), dtype=BF16, device=patch_out.device)
+    check(_lib.load().hvlm_clip_embed(_p(patch_out), _p(cls), _p(pos), _p(tokens), N, NP, D, _stream()), "clip_embed")
+    return tokens
+
+
+def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool) -> torch.Tensor:
+    _chk(tokens, BF16, "pool.tokens")
+    assert tokens.is_contiguous()
+    D = tokens.shape[-1]
+    out = torch.empty((B, T + 256, D), dtype=BF16, device=tokens.device)
+    check(_lib.load().hvlm_temporal_spatial_pool_fwd(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, _stream()),
+          "pool_fwd")
+    return out
+
+
+def temporal_spatial_pool_bwd(dout: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    D = dout.shape[-1]
+    dtok = torch.empty((B, T, 256, D), dtype=BF16, device=dout.device)
+    check(_lib.load().hvlm_temporal_spatial_pool_bwd(_p(dout), _p(dtok), B, T, D, _stream()), "pool_bwd")
+    return dtok
+
+
+def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None):
+    _chk(embed, BF16, "splice.embed"); _chk(src, torch.int32, "splice.src")
+    x = torch.empty((B * S, D), dtype=BF16, device=embed.device) if out is None else out
+    check(_lib.load().hvlm_embed_splice_fwd(_p(embed), _p(visual), _p(src), _p(hand_slot), _p(hands), _p(hand_scale),
+                                            _p(x), B, S, D, NV, NH, _stream()), "embed_splice_fwd")
+    return x
+
+
+def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV):
+    check(_lib.load().hvlm_embed_splice_bwd(_p(dx), _p(src), _p(dembed), _p(dvisual), B, S, D, NV, _stream()),
+          "embed_splice_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# heads / optimizer
+# ------------------------------------------------------------------------------------------------
+def ce_fwd(logits: torch.Tensor, targets: torch.Tensor, V: int):
+    """Returns (loss_sum[2] f32 = [sum nll, n_valid], row_lse[M])."""
+    _chk(logits, BF16, "ce.logits"); _chk(targets, torch.int32, "ce.targets")
+    M, ldl = logits.shape[0], logits.stride(0)
+    acc = torch.zeros((2,), dtype=torch.float32, device=logits.device)
+    row_lse = torch.empty((M,), dtype=torch.float32, device=logits.device)
+    check(_lib.load().hvlm_ce_fwd(_p(logits), _p(targets), _p(acc), _p(row_lse), M, V, ldl, _stream()), "ce_fwd")
+    return acc, row_lse
+
+
+def ce_bwd_(logits, targets, row_lse, grad_scale: torch.Tensor, V: int):
+    """In place: logits <- dlogits."""
+    M, ldl = logits.shape[0], logits.stride(0)
+    check(_lib.load().hvlm_ce_bwd(_p(logits), _p(targets), _p(row_lse), _p(grad_scale), _p(logits), M, V, ldl,
+                                  _stream()), "ce_bwd")
+    return logits
+
+
+def hand_gather_fwd(hidden: torch.Tensor, rows: torch.Tensor, B: int, D: int, out_dtype=torch.float32):
+    _chk(hidden, BF16, "hand_gather.hidden"); _chk(rows, torch.int32, "hand_gather.rows")
+    out = torch.empty((B, 2, 4, D // 2), dtype=out_dtype, device=hidden.device)
+    check(_lib.load().hvlm_hand_gather_fwd(_p(hidden), _p(rows), _p(out), B, D,
+                                           1 if out_dtype == torch.float32 else 0, _stream()), "hand_gather_fwd")
+    return out
+
+
+def hand_gather_bwd_(dout: torch.Tensor, rows: torch.Tensor, dhidden: torch.Tensor, B: int, D: int):
+    assert dout.is_contiguous()
+    check(_lib.load().hvlm_hand_gather_bwd(_p(dout), _p(rows), _p(dhidden), B, D,
+                                           1 if dout.dtype == torch.float32 else 0, _stream()), "hand_gather_bwd")
+    return dhidden
+
+
+def adamw_step_(master, m, v, grad, w, wt, lr, beta1, beta2, eps, wd, grad_scale, step):
+    R, C = (w.shape[0], w.shape[1]) if w.dim() == 2 else (1, w.numel())
+    check(_lib.load().hvlm_adamw_step(_p(master), _p(m), _p(v), _p(grad), _p(w), _p(wt), R, C, lr, beta1, beta2, eps,
+                                      wd, grad_scale, step, _stream()), "adamw_step")
+
+
+def add(a, b, out=None):
+    y = torch.empty_like(a) if out is None else out
+    check(_lib.load().hvlm_add_bf16(_p(a), _p(b), _p(y), a.numel(), _stream()), "add")
+    return y
+
+
+def cast_f32_to_bf16(x, out=None):
+    y = torch.empty(x.shape, dtype=BF16, device=x.device) if out is None else out
+    check(_lib.load().hvlm_cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "cast")
+    return y

@@ -1,0 +1,205 @@
+/*
+ * hvlm.h — C ABI of libhvlm_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the HandsOnVLM hot
+ * path (CLIP-ViT-L/14 -> mm_projector -> temporal/spatial pooling -> multimodal splice -> Vicuna
+ * decoder -> lm_head / cross-entropy; hand-trajectory gather), forward and backward.
+ *
+ * The reference (Kami-code/HandsOnVLM-release) is pure Python and has no FFI: its only
+ * kernel-swap precedent is llava/train/llama_flash_attn_monkey_patch.py:114-124 (assigning
+ * LlamaAttention.forward at import time).  Each entry point below therefore cites the reference
+ * call site (or the third-party transformers==4.31.0 function it calls, setup.py:15) whose
+ * arithmetic it replaces.  All paths are relative to the reference tree.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / STL types cross this boundary.
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees
+ *     or retains memory; workspaces are passed in explicitly.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, never synchronised.
+ *   - return value: HVLM_OK (0) or a negative HVLM_ERR_*; hvlm_last_error() gives the message of
+ *     the most recent failure on the calling thread.  Nothing throws across the ABI.
+ *   - "bf16" buffers are raw uint16 bfloat16; row-major; `ld*` are leading dimensions in ELEMENTS.
+ *   - tokens are stored token-major: activations are [M, features] with M = B*S (batch-major,
+ *     right-padded to S per sample) — the layout of inputs_embeds at handsonvlm.py:416-450.
+ */
+#ifndef HVLM_H
+#define HVLM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVLM_OK 0
+#define HVLM_ERR_INVALID (-1)
+#define HVLM_ERR_LAUNCH (-2)
+#define HVLM_ERR_UNSUPPORTED (-3)
+
+#define HVLM_ACT_NONE 0
+#define HVLM_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): transformers CLIP `quick_gelu` (clip_encoder.py:48) */
+
+#define HVLM_ABI_VERSION 1
+
+int hvlm_abi_version(void);
+const char* hvlm_last_error(void);
+/* Fills CU count, LDS bytes per workgroup and the gcnArchName of `device`. */
+int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------ *
+ * GEMM (MFMA, bf16 in, fp32 accumulate)
+ *   C[M,N] = act(A[M,K] @ B[N,K]^T + bias[N]) + residual[M,N]
+ * Replaces every nn.Linear on the path: LlamaAttention q/k/v/o_proj and LlamaMLP gate/up/down
+ * (transformers modeling_llama, called from handsonvlm.py:119-128), lm_head (handsonvlm.py:48,132),
+ * mm_projector (llava/model/llava_arch.py:33, applied at hoi_forecast/model/visual_to_tokens.py:279)
+ * and the CLIP q/k/v/out_proj/fc1/fc2 + patch-embed conv (clip_encoder.py:48).  Backward GEMMs
+ * (dX = dY @ W, dW = dY^T @ X) use the same entry point on transposed operands.
+ *   K % 64 == 0; lda/ldb/ldc/ldr in elements, multiples of 8; A,B,C 16-byte aligned.
+ *   bias (bf16[N]) / residual (bf16[M,ldr]) may be NULL.  out_f32 != 0 -> C is float32.
+ * ------------------------------------------------------------------------------------------ */
+int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda,
+                      int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
+                      int out_f32, void* stream);
+
+/* out[C,R] = in[R,C]^T (bf16), LDS-tiled.  Rows r >= R_valid of `in` are treated as zero when
+ * `R_pad` > R (out has leading dimension R_pad and its columns R..R_pad-1 are zero-filled): this
+ * builds the K-padded transposed operands for the dW GEMMs. */
+int hvlm_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int R_pad, void* stream);
+
+/* out[C] (f32) = sum over rows of in[R,C] (bf16): bias gradients (mm_projector.bias). */
+int hvlm_colsum_bf16(const void* in, float* out, int R, int C, int ld_in, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * RMSNorm — transformers LlamaRMSNorm.forward (x.float(), variance, rsqrt(var+eps), cast back,
+ * times weight), used (2L+1) times per LlamaModel.forward (handsonvlm.py:119).
+ *   fwd: y = bf16(bf16(x * rstd) * w), rstd[rows] (f32) saved when non-NULL.
+ *   bwd: dx = (add ? add : 0) + d(rmsnorm)/dx ; dw_partial[HVLM_NORM_BWD_BLOCKS, D] f32 partial
+ *        sums of dy * xhat, reduced by hvlm_reduce_rows_f32.
+ * ------------------------------------------------------------------------------------------ */
+#define HVLM_NORM_BWD_BLOCKS 256
+int hvlm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int D, float eps,
+                     void* stream);
+int hvlm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+                     const void* add, void* dx, float* dw_partial, int rows, int D, void* stream);
+/* out[D] = sum_r in[r, D]  (f32 -> bf16 when out_bf16 else f32); optional accumulate into out. */
+int hvlm_reduce_rows_f32(const float* in, void* out, int rows, int D, int out_bf16, void* stream);
+
+/* LayerNorm forward (CLIP pre_layrnorm / layer_norm1 / layer_norm2, eps 1e-5; clip_encoder.py:48
+ * -> transformers CLIPEncoderLayer).  y = bf16((x-mean)*rstd*w + b), fp32 statistics. */
+int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D,
+                       float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * RoPE — transformers apply_rotary_pos_emb / rotate_half (half-split, not interleaved), cited at
+ * llava/train/llama_flash_attn_monkey_patch.py:55-58.  In place on the q and k sections of the
+ * fused qkv buffer [M, 3*H*dh] (q at column 0, k at H*dh).  cos/sin: bf16 tables [max_pos, dh/2]
+ * (the reference casts the fp32 tables to the activation dtype); pos: int32[M].
+ * inverse != 0 applies the transposed rotation (backward pass).
+ * ------------------------------------------------------------------------------------------ */
+int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int32_t* pos, int M,
+                 int H, int dh, int ld, int inverse, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Attention (flash-style, MFMA, online softmax in fp32) on the fused qkv buffer.
+ * Replaces LlamaAttention's softmax(QK^T/sqrt(dh)+mask)V (eager) and the flash-attn call at
+ * llama_flash_attn_monkey_patch.py:81-94 (causal; key padding is at the right end so the causal
+ * mask alone decides, handsonvlm.py:441), and CLIPAttention (non-causal, dh=64).
+ *   qkv: bf16 [B*S, ld]  q at col 0, k at col H*dh, v at col 2*H*dh (per head dh contiguous)
+ *   out: bf16 [B*S, H*dh]; lse: f32 [B, H, S] (log-sum-exp of scaled scores; NULL to skip)
+ *   dh in {64, 128}.
+ *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): holds
+ *       the k-contiguous transposed operand copies (V^T forward; Q^T, K^T, dO^T and the
+ *       delta = rowsum(dO*O) vector backward) produced by an HBM-bound pre-pass.
+ * bwd: dqkv (same layout as qkv, fully written for rows < S) from dout [B*S, H*dh].
+ * ------------------------------------------------------------------------------------------ */
+size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh);
+size_t hvlm_attn_bwd_ws_bytes(int B, int S, int H, int dh);
+int hvlm_attn_fwd(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh,
+                  int ld, int causal, float scale, void* stream);
+int hvlm_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                  void* ws, int B, int S, int H, int dh, int ld, int causal, float scale,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * SwiGLU — transformers LlamaMLP: down(silu(gate(x)) * up(x)).  gu is the fused [M, 2F] output of
+ * the concatenated gate|up projection (gate in columns [0,F), up in [F,2F)).
+ * ------------------------------------------------------------------------------------------ */
+int hvlm_swiglu_fwd(const void* gu, void* act, int M, int F, void* stream);
+int hvlm_swiglu_bwd(const void* gu, const void* dact, void* dgu, int M, int F, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Visual-token pipeline
+ * ------------------------------------------------------------------------------------------ */
+/* im2col for the CLIP patch-embed conv (kernel = stride = P, no bias): images bf16
+ * [N,3,HW,HW] -> patches bf16 [N*(HW/P)^2, Kpad] (K = 3*P*P, zero-padded to Kpad). */
+int hvlm_patch_im2col(const void* images, void* patches, int N, int HW, int P, int Kpad, void* stream);
+/* tokens[n, 0, :] = cls + pos[0];  tokens[n, 1+p, :] = patch_out[n*NP+p, :] + pos[1+p]
+ * (transformers CLIPVisionEmbeddings). */
+int hvlm_clip_embed(const void* patch_out, const void* cls, const void* pos, void* tokens, int N,
+                    int NP, int D, void* stream);
+/* VisualToTokenHelper.compress_tokens('temporal_spatial_pool')
+ * (hoi_forecast/model/visual_to_tokens.py:252-272): tokens [B,T,256,D] -> out [B,T+256,D];
+ * rows [0,T): mean over the 256 patches of each frame; rows [T,T+256): frames
+ * round(linspace(0,T-1,4)) on their 16x16 grid, 2x2 average-pooled to 8x8.
+ * drop_cls != 0: the input has NP+1 tokens per frame and token 0 (CLS) is skipped
+ * (feature_select 'patch', clip_encoder.py:29-37). */
+int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,
+                                   int drop_cls, void* stream);
+/* backward of the above: dtokens [B,T,256,D] (fully written) from dout [B,T+256,D]. */
+int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D, void* stream);
+
+/* Multimodal splice (handsonvlm.py:212-451): builds inputs_embeds [B,S,D] where
+ *   src[b*S+s] >= 0  : row = embed_tokens[src]            (text token id)
+ *   src[b*S+s] == -1 : row = 0                             (right padding)
+ *   src[b*S+s] <= -2 : row = visual[b, -2-src]             (visual token index)
+ * and adds the <hand_traj> sinusoidal encoding (process_traj_positional_embedding,
+ * handsonvlm.py:310-338) to rows with hand_slot[b*S+s] >= 0:
+ *   + hand_scale[b] * posenc(hands[b, :, hand_slot, :])    (hands f32 [B,2,NH,2]).
+ * The scatter semantics of handsonvlm.py:368-375 (missing hand tokens fall on row 0 of the text
+ * chunk) are resolved on the host into (hand_slot, hand_scale). */
+int hvlm_embed_splice_fwd(const void* embed, const void* visual, const int32_t* src,
+                          const int32_t* hand_slot, const float* hands, const float* hand_scale,
+                          void* out, int B, int S, int D, int NV, int NH, void* stream);
+/* backward: scatter-add dX rows into dembed (f32 [V,D], atomics) and dvisual (bf16 [B,NV,D]). */
+int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* dembed, void* dvisual, int B,
+                          int S, int D, int NV, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Heads
+ * ------------------------------------------------------------------------------------------ */
+/* Shifted cross-entropy over bf16 logits [M, ldl] with V valid columns (handsonvlm.py:137-145:
+ * CrossEntropyLoss(mean over labels != -100)).  targets int32[M] already shifted by the host
+ * (target[m] = labels[m+1] within a sample, -100 at the last position / ignored).
+ *   loss_sum[0] += sum of -log p[target];  loss_sum[1] += number of valid targets.
+ *   when dlogits != NULL (may alias logits): dlogits = (softmax - onehot) * grad_scale[0] for
+ *   valid rows, 0 otherwise, zero in the padding columns [V, ldl).  grad_scale is a device f32. */
+int hvlm_ce_fwd(const void* logits, const int32_t* targets, float* loss_sum, float* row_lse, int M,
+                int V, int ldl, void* stream);
+int hvlm_ce_bwd(const void* logits, const int32_t* targets, const float* row_lse,
+                const float* grad_scale, void* dlogits, int M, int V, int ldl, void* stream);
+
+/* Hand-token gather (handsonvlm.py:146-187): out[b, hand, j, c] = hidden[row[b*4+j], 2*c + hand]
+ * (reshape(4, D/2, 2).permute(2,0,1)); row < 0 -> zeros.  out is f32 or bf16 [B,2,4,D/2]. */
+int hvlm_hand_gather_fwd(const void* hidden, const int32_t* rows, void* out, int B, int D,
+                         int out_f32, void* stream);
+/* backward: dhidden[row, 2*c+hand] += dout[b,hand,j,c] (rows are unique). dhidden is bf16 [M,D]. */
+int hvlm_hand_gather_bwd(const void* dout, const int32_t* rows, void* dhidden, int B, int D,
+                         int dout_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
+ * Optimizer / elementwise
+ * ------------------------------------------------------------------------------------------ */
+/* AdamW on fp32 master weights with bf16 gradients (scripts/finetune.sh:30-33: lr 2e-5, wd 0),
+ * writing the bf16 working copy W[R,C] and, when wt != NULL, its transpose WT[C,R] (operand of
+ * the dX GEMMs).  grad_scale multiplies the gradient (1/world for DP averaging, loss scaling).
+ * step >= 1. */
+int hvlm_adamw_step(float* master, float* m, float* v, const void* grad, void* w, void* wt, int R,
+                    int C, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, int step, void* stream);
+/* y = a + b (bf16, n elements). */
+int hvlm_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
+/* f32 -> bf16 and bf16 -> f32 casts (n elements). */
+int hvlm_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);
+int hvlm_cast_bf16_to_f32(const void* in, float* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVLM_H */
