@@ -91,7 +91,12 @@ def build_reference_model(cfg):
     tower.vision_tower = clip
     tower.select_layer = -2
     tower.select_feature = "patch"
-    model.model.vision_tower = tower
+    # Stored as a one-element list (the reference's own fsdp code path, llava/model/llava_arch.py:51-54;
+    # get_vision_tower() unwraps it): this keeps the CLIP modules out of LlamaModel's module tree.
+    # With transformers 5.x a CLIP registered under LlamaModel gets its hidden-state capture hooks
+    # installed twice after the first LlamaModel.forward, so hidden_states[-2] silently selects the
+    # wrong layer from the second forward on (a version-drift artefact, not reference behaviour).
+    model.model.vision_tower = [tower]
     model.model.mm_projector = nn.Linear(cfg["clip_d"], cfg["D"])
     params = synth.to_torch(synth.llama_params(cfg))
     missing, unexpected = model.load_state_dict(params, strict=False)
