@@ -1,0 +1,150 @@
+"""CLIP-ViT vision tower on the HIP kernels (forward only: the tower is frozen and runs under no_grad
+in the reference, llava/model/multimodal_encoder/clip_encoder.py:39-51).
+
+Mirror of `CLIPVisionTower`: `tower(images [N,3,H,W]) -> [N, 256, 1024]`, i.e.
+hidden_states[select_layer][:, 1:] of transformers' CLIPVisionModel.  `forward_tokens` additionally
+returns the un-sliced [N, 257, d] tensor so the pooling kernel can skip the CLS row without a copy.
+
+Per layer (all GEMMs = hvlm_gemm_bf16_nt with fused epilogues):
+    LN1 -> qkv GEMM (+bias) -> attention (non-causal, dh=64) -> out_proj GEMM (+bias, +residual)
+    LN2 -> fc1 GEMM (+bias, QuickGELU) -> fc2 GEMM (+bias, +residual)
+Only num_layers + 1 + select_layer layers are executed (23 of 24 for select_layer=-2): the reference
+computes the last layer and post_layernorm and discards them.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .config import CLIPVisionConfig
+
+BF16 = torch.bfloat16
+
+
+class CLIPVisionTower:
+    def __init__(self, cfg: CLIPVisionConfig, device, select_layer: int = -2, select_feature: str = "patch"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.select_layer = select_layer
+        self.select_feature = select_feature
+        self.is_loaded = False
+        d = cfg.hidden_size
+        self.kpad = (3 * cfg.patch_size ** 2 + 63) // 64 * 64
+        self.n_run = cfg.num_hidden_layers + 1 + select_layer if select_layer < 0 else select_layer
+        self.p: Dict[str, torch.Tensor] = {}
+
+    # -- properties the reference reads ---------------------------------------------------------
+    @property
+    def hidden_size(self):
+        return self.cfg.hidden_size
+
+    @property
+    def num_patches(self):
+        return self.cfg.num_patches
+
+    @property
+    def dtype(self):
+        return BF16
+
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=BF16)
+
+    # -- weights --------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = "vision_model."):
+        """Takes CLIPVisionModel keys (transformers 4.31 naming, `vision_model.*`)."""
+        cfg, dev = self.cfg, self.device
+        d = cfg.hidden_size
+        g = lambda k: sd[prefix + k].to(device=dev, dtype=BF16).contiguous()  # noqa: E731
+        p = {}
+        w = sd[prefix + "embeddings.patch_embedding.weight"].reshape(d, -1)
+        wp = torch.zeros(d, self.kpad, dtype=BF16, device=dev)
+        wp[:, : w.shape[1]] = w.to(device=dev, dtype=BF16)
+        p["patch_w"] = wp
+        p["cls"] = g("embeddings.class_embedding")
+        p["pos"] = g("embeddings.position_embedding.weight")
+        p["pre_ln_w"], p["pre_ln_b"] = g("pre_layrnorm.weight"), g("pre_layrnorm.bias")
+        for i in range(self.n_run):
+            lp = f"encoder.layers.{i}."
+            p[f"{i}.ln1_w"], p[f"{i}.ln1_b"] = g(lp + "layer_norm1.weight"), g(lp + "layer_norm1.bias")
+            p[f"{i}.ln2_w"], p[f"{i}.ln2_b"] = g(lp + "layer_norm2.weight"), g(lp + "layer_norm2.bias")
+            p[f"{i}.qkv_w"] = torch.cat([g(lp + f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
+            p[f"{i}.qkv_b"] = torch.cat([g(lp + f"self_attn.{n}.bias") for n in ("q_proj", "k_proj", "v_proj")], 0).contiguous()
+            p[f"{i}.o_w"], p[f"{i}.o_b"] = g(lp + "self_attn.out_proj.weight"), g(lp + "self_attn.out_proj.bias")
+            p[f"{i}.fc1_w"], p[f"{i}.fc1_b"] = g(lp + "mlp.fc1.weight"), g(lp + "mlp.fc1.bias")
+            p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = g(lp + "mlp.fc2.weight"), g(lp + "mlp.fc2.bias")
+        self.p = p
+        self.is_loaded = True
+        return self
+
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        """Random-init weights of the right shapes directly on the device (benchmarks)."""
+        cfg, dev = self.cfg, self.device
+        d, m = cfg.hidden_size, cfg.intermediate_size
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s, sc=std: (torch.randn(*s, device=dev, generator=gen) * sc).to(BF16)  # noqa: E731
+        p = {"patch_w": rn(d, self.kpad), "cls": rn(d), "pos": rn(cfg.num_patches + 1, d),
+             "pre_ln_w": torch.ones(d, device=dev, dtype=BF16), "pre_ln_b": torch.zeros(d, device=dev, dtype=BF16)}
+        p["patch_w"][:, 3 * cfg.patch_size ** 2:] = 0
+        for i in range(self.n_run):
+            for n in ("ln1", "ln2"):
+                p[f"{i}.{n}_w"] = torch.ones(d, device=dev, dtype=BF16)
+                p[f"{i}.{n}_b"] = torch.zeros(d, device=dev, dtype=BF16)
+            p[f"{i}.qkv_w"], p[f"{i}.qkv_b"] = rn(3 * d, d), rn(3 * d)
+            p[f"{i}.o_w"], p[f"{i}.o_b"] = rn(d, d), rn(d)
+            p[f"{i}.fc1_w"], p[f"{i}.fc1_b"] = rn(m, d), rn(m)
+            p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = rn(d, m), rn(d)
+        self.p = p
+        self.is_loaded = True
+        return self
+
+    # -- forward --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_tokens(self, images: torch.Tensor) -> torch.Tensor:
+        """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d]."""
+        cfg, p = self.cfg, self.p
+        assert self.is_loaded
+        N = images.shape[0]
+        d, heads = cfg.hidden_size, cfg.num_attention_heads
+        dh = d // heads
+        NP = cfg.num_patches
+        T = NP + 1
+        x_img = images.to(device=self.device, dtype=BF16).contiguous()
+        patches = ops.patch_im2col(x_img, cfg.patch_size, self.kpad)
+        pe = ops.gemm_nt(patches, p["patch_w"])
+        del patches
+        x = ops.clip_embed(pe, p["cls"], p["pos"], N, NP, d).view(N * T, d)
+        del pe
+        x = ops.layernorm_fwd(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
+        scale = dh ** -0.5
+        for i in range(self.n_run):
+            y = ops.layernorm_fwd(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
+            qkv = ops.gemm_nt(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
+            a, _ = ops.attn_fwd(qkv, N, T, heads, dh, False, scale, need_lse=False)
+            del qkv
+            x = ops.gemm_nt(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x)
+            y = ops.layernorm_fwd(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps, out=y)
+            hmid = ops.gemm_nt(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+            x = ops.gemm_nt(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x)
+            del hmid
+        return x.view(N, T, d)
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        """CLIPVisionTower.forward + feature_select (clip_encoder.py:29-51)."""
+        tok = self.forward_tokens(images)
+        if self.select_feature == "patch":
+            tok = tok[:, 1:]
+        elif self.select_feature != "cls_patch":
+            raise ValueError(f"Unexpected select feature: {self.select_feature}")
+        return tok.to(images.dtype if images.dtype.is_floating_point else BF16)
+
+    __call__ = forward
+
+    def flops_per_frame(self) -> float:
+        cfg = self.cfg
+        d, m, T = cfg.hidden_size, cfg.intermediate_size, cfg.num_patches + 1
+        per_layer = 2 * T * (4 * d * d + 2 * d * m) + 4 * T * T * d
+        return self.n_run * per_layer + 2 * cfg.num_patches * 3 * cfg.patch_size ** 2 * d

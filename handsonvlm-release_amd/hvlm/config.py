@@ -1,0 +1,76 @@
+"""Configuration of the HandsOnVLM hot path.  Field names follow the reference's config object
+(HandsOnVLMConfig(LlamaConfig) + the fields initialize_constants / initialize_vision_modules copy
+onto it: handsonvlm/model/handsonvlm_arch.py:34-45, llava/model/llava_arch.py:41-62) so that the
+flags of scripts/finetune.sh map 1:1."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+IGNORE_INDEX = -100        # handsonvlm/constants.py
+IMAGE_TOKEN_INDEX = -200   # handsonvlm/constants.py
+HAND_TOKEN_ID = 32100      # hard-coded at handsonvlm.py:146,349,609
+
+
+@dataclass
+class CLIPVisionConfig:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-5
+
+    @property
+    def num_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+
+@dataclass
+class HandsOnVLMConfig:
+    # LlamaConfig fields (Vicuna-7B v1.3 defaults)
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    vocab_size: int = 32101            # 32000 + 100 time tokens + <hand_traj>
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 10000.0
+    max_position_embeddings: int = 2048
+    pad_token_id: int = 0
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+    # multimodal fields
+    mm_vision_tower: str = "openai/clip-vit-large-patch14"
+    mm_hidden_size: int = 1024
+    mm_vision_select_layer: int = -2
+    mm_vision_select_feature: str = "patch"
+    fuse_input_mode: str = "origin"
+    video_compress_mode: str = "temporal_spatial_pool"
+    num_frames: int = 100
+    # loss weights (handsonvlm/arguments.py:104-109)
+    lambda_traj: float = 1.0
+    lambda_traj_kl: float = 1e-3
+    hoi_lambda: float = 1.0
+    traj_decoder_name: str = "CVAE"
+    # build-specific knobs (no reference counterpart)
+    project_after_pool: bool = True    # mm_projector commutes with the mean/avg pooling: 356 rows instead of 25 600
+    dedup_frames: bool = False         # run CLIP once per unique frame (EK100 tiles 10 frames x10)
+    clip_chunk_frames: int = 400       # frames per CLIP pass (bounds activation memory)
+    vision: CLIPVisionConfig = field(default_factory=CLIPVisionConfig)
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def vocab_padded(self) -> int:
+        return (self.vocab_size + 63) // 64 * 64
+
+    @classmethod
+    def vicuna_7b(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def vicuna_13b(cls, **kw):
+        return cls(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40, **kw)

@@ -1,0 +1,223 @@
+"""Vicuna/Llama decoder stack as an explicit forward/backward engine over the HIP kernels.
+
+Replaces transformers' LlamaModel.forward as called at handsonvlm.py:119-128 (inputs_embeds in,
+last hidden state out, position_ids = arange(S), causal mask; right padding needs no key mask).
+
+MI355X-first choices:
+  * token-major activations [M = B*S, features]; q/k/v live in ONE fused [M, 3D] buffer that the
+    attention kernel reads in place and whose gradient buffer feeds the qkv dW/dX GEMMs directly —
+    no [B,H,S,dh] permutes anywhere;
+  * gate|up fused into one [2F, D] GEMM; residual adds fused into the o_proj / down_proj epilogues;
+  * no activation recompute: with 288 GB of HBM3E the ~1.9 GB/layer of saved activations (7B,
+    B=16, S=868) fit, so backward costs 2x forward instead of the reference's 3x (gradient
+    checkpointing, scripts/finetune.sh:36);
+  * every weight keeps a resident transposed bf16 copy (written by the fused AdamW kernel) so dX
+    GEMMs are plain NT GEMMs on K-contiguous operands;
+  * weight gradients of one layer are views into ONE flat bf16 bucket (the RCCL all-reduce unit).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import HandsOnVLMConfig
+
+BF16 = torch.bfloat16
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class LayerParams:
+    """Fused per-layer parameter views over flat buffers (weights, transposes, grads)."""
+    NAMES = ("qkv", "o", "gu", "down", "ln1", "ln2")
+
+    def __init__(self, D: int, F: int, device, with_grad: bool, with_transpose: bool):
+        shapes = {"qkv": (3 * D, D), "o": (D, D), "gu": (2 * F, D), "down": (D, F), "ln1": (D,), "ln2": (D,)}
+        self.shapes = shapes
+        n = sum(math.prod(s) for s in shapes.values())
+        self.flat_w = torch.empty(n, dtype=BF16, device=device)
+        self.flat_g = torch.zeros(n, dtype=BF16, device=device) if with_grad else None
+        self.w: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        self.wt: Dict[str, torch.Tensor] = {}
+        off = 0
+        for k, s in shapes.items():
+            sz = math.prod(s)
+            self.w[k] = self.flat_w[off:off + sz].view(*s)
+            if with_grad:
+                self.g[k] = self.flat_g[off:off + sz].view(*s)
+            off += sz
+        if with_transpose:
+            for k in ("qkv", "o", "gu", "down"):
+                r, c = shapes[k]
+                self.wt[k] = torch.empty((c, r), dtype=BF16, device=device)
+
+    def refresh_transposes(self):
+        for k, t in self.wt.items():
+            ops.transpose(self.w[k], out=t)
+
+
+class LlamaStack:
+    def __init__(self, cfg: HandsOnVLMConfig, device, training: bool = True):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.training = training
+        D, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        self.D, self.F, self.L, self.H, self.dh = D, F, L, cfg.num_attention_heads, cfg.head_dim
+        assert D % 64 == 0 and F % 64 == 0, "hidden/intermediate sizes must be multiples of 64 (GEMM K tile)"
+        assert self.dh in (64, 128), "head_dim must be 64 or 128 (attention kernel)"
+        self.layers = [LayerParams(D, F, self.device, training, training) for _ in range(L)]
+        self.norm_w = torch.ones(D, dtype=BF16, device=self.device)
+        self.norm_g = torch.zeros(D, dtype=BF16, device=self.device) if training else None
+        # RoPE tables: fp32 cos/sin cast to bf16 like the reference's cos_cached.to(x.dtype)
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, self.dh, 2, dtype=torch.float32) / self.dh))
+        fr = torch.outer(torch.arange(cfg.max_position_embeddings, dtype=torch.float32), inv)
+        self.cos = fr.cos().to(BF16).to(self.device).contiguous()
+        self.sin = fr.sin().to(BF16).to(self.device).contiguous()
+        self.saved: List[dict] = []
+        self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        self.on_layer_grad_ready: Optional[Callable[[int], None]] = None   # DP hook: bucket i is final
+
+    # -- parameters -----------------------------------------------------------------------------
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        for lp in self.layers:
+            for k in ("qkv", "o", "gu", "down"):
+                lp.w[k].copy_((torch.randn(lp.shapes[k], device=self.device, generator=gen) * std).to(BF16))
+            lp.w["ln1"].fill_(1.0); lp.w["ln2"].fill_(1.0)
+            lp.refresh_transposes()
+        self.norm_w.fill_(1.0)
+
+    def load_hf(self, sd: Dict[str, torch.Tensor], prefix: str = "model."):
+        """HF-named Llama weights (model.layers.{i}.self_attn.q_proj.weight, ...) -> fused buffers."""
+        dev = self.device
+        g = lambda k: sd[prefix + k].to(device=dev, dtype=BF16)  # noqa: E731
+        for i, lp in enumerate(self.layers):
+            pre = f"layers.{i}."
+            lp.w["qkv"].copy_(torch.cat([g(pre + f"self_attn.{n}_proj.weight") for n in "qkv"], 0))
+            lp.w["o"].copy_(g(pre + "self_attn.o_proj.weight"))
+            lp.w["gu"].copy_(torch.cat([g(pre + "mlp.gate_proj.weight"), g(pre + "mlp.up_proj.weight")], 0))
+            lp.w["down"].copy_(g(pre + "mlp.down_proj.weight"))
+            lp.w["ln1"].copy_(g(pre + "input_layernorm.weight"))
+            lp.w["ln2"].copy_(g(pre + "post_attention_layernorm.weight"))
+            lp.refresh_transposes()
+        self.norm_w.copy_(g("norm.weight"))
+
+    def export_hf(self, prefix: str = "model.") -> Dict[str, torch.Tensor]:
+        D, F = self.D, self.F
+        out = {}
+        for i, lp in enumerate(self.layers):
+            pre = f"{prefix}layers.{i}."
+            q, k, v = lp.w["qkv"].split(D, 0)
+            out[pre + "self_attn.q_proj.weight"], out[pre + "self_attn.k_proj.weight"], out[pre + "self_attn.v_proj.weight"] = q, k, v
+            out[pre + "self_attn.o_proj.weight"] = lp.w["o"]
+            out[pre + "mlp.gate_proj.weight"], out[pre + "mlp.up_proj.weight"] = lp.w["gu"].split(F, 0)
+            out[pre + "mlp.down_proj.weight"] = lp.w["down"]
+            out[pre + "input_layernorm.weight"] = lp.w["ln1"]
+            out[pre + "post_attention_layernorm.weight"] = lp.w["ln2"]
+        out[prefix + "norm.weight"] = self.norm_w
+        return out
+
+    def _positions(self, B: int, S: int) -> torch.Tensor:
+        key = (B, S)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = torch.arange(S, dtype=torch.int32, device=self.device).repeat(B)
+        return self._pos_cache[key]
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
+                all_hidden: bool = False):
+        """x [B*S, D] bf16 -> final-normed hidden [B*S, D].  Saves activations for backward when
+        save (default: self.training)."""
+        save = self.training if save is None else save
+        cfg = self.cfg
+        M = B * S
+        assert x.shape == (M, self.D) and x.dtype == BF16 and S <= cfg.max_position_embeddings
+        pos = self._positions(B, S)
+        scale = self.dh ** -0.5
+        eps = cfg.rms_norm_eps
+        self.saved = []
+        hs = [x] if all_hidden else None
+        for lp in self.layers:
+            xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
+            qkv = ops.gemm_nt(xn, lp.w["qkv"])
+            ops.rope_qk_(qkv, self.cos, self.sin, pos, self.H, self.dh)
+            ao, lse = ops.attn_fwd(qkv, B, S, self.H, self.dh, True, scale, need_lse=save)
+            h = ops.gemm_nt(ao, lp.w["o"], residual=x)
+            hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
+            gu = ops.gemm_nt(hn, lp.w["gu"])
+            act = ops.swiglu_fwd(gu)
+            xo = ops.gemm_nt(act, lp.w["down"], residual=h)
+            if save:
+                self.saved.append(dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn,
+                                       gu=gu, act=act))
+            x = xo
+            if all_hidden:
+                hs.append(x)
+        hidden, rstd_f = ops.rmsnorm_fwd(x, self.norm_w, eps, save_rstd=save)
+        if save:
+            self.final = dict(x=x, rstd=rstd_f)
+            self.BS = (B, S)
+        if all_hidden:
+            hs[-1] = hidden
+            return hidden, hs
+        return hidden
+
+    # -- backward -------------------------------------------------------------------------------
+    def _dw(self, dy: torch.Tensor, xin: torch.Tensor, out: torch.Tensor, mpad: int):
+        """out[N,K] = dy[M,N]^T @ xin[M,K]  via K-contiguous transposed copies (zero-padded to mpad)."""
+        dyT = ops.transpose(dy, r_pad=mpad)
+        xT = ops.transpose(xin, r_pad=mpad)
+        ops.gemm_nt(dyT, xT, out=out)
+
+    def backward(self, dhidden: torch.Tensor) -> torch.Tensor:
+        """dhidden [M, D] (grad of the final-normed hidden) -> dx [M, D]; weight grads are written
+        (not accumulated) into the per-layer buckets."""
+        assert self.training and self.saved, "forward(save=True) must precede backward"
+        B, S = self.BS
+        M = B * S
+        mpad = _round_up(M, 64)
+        scale = self.dh ** -0.5
+        pos = self._positions(B, S)
+        dx, dwn = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"])
+        self.norm_g.copy_(dwn)
+        for i in range(self.L - 1, -1, -1):
+            lp, sv = self.layers[i], self.saved[i]
+            # ---- MLP ----
+            dact = ops.gemm_nt(dx, lp.wt["down"])                      # [M,F] = dx @ Wd
+            self._dw(dx, sv["act"], lp.g["down"], mpad)                 # dWd[D,F]
+            dgu = ops.swiglu_bwd(sv["gu"], dact)
+            del dact
+            dhn = ops.gemm_nt(dgu, lp.wt["gu"])                        # [M,D]
+            self._dw(dgu, sv["hn"], lp.g["gu"], mpad)
+            del dgu
+            dh, dw2 = ops.rmsnorm_bwd(dhn, sv["h"], lp.w["ln2"], sv["rstd2"], add=dx)
+            lp.g["ln2"].copy_(dw2)
+            # ---- attention ----
+            dao = ops.gemm_nt(dh, lp.wt["o"])
+            self._dw(dh, sv["ao"], lp.g["o"], mpad)
+            dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale)
+            ops.rope_qk_(dqkv, self.cos, self.sin, pos, self.H, self.dh, inverse=True)
+            dxn = ops.gemm_nt(dqkv, lp.wt["qkv"])
+            self._dw(dqkv, sv["xn"], lp.g["qkv"], mpad)
+            del dqkv, dao
+            dx, dw1 = ops.rmsnorm_bwd(dxn, sv["x"], lp.w["ln1"], sv["rstd1"], add=dh)
+            lp.g["ln1"].copy_(dw1)
+            self.saved[i] = None
+            if self.on_layer_grad_ready is not None:
+                self.on_layer_grad_ready(i)
+        self.saved = []
+        return dx
+
+    # -- bookkeeping ----------------------------------------------------------------------------
+    def gemm_params_per_layer(self) -> int:
+        return 4 * self.D * self.D + 3 * self.D * self.F
+
+    def flops_forward(self, B: int, S: int, vocab: int) -> float:
+        """Algorithmic forward FLOPs (2/MAC, causal attention counted at half)."""
+        return B * (2.0 * S * (self.L * self.gemm_params_per_layer() + self.D * vocab) + 0.5 * 4.0 * S * S * self.D * self.L)

@@ -1,0 +1,513 @@
+"""HandsOnVLMForCausalLM on the MI355X kernels — host-side mirror of the reference interface.
+
+Keeps the keyword signatures of handsonvlm/model/language_model/handsonvlm.py:
+    forward(input_ids, attention_mask, past_key_values, inputs_embeds, labels, image, future_hands,
+            contact_point, future_valid, gt_label_valid, use_cache, output_attentions,
+            output_hidden_states, return_dict, **kwargs)  -> CausalLMOutputWithPast-like (:70-210)
+    sample(input_ids, logits_processor, stopping_criteria, logits_warper, ..., **model_kwargs)
+            -> SampleDecoderOnlyOutput(sequences, pred_hands)                             (:478-672)
+    generate(input_ids, image=..., do_sample, temperature, top_p, max_new_tokens, ...)
+so the reference's training recipe (`model(**batch).loss.backward()`) and evaluation recipe
+(`model.generate(input_ids, image=...)` -> `.sequences`, `.pred_hands`) map onto it unchanged.
+Unknown collator keys (prompt, feat, bbox_feat, valid_mask ...) are swallowed by **kwargs.
+
+Everything heavy runs through the C ABI (hvlm.ops); the CVAE head and the loss assembly stay in
+PyTorch.  There is no torch fallback for the kernels.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .clip import CLIPVisionTower
+from .config import HAND_TOKEN_ID, IGNORE_INDEX, IMAGE_TOKEN_INDEX, HandsOnVLMConfig
+from .llama import LlamaStack, _round_up
+from .traj_decoder import CVAETrajDecoder, MLPTrajDecoder
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class CausalLMOutputWithPast:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[object] = None
+    loss_components: Optional[Dict[str, torch.Tensor]] = None   # text / traj / kl (the reference logs them to wandb)
+
+    def __getitem__(self, i):
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions)
+                     if v is not None)[i]
+
+
+@dataclass
+class SampleDecoderOnlyOutput:
+    sequences: torch.Tensor = None
+    scores: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+    hidden_states: Optional[tuple] = None
+    pred_hands: Optional[torch.Tensor] = None
+
+
+@dataclass
+class SplicePlan:
+    """Host-resolved layout of inputs_embeds (handsonvlm.py:212-451)."""
+    B: int
+    S: int
+    src: torch.Tensor          # int32 [B*S]: >=0 token id, -1 pad, <=-2 visual index
+    hand_slot: torch.Tensor    # int32 [B*S]: which hand encoding is added on this row, -1 none
+    hand_scale: torch.Tensor   # f32 [B]
+    labels: Optional[torch.Tensor]    # int64 [B,S] (device) or None
+    targets: Optional[torch.Tensor]   # int32 [B*S] shifted labels
+    hand_rows: Optional[torch.Tensor]  # int32 [B*4] rows preceding each <hand_traj> label, -1 if none
+    has_hand: Optional[np.ndarray]    # bool [B]
+    lengths: np.ndarray
+
+
+class _EngineLoss(torch.autograd.Function):
+    """Bridges `loss.backward()` to the explicit engine backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, value):
+        ctx.model = model
+        return value.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.model.backward(g)
+        return None, None, None
+
+
+class HandsOnVLMForCausalLM:
+    def __init__(self, config: HandsOnVLMConfig, device="cuda:0", training: bool = True, **kwargs):
+        self.config = config
+        self.device = torch.device(device)
+        self.training = training
+        self.token_dim = config.hidden_size
+        D, V, Vp = config.hidden_size, config.vocab_size, config.vocab_padded
+        dev = self.device
+        self.traj_decoder_name = kwargs.get("traj_decoder_name", config.traj_decoder_name)
+        self.tower = CLIPVisionTower(config.vision, dev, config.mm_vision_select_layer, config.mm_vision_select_feature)
+        self.stack = LlamaStack(config, dev, training)
+        self.embed = torch.zeros(V, D, dtype=BF16, device=dev)
+        self.lm_head = torch.zeros(Vp, D, dtype=BF16, device=dev)          # rows >= V stay zero
+        self.proj_w = torch.zeros(D, config.mm_hidden_size, dtype=BF16, device=dev)
+        self.proj_b = torch.zeros(D, dtype=BF16, device=dev)
+        if training:
+            self.lm_head_t = torch.zeros(D, Vp, dtype=BF16, device=dev)
+            self.embed_g = torch.zeros(V, D, dtype=BF16, device=dev)
+            self.embed_g32 = torch.zeros(V, D, dtype=torch.float32, device=dev)
+            self.lm_head_g = torch.zeros(Vp, D, dtype=BF16, device=dev)
+            self.proj_w_g = torch.zeros_like(self.proj_w)
+            self.proj_b_g = torch.zeros_like(self.proj_b)
+        dec = CVAETrajDecoder if self.traj_decoder_name == "CVAE" else MLPTrajDecoder
+        self.hand_traj_decoder = dec(token_dim=D // 2).to(dev)              # fp32 host-side head
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        self._ctx: Optional[dict] = None
+        self.on_grads_ready: Optional[Callable[[str], None]] = None         # DP hook for the non-layer bucket
+
+    # ------------------------------------------------------------------------------------------
+    # parameters / checkpoints
+    # ------------------------------------------------------------------------------------------
+    def train(self, mode: bool = True):
+        self.hand_traj_decoder.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def get_vision_tower(self):
+        return self.tower
+
+    def init_random(self, seed: int = 0, std: float = 0.02):
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        rn = lambda *s: (torch.randn(*s, device=self.device, generator=gen) * std).to(BF16)  # noqa: E731
+        self.embed.copy_(rn(*self.embed.shape))
+        self.lm_head[: self.config.vocab_size].copy_(rn(self.config.vocab_size, self.token_dim))
+        self.proj_w.copy_(rn(*self.proj_w.shape))
+        self.proj_b.zero_()
+        self.stack.init_random(seed + 1, std)
+        self.tower.init_random(seed + 2, std)
+        self._refresh_transposes()
+        return self
+
+    def _refresh_transposes(self):
+        if self.training:
+            ops.transpose(self.lm_head, out=self.lm_head_t)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Reference-named state dict: model.embed_tokens.weight, model.layers.*,
+        model.norm.weight, lm_head.weight, model.mm_projector.*, model.vision_tower.vision_tower.*,
+        hand_traj_decoder.*.  Unused reference tensors (time_embedding, bbox_to_feature ...) are ignored."""
+        dev = self.device
+        V = self.config.vocab_size
+        self.embed.copy_(sd["model.embed_tokens.weight"].to(dev, BF16))
+        self.lm_head[:V].copy_(sd["lm_head.weight"].to(dev, BF16))
+        self.proj_w.copy_(sd["model.mm_projector.weight"].to(dev, BF16))
+        self.proj_b.copy_(sd["model.mm_projector.bias"].to(dev, BF16))
+        self.stack.load_hf(sd, "model.")
+        head = {k[len("hand_traj_decoder."):]: v for k, v in sd.items() if k.startswith("hand_traj_decoder.")}
+        if head:
+            self.hand_traj_decoder.load_state_dict({k: v.to(torch.float32) for k, v in head.items()}, strict=True)
+        vt = "model.vision_tower.vision_tower."
+        if any(k.startswith(vt) for k in sd):
+            self.tower.load_state_dict({k[len(vt):]: v for k, v in sd.items() if k.startswith(vt)})
+        self._refresh_transposes()
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        V = self.config.vocab_size
+        out = {"model.embed_tokens.weight": self.embed, "lm_head.weight": self.lm_head[:V],
+               "model.mm_projector.weight": self.proj_w, "model.mm_projector.bias": self.proj_b}
+        out.update(self.stack.export_hf("model."))
+        out.update({"hand_traj_decoder." + k: v for k, v in self.hand_traj_decoder.state_dict().items()})
+        return out
+
+    def trainable_tensors(self) -> List[Tuple[str, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]:
+        """(name, weight bf16, grad bf16, transposed copy or None) for every kernel-side parameter."""
+        out = []
+        for i, lp in enumerate(self.stack.layers):
+            for k in lp.NAMES:
+                out.append((f"layers.{i}.{k}", lp.w[k], lp.g[k], lp.wt.get(k)))
+        out.append(("norm", self.stack.norm_w, self.stack.norm_g, None))
+        out.append(("embed", self.embed, self.embed_g, None))
+        out.append(("lm_head", self.lm_head, self.lm_head_g, self.lm_head_t))
+        out.append(("proj_w", self.proj_w, self.proj_w_g, None))
+        out.append(("proj_b", self.proj_b, self.proj_b_g, None))
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # visual tokens (VisualToTokenHelper.pipeline, 'origin' + 'temporal_spatial_pool')
+    # ------------------------------------------------------------------------------------------
+    def visual_tokens(self, image: torch.Tensor, keep_for_backward: bool = False) -> torch.Tensor:
+        cfg = self.config
+        B, T = image.shape[:2]
+        assert cfg.fuse_input_mode == "origin" and cfg.video_compress_mode == "temporal_spatial_pool", \
+            "only fuse_input_mode='origin' + video_arch='temporal_spatial_pool' are on the hot path"
+        d = cfg.mm_hidden_size
+        frames = image.reshape(B * T, *image.shape[2:])
+        inv = None
+        if cfg.dedup_frames:
+            # EK100 clips tile 10 frames x10 (handsonvlm/dataset/epic_dataset.py:90-95): encode unique frames once
+            flat = frames.reshape(B * T, -1)
+            keep = torch.ones(B * T, dtype=torch.bool, device=frames.device)
+            keep[1:] = (flat[1:] != flat[:-1]).any(dim=1)
+            inv = torch.cumsum(keep.to(torch.int64), 0) - 1
+            frames = frames[keep]
+        n = frames.shape[0]
+        chunks = []
+        for s in range(0, n, cfg.clip_chunk_frames):
+            chunks.append(self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames]))
+        tok = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)          # [n, 257, d]
+        if inv is not None:
+            tok = tok[inv]
+        tok = tok.contiguous()
+        NV = T + 256
+        if cfg.project_after_pool:
+            pooled = ops.temporal_spatial_pool_fwd(tok, B, T, drop_cls=True).view(B * NV, d)
+            vis = ops.gemm_nt(pooled, self.proj_w, bias=self.proj_b)
+            if keep_for_backward:
+                self._vis_saved = dict(pooled=pooled)
+        else:
+            feats = tok[:, 1:].contiguous().view(B * T * 256, d)
+            ptok = ops.gemm_nt(feats, self.proj_w, bias=self.proj_b)
+            vis = ops.temporal_spatial_pool_fwd(ptok, B, T, drop_cls=False).view(B * NV, self.token_dim)
+            if keep_for_backward:
+                self._vis_saved = dict(feats=feats)
+        return vis.view(B, NV, self.token_dim)
+
+    # ------------------------------------------------------------------------------------------
+    # splice plan (host)
+    # ------------------------------------------------------------------------------------------
+    def build_splice_plan(self, input_ids, labels, NV: int, n_hands: int, is_evaluate: bool,
+                          has_future_hands: bool) -> SplicePlan:
+        ids = input_ids.detach().cpu().numpy().astype(np.int64)
+        lab = None if labels is None else labels.detach().cpu().numpy().astype(np.int64)
+        B, T = ids.shape
+        rows_src, rows_lab, rows_slot, scales = [], [], [], []
+        for b in range(B):
+            img = np.nonzero(ids[b] == IMAGE_TOKEN_INDEX)[0]
+            if img.size == 0:
+                src = ids[b].copy()
+                nl = None if lab is None else lab[b].copy()
+                slot = np.full(T, -1, dtype=np.int64)
+                scale = 0.0
+            else:
+                if img.size != 1:
+                    raise NotImplementedError("one <image> token per sample (the reference indexes visual tokens "
+                                              "with a running counter, handsonvlm.py:231-300)")
+                p = int(img[0])
+                tail = ids[b, p + 1:]
+                src = np.concatenate([ids[b, :p], -2 - np.arange(NV), tail])
+                nl = None if lab is None else np.concatenate([lab[b, :p], np.full(NV, IGNORE_INDEX), lab[b, p + 1:]])
+                slot = np.full(src.shape[0], -1, dtype=np.int64)
+                ts = p + NV
+                scale = 0.0
+                if tail.size > 0:
+                    hp = np.nonzero(tail == HAND_TOKEN_ID)[0]
+                    cnt = hp.size
+                    if not is_evaluate:
+                        assert cnt <= 4, f"more than 4 <hand_traj> tokens ({cnt})"
+                        idx = list(hp) + [0] * (4 - cnt)           # missing ones land on row 0 of the chunk
+                        for j in range(4):
+                            slot[ts + idx[j]] = j                  # scatter: later write wins (:368-375)
+                        scale = cnt / 4.0
+                    elif has_future_hands:
+                        assert n_hands == cnt, f"gt_hand_num: {n_hands}, hand_token_cnt: {cnt}"
+                        for j in range(cnt):
+                            slot[ts + hp[j]] = j
+                        scale = 1.0
+            rows_src.append(src); rows_lab.append(nl); rows_slot.append(slot); scales.append(scale)
+        lengths = np.array([r.shape[0] for r in rows_src])
+        S = int(lengths.max())
+        src = np.full((B, S), -1, dtype=np.int32)
+        slot = np.full((B, S), -1, dtype=np.int32)
+        nl = None if lab is None else np.full((B, S), IGNORE_INDEX, dtype=np.int64)
+        for b in range(B):
+            n = lengths[b]
+            src[b, :n] = rows_src[b]; slot[b, :n] = rows_slot[b]
+            if nl is not None:
+                nl[b, :n] = rows_lab[b]
+        dev = self.device
+        targets = hand_rows = has_hand = None
+        if nl is not None:
+            tg = np.full((B, S), IGNORE_INDEX, dtype=np.int32)
+            tg[:, :-1] = nl[:, 1:]
+            targets = torch.from_numpy(tg.reshape(-1)).to(dev)
+            hr = np.full((B, 4), -1, dtype=np.int32)
+            has_hand = np.zeros(B, dtype=bool)
+            for b in range(B):
+                pos = np.nonzero(nl[b, 1:] == HAND_TOKEN_ID)[0]    # shifted mask (:167-170)
+                if pos.size:
+                    assert pos.size == 4, f"expected 4 <hand_traj> labels, got {pos.size}"
+                    hr[b] = b * S + pos
+                    has_hand[b] = True
+            hand_rows = torch.from_numpy(hr.reshape(-1)).to(dev)
+        return SplicePlan(B=B, S=S, src=torch.from_numpy(src.reshape(-1)).to(dev),
+                          hand_slot=torch.from_numpy(slot.reshape(-1)).to(dev),
+                          hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
+                          labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets,
+                          hand_rows=hand_rows, has_hand=has_hand, lengths=lengths)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
+                image=None, future_hands=None, contact_point=None, future_valid=None, gt_label_valid=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+        cfg = self.config
+        dev = self.device
+        B = image.shape[0]
+        if labels is not None:
+            assert future_hands.shape == (B, 2, 5, 2), future_hands.shape
+            assert contact_point is None or contact_point.shape == (B, 2), contact_point.shape
+            assert future_valid.shape == (B, 2), future_valid.shape
+            assert gt_label_valid is None or gt_label_valid.shape == (B,), gt_label_valid.shape
+            future_hands = future_hands[:, :, 1:, :]
+        assert image.dim() == 5 and image.shape[:3] == (B, cfg.num_frames, 3), image.shape
+        assert not use_cache and past_key_values is None, "KV cache is handled inside sample(); forward is cache-less"
+        is_evaluate = kwargs.get("is_evaluate", False)
+        training_pass = labels is not None and self.training
+        T = input_ids.shape[1]
+
+        vis = kwargs.get("visual_tokens")
+        if vis is None:
+            vis = self.visual_tokens(image.to(dev), keep_for_backward=training_pass)
+        NV = vis.shape[1]
+        n_hands = 0 if future_hands is None else future_hands.shape[2]
+        plan = self.build_splice_plan(input_ids, labels, NV, n_hands, is_evaluate, future_hands is not None)
+        S = plan.S
+        assert S <= cfg.max_position_embeddings, f"spliced length {S} exceeds max_position_embeddings"
+        hands_dev = None
+        if future_hands is not None and n_hands > 0:
+            hands_dev = future_hands.detach().to(dev, torch.float32).contiguous()
+        x = ops.embed_splice_fwd(self.embed, vis, plan.src, plan.hand_slot if hands_dev is not None else None,
+                                 hands_dev, plan.hand_scale if hands_dev is not None else None, B, S, self.token_dim,
+                                 NV, max(n_hands, 1))
+        if output_hidden_states:
+            hidden, hs = self.stack.forward(x, B, S, save=training_pass, all_hidden=True)
+            hs = tuple(h.view(B, S, -1) for h in hs)
+        else:
+            hidden, hs = self.stack.forward(x, B, S, save=training_pass), None
+        last_only = kwargs.get("last_logits_only", False) and labels is None
+        if last_only:
+            rows = torch.from_numpy((np.arange(B) * S + plan.lengths - 1).astype(np.int64)).to(dev)
+            self._last_hidden = hidden[rows].contiguous()                     # read by sample() on <hand_traj>
+            logits_p = ops.gemm_nt(self._last_hidden, self.lm_head)
+            logits = logits_p[:, : cfg.vocab_size].unsqueeze(1)
+        else:
+            logits_p = ops.gemm_nt(hidden, self.lm_head)                     # [M, Vpad] bf16
+            logits = logits_p.view(B, S, -1)[:, :, : cfg.vocab_size]
+        loss = comps = None
+        if labels is not None:
+            acc, row_lse = ops.ce_fwd(logits_p, plan.targets, cfg.vocab_size)
+            loss_text = acc[0] / acc[1]
+            # hand-token gather (:146-187); samples without hand labels get zeros and future_valid[b] = 0
+            fv = future_valid
+            if not plan.has_hand.all():
+                fv[torch.from_numpy(~plan.has_hand).to(fv.device)] = 0      # in place, like the reference (:178)
+            emb = ops.hand_gather_fwd(hidden, plan.hand_rows, B, self.token_dim, torch.float32)
+            emb.requires_grad_(training_pass)
+            with torch.enable_grad():
+                tl = self.hand_traj_decoder(emb, future_hands.to(dev, torch.float32), fv.to(dev, torch.float32),
+                                            cfg.lambda_traj, cfg.lambda_traj_kl, eps=kwargs.get("cvae_eps"))
+                head_loss = cfg.hoi_lambda * tl["total_loss"]
+            value = head_loss.detach() + loss_text
+            comps = {"text loss": loss_text, "traj_loss": tl["traj_loss"].detach(), "traj_kl_loss": tl["traj_kl_loss"].detach()}
+            if training_pass:
+                self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb,
+                                 head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1])
+                loss = _EngineLoss.apply(self._anchor, self, value)
+            else:
+                loss = value
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None,
+                                     loss_components=comps)
+        if return_dict is False:
+            return (loss, logits) if loss is not None else (logits,)
+        return out
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------------
+    # backward (explicit engine; also reached through loss.backward())
+    # ------------------------------------------------------------------------------------------
+    def backward(self, grad_scale=None):
+        """Back-propagates d(loss)*grad_scale into every trainable tensor's grad buffer (overwrite)."""
+        c = self._ctx
+        assert c is not None, "forward with labels (training) must precede backward"
+        self._ctx = None
+        cfg, dev = self.config, self.device
+        plan, B, S, NV = c["plan"], c["B"], c["S"], c["NV"]
+        M = B * S
+        mpad = _round_up(M, 64)
+        if grad_scale is None:
+            grad_scale = torch.ones((), device=dev)
+        grad_scale = grad_scale.to(dev, torch.float32).reshape(())
+        gs = (grad_scale / c["n_valid"]).reshape(1).contiguous()
+        dlogits = ops.ce_bwd_(c["logits_p"], plan.targets, c["row_lse"], gs, cfg.vocab_size)
+        dhidden = ops.gemm_nt(dlogits, self.lm_head_t)                        # [M, D]
+        self.stack._dw(dlogits, c["hidden"], self.lm_head_g, mpad)
+        del dlogits
+        c["logits_p"] = None
+        # CVAE head (PyTorch autograd): grads of the head's own params + d(emb)
+        for p in self.hand_traj_decoder.parameters():
+            p.grad = None
+        with torch.enable_grad():
+            (c["head_loss"] * grad_scale).backward()
+        ops.hand_gather_bwd_(c["emb"].grad.contiguous(), plan.hand_rows, dhidden, B, self.token_dim)
+        if self.on_grads_ready is not None:
+            self.on_grads_ready("head")
+        dx = self.stack.backward(dhidden)
+        self.embed_g32.zero_()
+        dvis = torch.empty((B * NV, self.token_dim), dtype=BF16, device=dev)
+        ops.embed_splice_bwd(dx, plan.src, self.embed_g32, dvis, B, S, self.token_dim, NV)
+        ops.cast_f32_to_bf16(self.embed_g32, out=self.embed_g)
+        sv = self._vis_saved
+        if cfg.project_after_pool:
+            self.stack._dw(dvis, sv["pooled"], self.proj_w_g, _round_up(B * NV, 64))
+            ops.cast_f32_to_bf16(ops.colsum(dvis), out=self.proj_b_g)
+        else:
+            dtok = ops.temporal_spatial_pool_bwd(dvis.view(B, NV, -1), B, c["T"]).view(-1, self.token_dim)
+            self.stack._dw(dtok, sv["feats"], self.proj_w_g, _round_up(dtok.shape[0], 64))
+            ops.cast_f32_to_bf16(ops.colsum(dtok), out=self.proj_b_g)
+        self._vis_saved = None
+        if self.on_grads_ready is not None:
+            self.on_grads_ready("tail")
+
+    # ------------------------------------------------------------------------------------------
+    # generation (custom sampling loop of the reference, batch 1)
+    # ------------------------------------------------------------------------------------------
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      **kwargs):
+        return {"input_ids": input_ids, "past_key_values": None, "use_cache": False, "attention_mask": attention_mask,
+                "image": kwargs.get("image"), "is_evaluate": True}
+
+    @torch.no_grad()
+    def sample(self, input_ids, logits_processor=None, stopping_criteria=None, logits_warper=None, max_length=None,
+               pad_token_id=None, eos_token_id=None, output_attentions=None, output_hidden_states=None,
+               output_scores=None, return_dict_in_generate=None, synced_gpus=False, streamer=None, **model_kwargs):
+        """Multinomial sampling loop with hand decoding on token 32100 (handsonvlm.py:478-672).
+        Batch 1 (the reference calls .item() on the sampled token).  Differences from the reference,
+        none of which change results: the CLIP tower runs once per call instead of once per generated
+        token (visual tokens do not depend on the text), and only the last position's logits are
+        computed.  `hand_noise` (optional list of z tensors [2, latent], already scaled) pins the
+        CVAE noise for reproducible tests."""
+        cfg, dev = self.config, self.device
+        assert input_ids.shape[0] == 1, "sample() is batch-1 like the reference"
+        procs = list(logits_processor or []) + list(logits_warper or [])
+        pad_token_id = cfg.pad_token_id if pad_token_id is None else pad_token_id
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        eos = [eos] if isinstance(eos, int) else list(eos)
+        image = model_kwargs.get("image")
+        hand_noise = model_kwargs.get("hand_noise")
+        vis = self.visual_tokens(image.to(dev))
+        input_ids = input_ids.to(dev)
+        pred_hands: List[torch.Tensor] = []
+        scores = []
+        n_new = 0
+        while True:
+            fh = torch.stack(pred_hands, dim=2) if pred_hands else None
+            out = self.forward(input_ids=input_ids, image=image, future_hands=fh, is_evaluate=True, visual_tokens=vis,
+                               last_logits_only=True, output_hidden_states=False)
+            next_scores = out.logits[:, -1, :].float()
+            for proc in procs:
+                next_scores = proc(input_ids, next_scores)
+            if output_scores:
+                scores.append(next_scores)
+            probs = torch.softmax(next_scores, dim=-1)
+            next_tokens = torch.multinomial(probs, num_samples=1).squeeze(1)
+            tok = int(next_tokens.item())
+            if tok == HAND_TOKEN_ID:
+                h = self._last_hidden                                           # [1, D]
+                emb = h.float().reshape(1, self.token_dim // 2, 2).permute(0, 2, 1).unsqueeze(2)   # [1,2,1,D/2]
+                z = None if hand_noise is None else hand_noise[len(pred_hands)].to(dev, torch.float32)
+                pred_hands.append(self.hand_traj_decoder.inference(emb, z).squeeze(2))
+            input_ids = torch.cat([input_ids, next_tokens[:, None]], dim=-1)
+            n_new += 1
+            if streamer is not None:
+                streamer.put(next_tokens.cpu())
+            done = tok in eos
+            if stopping_criteria is not None:
+                sc = stopping_criteria(input_ids, None)
+                done = done or bool(sc.all() if torch.is_tensor(sc) else sc)
+            if max_length is not None and input_ids.shape[1] >= max_length:
+                done = True
+            if done:
+                break
+        if streamer is not None:
+            streamer.end()
+        ph = torch.stack(pred_hands, dim=2) if pred_hands else torch.empty(1, 2, 0, 2, device=dev)
+        if return_dict_in_generate is False:
+            return input_ids
+        return SampleDecoderOnlyOutput(sequences=input_ids, scores=tuple(scores) if output_scores else None,
+                                       pred_hands=ph)
+
+    @torch.no_grad()
+    def generate(self, input_ids, image=None, do_sample=True, temperature=1.0, top_p=1.0, num_beams=1,
+                 max_new_tokens=100, use_cache=False, output_hidden_states=True, return_dict_in_generate=True, **kw):
+        """The call made by handsonvlm/evaluation/handsonvlm_inference.py:99-109."""
+        assert num_beams == 1
+        procs = []
+        if do_sample and temperature != 1.0:
+            procs.append(lambda ids, s: s / temperature)
+        if do_sample and top_p < 1.0:
+            procs.append(lambda ids, s: _top_p_filter(s, top_p))
+        if not do_sample:
+            procs.append(lambda ids, s: torch.full_like(s, float("-inf")).scatter(1, s.argmax(-1, keepdim=True), 0.0))
+        return self.sample(input_ids, logits_processor=procs, max_length=input_ids.shape[1] + max_new_tokens,
+                           image=image, return_dict_in_generate=return_dict_in_generate, **kw)
+
+
+def _top_p_filter(scores: torch.Tensor, top_p: float) -> torch.Tensor:
+    """TopPLogitsWarper (transformers): keep the smallest set of tokens with cumulative prob >= top_p."""
+    sorted_logits, sorted_idx = torch.sort(scores, descending=False)
+    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    remove = cum <= (1 - top_p)
+    remove[..., -1:] = False
+    remove = remove.scatter(1, sorted_idx, remove)
+    return scores.masked_fill(remove, float("-inf"))
