@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""bench.py — HandsOnVLM-7B supervised-fine-tuning step on N MI355X GPUs of one node.
+
+Metric (BASELINE.json): SFT samples/sec, HandsOnVLM-7B.  One "step" = one full SFT step of the hot path
+on one synthetic minibatch per GPU (reference-equivalent work: CLIP-ViT-L/14 on all 100 frames of every
+sample -> mm_projector -> pooling -> splice -> 32-layer Vicuna decoder fwd+bwd -> lm_head/CE + CVAE head
+-> gradient all-reduce (N>1) -> AdamW).  Per-GPU batch is fixed (weak scaling), inputs are resident in
+HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  "roofline":     dominant kernel (gemm_bf16_nt_kernel, MFMA-bound): algorithmic FLOPs of all its launches
+                  in the timed region / their summed duration (HIP events on the launch stream), vs the
+                  dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
+  "cpu_baseline": the CPU oracle (oracle/ref_cpu.py, a port of the reference's eager fp32 path) timed on
+                  this host's cores on a bounded sample and scaled to samples/s (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (scripts/finetune.sh:20)")
+    ap.add_argument("--text-len", type=int, default=512, help="prompt tokens T; S = T + 355")
+    ap.add_argument("--unique-frames", type=int, default=10, help="EK100 tiles 10 frames x10 -> 100")
+    ap.add_argument("--dedup", action="store_true", help="encode unique frames once (reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
+    return ap.parse_args()
+
+
+def make_config(args):
+    from hvlm.config import CLIPVisionConfig, HandsOnVLMConfig
+    if args.model == "7b":
+        cfg = HandsOnVLMConfig.vicuna_7b()
+    elif args.model == "13b":
+        cfg = HandsOnVLMConfig.vicuna_13b()
+    else:
+        cfg = HandsOnVLMConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                               mm_hidden_size=64, vision=CLIPVisionConfig(hidden_size=64, intermediate_size=128,
+                                                                          num_hidden_layers=3, num_attention_heads=1))
+    if args.layers is not None:
+        cfg.num_hidden_layers = args.layers
+    cfg.dedup_frames = args.dedup
+    return cfg
+
+
+def make_batch(cfg, B, T, unique, seed, device):
+    """Synthetic EK100-shaped minibatch: uniform token ids with one <image> marker, labels
+    -100 on the first 40 %, four <hand_traj> tokens at the tail; 100 frames = `unique` frames tiled."""
+    from hvlm.synthetic import make_text_batch_np
+    ids, labels = make_text_batch_np(B, T, seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    base = torch.randn(B, unique, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
+    idx = (torch.arange(cfg.num_frames, device=device) * unique) // cfg.num_frames
+    image = base[:, idx].contiguous()
+    fh = torch.rand(B, 2, 5, 2, device=device, generator=g)
+    return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labels),
+                attention_mask=torch.ones(B, T, dtype=torch.bool), image=image, future_hands=fh,
+                contact_point=torch.zeros(B, 2, device=device), future_valid=torch.ones(B, 2, device=device),
+                gt_label_valid=torch.ones(B, device=device))
+
+
+class GemmEvents:
+    """HIP-event pairs around every GEMM launch on the launch (= torch current) stream."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+        self._cur = None
+
+    def __call__(self, M, N, K, begin):
+        if not self.enabled:
+            return
+        if begin:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._cur = e
+        else:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.pairs.append((self._cur, e, 2.0 * M * N * K))
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.pairs)
+        fl = sum(f for _, _, f in self.pairs)
+        return dict(launches=len(self.pairs), total_ms=ms, total_flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+                    avg_us=ms * 1e3 / len(self.pairs))
+
+
+def cpu_baseline(cfg, T):
+    """Times the CPU oracle (port of the reference's eager fp32 path) on a bounded sample and scales it to
+    SFT samples/s: one Vicuna decoder layer fwd+bwd at full width on ONE sample (S = T+355), one CLIP layer
+    on 10 frames, and the lm_head GEMM; scaled by the layer / frame counts (per-layer time is linear)."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(os.cpu_count())
+    D, F, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+    S = T + 355
+    g = torch.Generator().manual_seed(0)
+    p = {}
+    pre = "l."
+    for n, shp in {"self_attn.q_proj": (D, D), "self_attn.k_proj": (D, D), "self_attn.v_proj": (D, D),
+                   "self_attn.o_proj": (D, D), "mlp.gate_proj": (F, D), "mlp.up_proj": (F, D), "mlp.down_proj": (D, F)}.items():
+        p[pre + n + ".weight"] = (torch.randn(*shp, generator=g) * 0.02).requires_grad_(True)
+    p[pre + "input_layernorm.weight"] = torch.ones(D, requires_grad=True)
+    p[pre + "post_attention_layernorm.weight"] = torch.ones(D, requires_grad=True)
+    x = torch.randn(1, S, D, generator=g).requires_grad_(True)
+    cos, sin = R.rope_tables(D // H, S)
+    def llama_step():
+        y = R.llama_layer(x, p, pre, H, cos, sin, 1e-6)
+        y.sum().backward()
+    llama_step()
+    t0 = time.perf_counter(); llama_step(); llama_step(); t_llama = (time.perf_counter() - t0) / 2
+    # lm_head fwd+bwd
+    wl = (torch.randn(cfg.vocab_size, D, generator=g) * 0.02).requires_grad_(True)
+    h = torch.randn(S, D, generator=g).requires_grad_(True)
+    t0 = time.perf_counter(); (h @ wl.t()).sum().backward(); t_head = time.perf_counter() - t0
+    # CLIP layer (forward only, frozen) on 10 frames
+    v = cfg.vision
+    d, m = v.hidden_size, v.intermediate_size
+    cp = {}
+    cpre = "c."
+    for n, shp in {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d),
+                   "self_attn.out_proj": (d, d), "mlp.fc1": (m, d), "mlp.fc2": (d, m)}.items():
+        cp[cpre + n + ".weight"] = torch.randn(*shp, generator=g) * 0.02
+        cp[cpre + n + ".bias"] = torch.zeros(shp[0])
+    for n in ("layer_norm1", "layer_norm2"):
+        cp[cpre + n + ".weight"] = torch.ones(d); cp[cpre + n + ".bias"] = torch.zeros(d)
+    xc = torch.randn(10, v.num_patches + 1, d, generator=g)
+    with torch.no_grad():
+        R.clip_layer(xc, cp, cpre, v.num_attention_heads)
+        t0 = time.perf_counter(); R.clip_layer(xc, cp, cpre, v.num_attention_heads); t_clip10 = time.perf_counter() - t0
+    n_clip_layers = v.num_hidden_layers + 1 + cfg.mm_vision_select_layer
+    per_sample = cfg.num_hidden_layers * t_llama + t_head + n_clip_layers * (cfg.num_frames / 10.0) * t_clip10
+    return {"value": 1.0 / per_sample, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": (f"oracle/ref_cpu.py fp32 eager, torch {torch.get_num_threads()} threads: 1 decoder layer fwd+bwd at "
+                       f"D={D},S={S},B=1 ({t_llama:.2f}s) x{cfg.num_hidden_layers} + lm_head fwd+bwd ({t_head:.2f}s) + 1 CLIP "
+                       f"layer fwd on 10 frames ({t_clip10:.2f}s) x{n_clip_layers} layers x{cfg.num_frames // 10}; "
+                       "optimizer/pooling/splice not counted")}
+
+
+def main():
+    args = parse()
+    from hvlm import dp as hdp
+    rank, local, world = hdp.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    from hvlm import ops
+    from hvlm.model import HandsOnVLMForCausalLM
+    from hvlm.optim import AdamW
+
+    cfg = make_config(args)
+    B, T = args.batch, args.text_len
+    model = HandsOnVLMForCausalLM(cfg, device=device, training=True).init_random(seed=0)
+    opt = AdamW(model, lr=2e-5, weight_decay=0.0)
+    buckets = hdp.attach(model, hdp.GradBuckets())
+    batch = make_batch(cfg, B, T, args.unique_frames, seed=100 + rank, device=device)
+    ev = GemmEvents()
+    if not args.no_gemm_events:
+        ops.set_gemm_hook(ev)
+
+    def step():
+        out = model(**batch)
+        model.backward()
+        buckets.wait()
+        opt.step(grad_scale=1.0 / world)
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    ev.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ev.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(out.loss.detach())
+    gs = ev.summary()
+    peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+
+    if rank == 0:
+        S = T + 355
+        n_frames = B * cfg.num_frames if not args.dedup else B * args.unique_frames
+        flops_llm = 3.0 * model.stack.flops_forward(B, S, cfg.vocab_size)
+        flops_clip = n_frames * model.tower.flops_per_frame()
+        step_flops = flops_llm + flops_clip
+        res = {
+            "metric": "SFT samples/sec HandsOnVLM-7B" if args.model == "7b" else f"SFT samples/sec HandsOnVLM-{args.model}",
+            "value": world * B * args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"sft_step_{args.model}_b{B}_T{T}_S{S}_{cfg.num_frames}x224px"
+                                   + ("_dedupclip" if args.dedup else "_refequiv"),
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       "frames_through_clip_per_sample": n_frames // B,
+                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": False},
+            "step_tflop_algorithmic": step_flops / 1e12,
+            "model_tflops_per_gpu": step_flops / (dt / args.steps) / 1e12,
+            "mfma_roofline_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "loss": loss,
+            "peak_mem_gib": peak_mem,
+        }
+        if args.layers is not None:
+            res["INVALID_debug_layers"] = args.layers
+        if gs is not None:
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": gs["tflops"],
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                               "traffic": None, "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
+                               "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
+                               "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, T)
+            except Exception as ex:  # noqa
+                res["cpu_baseline"] = {"error": str(ex)[:200]}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

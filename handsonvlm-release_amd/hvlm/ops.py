@@ -22,6 +22,15 @@ IGNORE_INDEX = -100
 BF16 = torch.bfloat16
 
 
+# Optional instrumentation (bench.py): called as hook(M, N, K) -> context manager around each GEMM launch.
+_gemm_hook = None
+
+
+def set_gemm_hook(hook):
+    global _gemm_hook
+    _gemm_hook = hook
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -67,9 +76,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     if bias is not None:
         _chk(bias, BF16, "gemm.bias")
         assert bias.numel() == N and bias.is_contiguous()
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
     check(_lib.load().hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
                                         out.stride(0), _p(bias), _p(residual), ldr, act,
                                         1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")
+    if hook is not None:
+        hook(M, N, K, False)
     return out
 
 
