@@ -18,13 +18,13 @@
 //
 // Reference arithmetic replaced: every nn.Linear on the path (see include/hvlm.h).
 #include "common.h"
+#include <stdlib.h>
 
 namespace hvlm {
 
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int NT = 512;                       // 8 waves
 constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // 128 KiB, 2-deep ring
@@ -48,7 +48,12 @@ __device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_off, char* 
 
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
+template <int VARIANT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;            // waves per workgroup
+  constexpr int FM = BM / WM / 32;       // 32-row A fragments per wave
+  constexpr int FN = BN / WN / 32;       // 32-col B fragments per wave
+  constexpr int PPW = 32 / NW;           // LDS-DMA pieces per wave per operand tile (32 pieces of 8 rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int l = tid & 63;
@@ -76,79 +81,129 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(GemmArgs p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-lane LDS-DMA source pointers (4 A pieces + 4 B pieces per wave per K-tile) ----
-  const bf16_t* ga[4];
-  const bf16_t* gb[4];
+  const bf16_t* ga[PPW];
+  const bf16_t* gb[PPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = w * 32 + i * 8 + (l >> 3);           // tile row this lane feeds
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (w * PPW + i) * 8 + (l >> 3);        // tile row this lane feeds
     const int c = (l & 7) ^ ((row >> 1) & 7);            // source chunk for chunk position l&7
     const int ra = min(m0 + row, p.M - 1);
     const int rb = min(n0 + row, p.N - 1);
     ga[i] = p.A + (size_t)ra * p.lda + c * 8;
     gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
   }
-  const unsigned dma_off = (unsigned)(w * 4) * 1024u;    // + i*1024 ; wave-uniform
+  const unsigned dma_off = (unsigned)(w * PPW) * 1024u;  // + i*1024 ; wave-uniform
 
   auto stage = [&](int buf, int kt) {
     const unsigned base = (unsigned)buf * STAGE_BYTES + dma_off;
     const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(ga[i] + k0, base + i * 1024u, smem);
+    for (int i = 0; i < PPW; ++i) glds16(ga[i] + k0, base + i * 1024u, smem);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(gb[i] + k0, base + TILE_BYTES + i * 1024u, smem);
+    for (int i = 0; i < PPW; ++i) glds16(gb[i] + k0, base + TILE_BYTES + i * 1024u, smem);
   };
 
   // ---- fragment read offsets ----------------------------------------------------------------
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WN, wn = w % WN;
   const int sw = (l31 >> 1) & 7;
   unsigned koff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) koff[ks] = (unsigned)(((ks * 2 + hi) ^ sw) << 4);
-  const unsigned a_base = (unsigned)(wm * 128 + l31) * 128u;
-  const unsigned b_base = (unsigned)TILE_BYTES + (unsigned)(wn * 64 + l31) * 128u;
+  const unsigned a_base = (unsigned)(wm * (FM * 32) + l31) * 128u;
+  const unsigned b_base = (unsigned)TILE_BYTES + (unsigned)(wn * (FN * 32) + l31) * 128u;
 
-  f32x16 acc[2][4];
+  f32x16 acc[FN][FM];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < FN; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of tile kt landed
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
+  if constexpr (VARIANT == 0) {
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces of tile kt landed
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 af[4], bfr[2];
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 af[FM], bfr[FN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + i * 4096u + koff[ks]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+      }
+    }
+  } else {
+    // VARIANT 1: register double-buffered fragments (reads of k-step s+1 fly under the MFMAs of s),
+    // LDS-DMA of the next tile spread over the four k-steps (2 pieces each), s_setprio around MFMA.
+    auto stage_part = [&](int buf, int kt, int part) {
+      const unsigned base = (unsigned)buf * STAGE_BYTES + dma_off;
+      const int k0 = kt * BK;
+      if constexpr (PPW == 4) {
+        glds16(ga[part] + k0, base + part * 1024u, smem);
+        glds16(gb[part] + k0, base + TILE_BYTES + part * 1024u, smem);
+      } else {   // PPW == 2: A pieces on even k-steps, B pieces on odd
+        const int i = part >> 1;
+        if (part & 1) glds16(gb[i] + k0, base + TILE_BYTES + i * 1024u, smem);
+        else glds16(ga[i] + k0, base + i * 1024u, smem);
+      }
+    };
+    auto load_frags = [&](unsigned sb, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
         af[i] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + i * 4096u + koff[ks]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < FN; ++j)
         bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
+      const bool more = kt + 1 < nk;
+      bf16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+      load_frags(sb, 0, afA, bfA);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int ks = 0; ks < 4; ++ks) {
+        if (more) stage_part((kt + 1) & 1, kt + 1, ks);
+        if (ks < 3) {
+          if (ks & 1) load_frags(sb, ks + 1, afA, bfA); else load_frags(sb, ks + 1, afB, bfB);
+        }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            if (ks & 1) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfB[j], afB[i], acc[j][i], 0, 0, 0);
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfA[j], afA[i], acc[j][i], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
     }
   }
 
   // ---- epilogue: lane holds row m, 4 consecutive columns per register quad ----------------
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 128 + i * 32 + l31;
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * (FM * 32) + i * 32 + l31;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < FN; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wn * 64 + j * 32 + 8 * g + 4 * hi;
+        const int nb = n0 + wn * (FN * 32) + j * 32 + 8 * g + 4 * hi;
         if (nb >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -223,17 +278,30 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return HVLM_ERR_LAUNCH;
-    }
-    attr_set = true;
-  }
+  const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
+  const int variant = ve ? atoi(ve) : 1;
   const int grid = p.tiles_m * p.tiles_n;
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(grid), dim3(NT), LDS_BYTES, as_stream(stream), p);
+#define HVLM_LAUNCH_GEMM(V, WM_, WN_)                                                                 \
+  do {                                                                                                \
+    static bool attr_done = false;                                                                    \
+    if (!attr_done) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<V, WM_, WN_>,               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);      \
+      if (e != hipSuccess) {                                                                          \
+        set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));                      \
+        return HVLM_ERR_LAUNCH;                                                                       \
+      }                                                                                               \
+      attr_done = true;                                                                               \
+    }                                                                                                 \
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<V, WM_, WN_>), dim3(grid), dim3(WM_ * WN_ * 64), LDS_BYTES, \
+                       as_stream(stream), p);                                                         \
+  } while (0)
+  switch (variant) {
+    case 0: HVLM_LAUNCH_GEMM(0, 2, 4); break;
+    case 2: HVLM_LAUNCH_GEMM(0, 4, 4); break;
+    case 3: HVLM_LAUNCH_GEMM(1, 4, 4); break;
+    default: HVLM_LAUNCH_GEMM(1, 2, 4); break;
+  }
+#undef HVLM_LAUNCH_GEMM
   return check_launch("gemm_bf16_nt");
 }

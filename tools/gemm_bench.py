@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""GEMM micro-benchmark + correctness (GPU box).  HVLM_GEMM_VARIANT selects the kernel variant."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
+import torch
+from hvlm import ops
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+
+def timeit(fn, iters=10, warmup=3):
+    for _ in range(warmup): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+def main():
+    variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["0"]
+    shapes = [(13872, 12288, 4096), (13872, 4096, 4096), (13872, 22016, 4096), (13872, 4096, 11008), (4096, 4096, 13888),
+              (11008, 4096, 13888), (8192, 8192, 8192), (102800, 4096, 1024), (102800, 1024, 4096), (102800, 3072, 1024)]
+    torch.manual_seed(0)
+    res = {}
+    # correctness
+    for v in variants:
+        os.environ["HVLM_GEMM_VARIANT"] = v
+        errs = []
+        for (M, N, K) in [(300, 520, 128), (1000, 1000, 512), (868, 4096, 4096), (257, 64, 64)]:
+            a = torch.randn(M, K, device=dev).to(BF); b = torch.randn(N, K, device=dev).to(BF)
+            bias = torch.randn(N, device=dev).to(BF); r = torch.randn(M, N, device=dev).to(BF)
+            ref = (a.float() @ b.float().t() + bias.float()); ref = ref * torch.sigmoid(1.702 * ref) + r.float()
+            c = ops.gemm_nt(a, b, bias=bias, residual=r, act=1)
+            errs.append(float((c.float() - ref).norm() / ref.norm()))
+        res[f"v{v}_err"] = max(errs)
+    for (M, N, K) in shapes:
+        a = torch.rand(M, K, device=dev).sub_(0.5).to(BF); b = torch.rand(N, K, device=dev).sub_(0.5).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=dev)
+        row = {}
+        for rep in range(2):
+            for v in variants:
+                os.environ["HVLM_GEMM_VARIANT"] = v
+                ms = timeit(lambda: ops.gemm_nt(a, b, out=out), iters=8, warmup=2)
+                row.setdefault(v, []).append(2.0 * M * N * K / ms / 1e9)
+        res[f"{M}x{N}x{K}"] = {v: round(max(t), 1) for v, t in row.items()}
+        print(f"{M}x{N}x{K}", res[f"{M}x{N}x{K}"], flush=True)
+        del a, b, out
+    print(json.dumps(res))
+
+main()
