@@ -22,6 +22,7 @@
 // (transformers modeling_llama; flash path llava/train/llama_flash_attn_monkey_patch.py:81-94) and
 // CLIPAttention (non-causal, dh = 64).
 #include "common.h"
+#include <type_traits>
 
 namespace hvlm {
 namespace {
@@ -47,16 +48,17 @@ __device__ __forceinline__ int swz_bits(int r) {
 
 // LDS-DMA a [ROWS][COLS] tile (4 waves).  Row r of the tile is global row min(row0 + r, row_lim-1)
 // of a matrix with `stride` elements between rows, starting at `gbase`.
-template <int ROWS, int COLS>
+template <int ROWS, int COLS, int NW = 4>
 __device__ __forceinline__ void load_tile(char* smem, unsigned tile_off, const bf16_t* gbase,
                                           long stride, int row0, int row_lim, int w, int l) {
   constexpr int CPR = COLS / 8;        // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;        // rows per wave-instruction (1 KiB)
   constexpr int NPIECE = ROWS / RPI;
-  constexpr int PPW = NPIECE / 4;      // pieces per wave
+  constexpr int PPW = (NPIECE + NW - 1) / NW;   // pieces per wave (round-robin over the NW waves)
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int pi = w * PPW + i;
+    const int pi = i * NW + w;
+    if (NPIECE % NW != 0 && pi >= NPIECE) break;
     const int r = pi * RPI + l / CPR;
     const int cp = l % CPR;
     const int c = cp ^ swz_bits<COLS>(r);
@@ -87,8 +89,8 @@ constexpr float LN2 = 0.6931471805599453f;
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+template <int DH, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                        const bf16_t* __restrict__ vt,
                                                        bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int H, int ld,
@@ -99,10 +101,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
-  const int nqt = (S + 127) / 128;
+  constexpr int QB = NW * 32;            // query rows per workgroup
+  const int nqt = (S + QB - 1) / QB;
   const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;  // heavy tiles first
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = qt * 128;
+  const int q0 = qt * QB;
   const int qi = q0 + w * 32 + l31;
   const long tok0 = (long)b * S;
 
@@ -120,14 +123,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   float m = -INFINITY, lsum = 0.f;
 
   const int nkt_all = (S + 63) / 64;
-  const int nkt = CAUSAL ? min(nkt_all, min(q0 + 127, S - 1) / 64 + 1) : nkt_all;
+  const int nkt = CAUSAL ? min(nkt_all, min(q0 + QB - 1, S - 1) / 64 + 1) : nkt_all;
   const bf16_t* kbase = qkv + tok0 * ld + (long)H * DH + h * DH;
   const bf16_t* vtbase = vt + ((long)b * H + h) * DH * (long)S_pad;
 
   auto stage = [&](int buf, int kt) {
     const unsigned base = (unsigned)buf * STAGE;
-    load_tile<64, DH>(smem, base, kbase, ld, kt * 64, S, w, l);
-    load_tile<DH, 64>(smem, base + KT, vtbase + kt * 64, S_pad, 0, DH, w, l);
+    load_tile<64, DH, NW>(smem, base, kbase, ld, kt * 64, S, w, l);
+    load_tile<DH, 64, NW>(smem, base + KT, vtbase + kt * 64, S_pad, 0, DH, w, l);
   };
 
   stage(0, 0);
@@ -139,68 +142,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     if (CAUSAL && kv0 > q0 + w * 32 + 31) continue;   // wave-uniform: tile fully above the diagonal
     const unsigned sK = (unsigned)(kt & 1) * STAGE, sV = sK + KT;
 
-    f32x16 s[2];
+    // second 32-key block of the tile entirely past the sequence end (or above the diagonal): skip it
+    const bool kb1 = (kv0 + 32 < S) && !(CAUSAL && kv0 + 32 > q0 + w * 32 + 31);
+    auto tile_body = [&](auto nkb_tag) {
+      constexpr int NKB = decltype(nkb_tag)::value;
+      f32x16 s[NKB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < DH / 16; ++ks)
+      for (int ks = 0; ks < DH / 16; ++ks)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-      }
-    const bool need_mask = (kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = s[kb][r] * scale_log2;
-        if (need_mask) {
-          const int key = kv0 + kb * 32 + crow(r, hi);
-          if (key >= S || (CAUSAL && key > qi)) t = -INFINITY;
+        for (int kb = 0; kb < NKB; ++kb) {
+          const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
         }
-        s[kb][r] = t;
-        mx = fmaxf(mx, t);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mnew = fmaxf(m, mx);
-    const float alpha = exp2f(m - mnew);
-    m = mnew;
-    float psum = 0.f;
+      const bool need_mask = (kv0 + 32 * NKB > S) || (CAUSAL && kv0 + 32 * NKB - 1 > q0 + w * 32);
+      float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kb][r] - mnew);
-        s[kb][r] = p;
-        psum += p;
-      }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < DH / 32; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
-        const bf16x8 pf = pack8(pv);
-        const int c1 = kb * 4 + 2 * sp;
-#pragma unroll
-        for (int db = 0; db < DH / 32; ++db) {
-          const int r = db * 32 + l31;
-          const bf16x8 vf = lds_frag64x2(smem, sV + tile_addr<64>(r, c1) + 8u * hi,
-                                         sV + tile_addr<64>(r, c1 + 1) + 8u * hi);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          float t = s[kb][r] * scale_log2;
+          if (need_mask) {
+            const int key = kv0 + kb * 32 + crow(r, hi);
+            if (key >= S || (CAUSAL && key > qi)) t = -INFINITY;
+          }
+          s[kb][r] = t;
+          mx = fmaxf(mx, t);
         }
-      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);
+      const float alpha = exp2f(m - mnew);
+      m = mnew;
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = exp2f(s[kb][r] - mnew);
+          s[kb][r] = p;
+          psum += p;
+        }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
+          const bf16x8 pf = pack8(pv);
+          const int c1 = kb * 4 + 2 * sp;
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db) {
+            const int r = db * 32 + l31;
+            const bf16x8 vf = lds_frag64x2(smem, sV + tile_addr<64>(r, c1) + 8u * hi,
+                                           sV + tile_addr<64>(r, c1 + 1) + 8u * hi);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+          }
+        }
+    };
+    if (kb1) tile_body(std::integral_constant<int, 2>{});
+    else tile_body(std::integral_constant<int, 1>{});
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   if (qi < S) {
@@ -538,11 +547,21 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   int rc = launch_head_transpose<DH>(qkv, ws, B, S, H, ld, 2 * H * DH, st);
   if (rc) return rc;
   constexpr int LDS = 2 * 2 * 64 * DH * 2;
-  rc = set_lds(attn_fwd_kernel<DH, CAUSAL>, LDS, "attn_fwd");
-  if (rc) return rc;
-  dim3 grid((S + 127) / 128, H, B);
-  hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)ws, out,
-                     lse, S, H, ld, spad(S), scale * LOG2E);
+  // rows per workgroup: 128 (4 waves) or 96 (3 waves) — whichever wastes fewer query rows (S=257 -> 96)
+  const int waste4 = (S + 127) / 128 * 128 - S, waste3 = (S + 95) / 96 * 96 - S;
+  if (waste3 < waste4) {
+    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 3>, LDS, "attn_fwd");
+    if (rc) return rc;
+    dim3 grid((S + 95) / 96, H, B);
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 3>), grid, dim3(192), LDS, st, qkv, (const bf16_t*)ws, out,
+                       lse, S, H, ld, spad(S), scale * LOG2E);
+  } else {
+    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4>, LDS, "attn_fwd");
+    if (rc) return rc;
+    dim3 grid((S + 127) / 128, H, B);
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 4>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)ws, out,
+                       lse, S, H, ld, spad(S), scale * LOG2E);
+  }
   return check_launch("attn_fwd");
 }
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
       }
     }
-  } else {
+  } else if constexpr (VARIANT != 4 && VARIANT != 5) {
     // VARIANT 1: register double-buffered fragments (reads of k-step s+1 fly under the MFMAs of s),
     // LDS-DMA of the next tile spread over the four k-steps (2 pieces each), s_setprio around MFMA.
     auto stage_part = [&](int buf, int kt, int part) {
@@ -167,19 +167,104 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
       for (int j = 0; j < FN; ++j)
         bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
     };
+    // ablation bits (development only; results are wrong when set): VARIANT = 1 + 16*bits
+    constexpr bool NO_GLDS = (VARIANT >> 4) & 1;     // no LDS-DMA inside the loop
+    constexpr bool NO_READ = (VARIANT >> 4) & 2;     // fragments loaded once
+    constexpr bool NO_SYNC = (VARIANT >> 4) & 4;     // no vmcnt wait / barrier inside the loop
+    constexpr bool HOT_GLDS = (VARIANT >> 4) & 8;    // LDS-DMA always re-reads K-tile 0 (cache-hot source)
     stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    bf16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+    if constexpr (NO_READ) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      load_frags(0, 0, afA, bfA);
+      load_frags(0, 1, afB, bfB);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (!NO_SYNC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
+      const bool more = kt + 1 < nk;
+      if constexpr (!NO_READ) load_frags(sb, 0, afA, bfA);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if constexpr (!NO_GLDS) {
+          if (more) stage_part((kt + 1) & 1, HOT_GLDS ? 0 : kt + 1, ks);
+        }
+        if constexpr (!NO_READ) {
+          if (ks < 3) {
+            if (ks & 1) load_frags(sb, ks + 1, afA, bfA); else load_frags(sb, ks + 1, afB, bfB);
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            if (ks & 1) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfB[j], afB[i], acc[j][i], 0, 0, 0);
+            else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfA[j], afA[i], acc[j][i], 0, 0, 0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+
+  if constexpr (VARIANT == 4 || VARIANT == 5) {
+    // VARIANT 4/5: register-staged operand tiles.  Tile t+1 is fetched with plain 16-byte global loads
+    // at the top of tile t (cheap to issue, fully asynchronous) and written to the other LDS stage with
+    // ds_write_b128 late in tile t, instead of 8 LDS-DMA instructions per wave per tile whose issue cost
+    // (~100 cycles each) was measured to take 20 % of the kernel (ablation in DESIGN.md).
+    u32x4 ra[PPW], rb[PPW];
+    auto gload = [&](int kt) {
+      const int k0 = kt * BK;
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ga[i] + k0);
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) rb[i] = *reinterpret_cast<const u32x4*>(gb[i] + k0);
+    };
+    const unsigned wr_off = dma_off + (unsigned)l * 16u;
+    auto lwrite_a = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        *reinterpret_cast<u32x4*>(smem + (unsigned)buf * STAGE_BYTES + wr_off + i * 1024u) = ra[i];
+    };
+    auto lwrite_b = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i)
+        *reinterpret_cast<u32x4*>(smem + (unsigned)buf * STAGE_BYTES + TILE_BYTES + wr_off + i * 1024u) = rb[i];
+    };
+    auto load_frags = [&](unsigned sb, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + i * 4096u + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
+    };
+    gload(0);
+    lwrite_a(0);
+    lwrite_b(0);
+    bf16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+    for (int kt = 0; kt < nk; ++kt) {
       __syncthreads();
       const unsigned sb = (unsigned)(kt & 1) * STAGE_BYTES;
       const bool more = kt + 1 < nk;
-      bf16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+      if (more) gload(kt + 1);
       load_frags(sb, 0, afA, bfA);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        if (more) stage_part((kt + 1) & 1, kt + 1, ks);
         if (ks < 3) {
           if (ks & 1) load_frags(sb, ks + 1, afA, bfA); else load_frags(sb, ks + 1, afB, bfB);
+        }
+        if (more) {
+          if constexpr (VARIANT == 4) {
+            if (ks == 2) lwrite_a((kt + 1) & 1);
+            if (ks == 3) lwrite_b((kt + 1) & 1);
+          } else {
+            if (ks == 3) { lwrite_a((kt + 1) & 1); lwrite_b((kt + 1) & 1); }
+          }
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -300,6 +385,14 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 0: HVLM_LAUNCH_GEMM(0, 2, 4); break;
     case 2: HVLM_LAUNCH_GEMM(0, 4, 4); break;
     case 3: HVLM_LAUNCH_GEMM(1, 4, 4); break;
+    case 4: HVLM_LAUNCH_GEMM(4, 2, 4); break;
+    case 5: HVLM_LAUNCH_GEMM(5, 2, 4); break;
+    case 17: HVLM_LAUNCH_GEMM(17, 2, 4); break;
+    case 129: HVLM_LAUNCH_GEMM(129, 2, 4); break;
+    case 33: HVLM_LAUNCH_GEMM(33, 2, 4); break;
+    case 49: HVLM_LAUNCH_GEMM(49, 2, 4); break;
+    case 113: HVLM_LAUNCH_GEMM(113, 2, 4); break;
+    case 65: HVLM_LAUNCH_GEMM(65, 2, 4); break;
     default: HVLM_LAUNCH_GEMM(1, 2, 4); break;
   }
 #undef HVLM_LAUNCH_GEMM

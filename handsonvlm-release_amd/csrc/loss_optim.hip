@@ -116,27 +116,54 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
   __shared__ bf16_t tile[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
+  const bool vec_ok = (C % 4) == 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int idx = t + k * 256;       // 1024 items of 4 elements
     const int r = idx >> 4, c = (idx & 15) * 4;
     bf16_t outv[4] = {0, 0, 0, 0};
     if (r0 + r < R) {
+      const int cc0 = c0 + c;
+      const size_t off0 = (size_t)(r0 + r) * C + cc0;
+      if (vec_ok && cc0 + 3 < C) {
+        // 16-byte fp32 accesses, 8-byte bf16 accesses
+        const u32x2 gv = *reinterpret_cast<const u32x2*>(grad + off0);
+        f32x4 pv = *reinterpret_cast<const f32x4*>(master + off0);
+        f32x4 mv = *reinterpret_cast<const f32x4*>(m + off0);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(v + off0);
+        const float g4[4] = {bf_lo(gv[0]) * a.gscale, bf_hi(gv[0]) * a.gscale, bf_lo(gv[1]) * a.gscale, bf_hi(gv[1]) * a.gscale};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int cc = c0 + c + e;
-        if (cc < C) {
-          const size_t off = (size_t)(r0 + r) * C + cc;
-          const float g = bf2f(grad[off]) * a.gscale;
-          float p = master[off];
-          p *= (1.f - a.lr * a.wd);
-          const float mm = a.beta1 * m[off] + (1.f - a.beta1) * g;
-          const float vv = a.beta2 * v[off] + (1.f - a.beta2) * g * g;
-          const float denom = sqrtf(vv) / a.bc2 + a.eps;   // bc2 = sqrt(1 - beta2^t)
+        for (int e = 0; e < 4; ++e) {
+          float p = pv[e] * (1.f - a.lr * a.wd);
+          const float mm = a.beta1 * mv[e] + (1.f - a.beta1) * g4[e];
+          const float v2 = a.beta2 * vv[e] + (1.f - a.beta2) * g4[e] * g4[e];
+          const float denom = sqrtf(v2) / a.bc2 + a.eps;
           p -= (a.lr / a.bc1) * (mm / denom);
-          master[off] = p; m[off] = mm; v[off] = vv;
+          pv[e] = p; mv[e] = mm; vv[e] = v2;
           outv[e] = f2bf(p);
-          w[off] = outv[e];
+        }
+        *reinterpret_cast<f32x4*>(master + off0) = pv;
+        *reinterpret_cast<f32x4*>(m + off0) = mv;
+        *reinterpret_cast<f32x4*>(v + off0) = vv;
+        u32x2 wv = {outv[0] | ((unsigned)outv[1] << 16), outv[2] | ((unsigned)outv[3] << 16)};
+        *reinterpret_cast<u32x2*>(w + off0) = wv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = cc0 + e;
+          if (cc < C) {
+            const size_t off = off0 + e;
+            const float g = bf2f(grad[off]) * a.gscale;
+            float p = master[off];
+            p *= (1.f - a.lr * a.wd);
+            const float mm = a.beta1 * m[off] + (1.f - a.beta1) * g;
+            const float vv = a.beta2 * v[off] + (1.f - a.beta2) * g * g;
+            const float denom = sqrtf(vv) / a.bc2 + a.eps;   // bc2 = sqrt(1 - beta2^t)
+            p -= (a.lr / a.bc1) * (mm / denom);
+            master[off] = p; m[off] = mm; v[off] = vv;
+            outv[e] = f2bf(p);
+            w[off] = outv[e];
+          }
         }
       }
     }
