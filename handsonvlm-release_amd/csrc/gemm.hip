@@ -1,20 +1,26 @@
 // bf16 GEMM on MFMA for gfx950:  C[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.
 //
-// Structure (one workgroup = one 256x256 output tile, 8 waves as 2(M) x 4(N), wave tile 128x64):
+// Structure (256x256 output tiles, 8 waves as 2(M) x 4(N), wave tile 128x64):
+//   * persistent workgroups (one per CU): each walks output tiles in an XCD-aware order and runs ONE
+//     flat K-tile pipeline across tile boundaries — the LDS-DMA of the next tile's first K-tile is
+//     issued during the last K-tile of the current one, so the epilogue overlaps loads in flight;
 //   * K is walked in 64-wide tiles; both operand tiles (256 rows x 128 B) are copied HBM -> LDS by
 //     LDS-DMA (`global_load_lds_dwordx4`, 1 KiB per wave-instruction, no VGPR round trip) into a
-//     2-deep ring, so tile t+1 is in flight while tile t feeds the matrix pipe.
+//     2-deep ring; the 8 DMA pieces per wave are spread over the 4 k-steps of the running tile;
+//   * fragments are register double-buffered: the ds_read_b128 of k-step s+1 fly under the MFMAs of s;
 //   * LDS image: row-major 128-B rows, 16-B chunk c of row r stored at chunk position
 //     c ^ ((r>>1)&7).  LDS-DMA writes lane-linear, so the permutation is applied to the per-lane
 //     SOURCE address and again on the fragment read; with it every ds_read_b128 lane group of a
-//     32-row fragment touches 16 distinct 16-B slots of the 256-B bank row (conflict-free).
+//     32-row fragment touches 16 distinct 16-B slots of the 256-B bank row (SQ_LDS_BANK_CONFLICT = 0);
 //   * v_mfma_f32_32x32x16_bf16 with the operands SWAPPED (weight-tile rows as the MFMA "A"):
 //     the accumulator then holds, per lane, one output row m and 4 consecutive output columns per
 //     register quad, so the epilogue (bias, QuickGELU, residual, bf16 pack) stores 8 contiguous
-//     bytes per lane without an LDS transpose.
-//   * blockIdx -> tile map is XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous
-//     range of a grouped (GM row-panels x all column-panels) ordering so the 32 tiles resident on
-//     one XCD share operand panels in that XCD's private L2.
+//     bytes per lane without an LDS transpose;
+//   * tile order is XCD-aware (block b runs on XCD b%8): each XCD gets a contiguous range of a
+//     grouped (GROUP_M row-panels x all column-panels) ordering so the tiles resident on one XCD
+//     share operand panels in that XCD's private L2.
+// Other template variants (plain 2-stage loop, 16-wave layout, register staging, ablations) are kept
+// for A/B measurements (tools/gemm_bench.py, HVLM_GEMM_VARIANT); numbers in DESIGN.md.
 //
 // Reference arithmetic replaced: every nn.Linear on the path (see include/hvlm.h).
 #include "common.h"
@@ -62,36 +68,36 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
 
   // ---- XCD-aware, grouped tile mapping ---------------------------------------------------
   const int nwg = p.tiles_m * p.tiles_n;
-  int swz;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tm, tn;
-  {
+  auto tile_coords = [&](int vb, int& tm_, int& tn_) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int gsz = GROUP_M * p.tiles_n;
     const int gid = swz / gsz;
     const int first_m = gid * GROUP_M;
     const int gm = min(p.tiles_m - first_m, GROUP_M);
     const int in = swz - gid * gsz;
-    tm = first_m + in % gm;
-    tn = in / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
+    tm_ = first_m + in % gm;
+    tn_ = in / gm;
+  };
+  int tm, tn;
+  tile_coords(blockIdx.x, tm, tn);
+  int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-lane LDS-DMA source pointers (4 A pieces + 4 B pieces per wave per K-tile) ----
   const bf16_t* ga[PPW];
   const bf16_t* gb[PPW];
+  auto set_pointers = [&](int m0_, int n0_) {
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int row = (w * PPW + i) * 8 + (l >> 3);        // tile row this lane feeds
-    const int c = (l & 7) ^ ((row >> 1) & 7);            // source chunk for chunk position l&7
-    const int ra = min(m0 + row, p.M - 1);
-    const int rb = min(n0 + row, p.N - 1);
-    ga[i] = p.A + (size_t)ra * p.lda + c * 8;
-    gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
-  }
+    for (int i = 0; i < PPW; ++i) {
+      const int row = (w * PPW + i) * 8 + (l >> 3);        // tile row this lane feeds
+      const int c = (l & 7) ^ ((row >> 1) & 7);            // source chunk for chunk position l&7
+      const int ra = min(m0_ + row, p.M - 1);
+      const int rb = min(n0_ + row, p.N - 1);
+      ga[i] = p.A + (size_t)ra * p.lda + c * 8;
+      gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
+    }
+  };
+  set_pointers(m0, n0);
   const unsigned dma_off = (unsigned)(w * PPW) * 1024u;  // + i*1024 ; wave-uniform
 
   auto stage = [&](int buf, int kt) {
@@ -120,7 +126,135 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
+  // ---- epilogue: lane holds row m, 4 consecutive columns per register quad ----------------
+  auto epilogue = [&](int m0, int n0) {
+  #pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm * (FM * 32) + i * 32 + l31;
+      if (m >= p.M) continue;
+  #pragma unroll
+      for (int j = 0; j < FN; ++j) {
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = n0 + wn * (FN * 32) + j * 32 + 8 * g + 4 * hi;
+          if (nb >= p.N) continue;
+          float v[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+          const bool full = (nb + 3 < p.N);
+          if (p.bias) {
+            if (full) {
+              const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + nb);
+              v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(p.bias[nb + e]);
+            }
+          }
+          if (p.act == HVLM_ACT_QUICK_GELU) {
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+          }
+          if (p.res) {
+            const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
+            if (full) {
+              const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+              v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(rp[e]);
+            }
+          }
+          if (p.out_f32) {
+            float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb;
+            if (full) {
+              f32x4 o = {v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(cp) = o;
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = v[e];
+            }
+          } else {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
+            if (full) {
+              u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(cp) = o;
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = f2bf(v[e]);
+            }
+          }
+        }
+      }
+    }
+  };
+
   const int nk = p.K / BK;
+  if constexpr (VARIANT == 6) {
+    // VARIANT 6: persistent workgroups.  Each workgroup walks output tiles vb = blockIdx.x + k*gridDim.x
+    // (same XCD-aware order), running ONE flat K-tile pipeline across tile boundaries: the LDS-DMA of the
+    // next output tile's first K-tile is issued during the last K-tile of the current one, so the
+    // epilogue (and the first-tile latency) overlaps with loads already in flight.
+    auto stage_part = [&](int buf, int kt, int part) {
+      const unsigned base = (unsigned)buf * STAGE_BYTES + dma_off;
+      const int k0 = kt * BK;
+      glds16(ga[part] + k0, base + part * 1024u, smem);
+      glds16(gb[part] + k0, base + TILE_BYTES + part * 1024u, smem);
+    };
+    auto load_frags = [&](unsigned sb, int ks, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + i * 4096u + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + j * 4096u + koff[ks]);
+    };
+    int vb = blockIdx.x;
+    unsigned g = 0;                       // running K-tile counter: K-tile uses LDS stage g & 1
+    stage(0, 0);
+    bf16x8 afA[FM], bfA[FN], afB[FM], bfB[FN];
+    while (true) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+      const int cm0 = m0, cn0 = n0;
+      const int nvb = vb + (int)gridDim.x;
+      const bool has_next = nvb < nwg;
+      for (int kt = 0; kt < nk; ++kt, ++g) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned sb = (g & 1u) * STAGE_BYTES;
+        const bool last = kt + 1 == nk;
+        if (last && has_next) {           // all loads of the current tile are issued: retarget the pointers
+          tile_coords(nvb, tm, tn);
+          m0 = tm * BM; n0 = tn * BN;
+          set_pointers(m0, n0);
+        }
+        const bool more = !last || has_next;
+        const int nkt = last ? 0 : kt + 1;
+        load_frags(sb, 0, afA, bfA);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (more) stage_part((int)((g + 1) & 1u), nkt, ks);
+          if (ks < 3) {
+            if (ks & 1) load_frags(sb, ks + 1, afA, bfA); else load_frags(sb, ks + 1, afB, bfB);
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+              if (ks & 1) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfB[j], afB[i], acc[j][i], 0, 0, 0);
+              else acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfA[j], afA[i], acc[j][i], 0, 0, 0);
+            }
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+      epilogue(cm0, cn0);
+      if (!has_next) break;
+      vb = nvb;
+    }
+    return;
+  }
   if constexpr (VARIANT == 0) {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -144,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
       }
     }
-  } else if constexpr (VARIANT != 4 && VARIANT != 5) {
+  } else if constexpr (VARIANT != 4 && VARIANT != 5 && VARIANT != 6) {
     // VARIANT 1: register double-buffered fragments (reads of k-step s+1 fly under the MFMAs of s),
     // LDS-DMA of the next tile spread over the four k-steps (2 pieces each), s_setprio around MFMA.
     auto stage_part = [&](int buf, int kt, int part) {
@@ -279,62 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
     }
   }
 
-  // ---- epilogue: lane holds row m, 4 consecutive columns per register quad ----------------
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * (FM * 32) + i * 32 + l31;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nb = n0 + wn * (FN * 32) + j * 32 + 8 * g + 4 * hi;
-        if (nb >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
-        const bool full = (nb + 3 < p.N);
-        if (p.bias) {
-          if (full) {
-            const u32x2 bb = *reinterpret_cast<const u32x2*>(p.bias + nb);
-            v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
-          } else {
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(p.bias[nb + e]);
-          }
-        }
-        if (p.act == HVLM_ACT_QUICK_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
-        }
-        if (p.res) {
-          const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
-          if (full) {
-            const u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
-            v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
-          } else {
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(rp[e]);
-          }
-        }
-        if (p.out_f32) {
-          float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb;
-          if (full) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cp) = o;
-          } else {
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = v[e];
-          }
-        } else {
-          bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
-          if (full) {
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(cp) = o;
-          } else {
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = f2bf(v[e]);
-          }
-        }
-      }
-    }
-  }
+  epilogue(m0, n0);
 }
 
 }  // namespace
@@ -364,8 +443,15 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
-  const int variant = ve ? atoi(ve) : 1;
-  const int grid = p.tiles_m * p.tiles_n;
+  const int variant = ve ? atoi(ve) : 6;
+  int grid = p.tiles_m * p.tiles_n;
+  static int pgrid = 0;
+  if (!pgrid) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) pgrid = prop.multiProcessorCount;
+    else pgrid = 256;
+    pgrid = (pgrid / 8) * 8;
+  }
 #define HVLM_LAUNCH_GEMM(V, WM_, WN_)                                                                 \
   do {                                                                                                \
     static bool attr_done = false;                                                                    \
@@ -386,6 +472,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 2: HVLM_LAUNCH_GEMM(0, 4, 4); break;
     case 3: HVLM_LAUNCH_GEMM(1, 4, 4); break;
     case 4: HVLM_LAUNCH_GEMM(4, 2, 4); break;
+    case 6: { const int full = grid; grid = grid < pgrid ? grid : pgrid; (void)full; HVLM_LAUNCH_GEMM(6, 2, 4); break; }
     case 5: HVLM_LAUNCH_GEMM(5, 2, 4); break;
     case 17: HVLM_LAUNCH_GEMM(17, 2, 4); break;
     case 129: HVLM_LAUNCH_GEMM(129, 2, 4); break;
