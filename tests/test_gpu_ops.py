@@ -1,0 +1,324 @@
+"""GPU parity of every C-ABI op against the CPU oracle (oracle/ref_cpu.py) on the same seeded inputs, plus
+size-independent property checks at BASELINE.json's full sizes (7B shapes).
+
+Tolerances (bf16 kernels, fp32 oracle evaluated on the SAME bf16-rounded inputs):
+  * rel-L2 <= 1e-3 against the oracle rounded to bf16 where the op is a single rounding of an fp32 result
+    (GEMM, norms, pooling, elementwise) — i.e. the two bf16 results agree except for rare 1-ulp flips;
+  * rel-L2 <= 4e-3 against the fp32 oracle for ops with internal bf16 roundings the oracle does not make
+    (attention P in bf16, fused backward kernels);  bit-exact for integer / index / copy work.
+Run with `pytest -m gpu` on the MI355X box."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle import synth  # noqa: E402
+
+BF = torch.bfloat16
+T = torch.from_numpy
+
+
+def rel(a, b):
+    a = a.detach().float().cpu(); b = torch.as_tensor(b).detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return (T(np.random.RandomState(seed).standard_normal(shape).astype(np.float32)) * scale).to(BF)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hvlm import ops as o
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 8, 64), (77, 100, 64), (256, 256, 512), (300, 520, 128), (868, 4096, 4096),
+                                    (1000, 32128, 128), (513, 12288, 256)])
+def test_gemm_vs_oracle(ops, M, N, K):
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    ref = torch.nn.functional.linear(a.float(), b.float())           # the nn.Linear the kernel replaces
+    c = ops.gemm_nt(a.cuda(), b.cuda())
+    assert rel(c, ref.to(BF)) <= 1e-3
+    c32 = ops.gemm_nt(a.cuda(), b.cuda(), out_dtype=torch.float32)
+    assert rel(c32, ref) <= 1e-5
+
+
+def test_gemm_epilogues_and_transposition_detecting(ops):
+    M, N, K = 384, 520, 192
+    a, b, bias, res = rnd(M, K, seed=3), rnd(N, K, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+    lin = torch.nn.functional.linear(a.float(), b.float(), bias.float())
+    ref = R.quick_gelu(lin) + res.float()                          # CLIP fc1 epilogue + residual
+    c = ops.gemm_nt(a.cuda(), b.cuda(), bias=bias.cuda(), residual=res.cuda(), act=ops.ACT_QUICK_GELU)
+    assert rel(c, ref.to(BF)) <= 1e-3
+    eye = torch.eye(256).to(BF)
+    bb = rnd(256, 256, seed=7)                                      # asymmetric B: catches a transposed C write
+    assert torch.equal(ops.gemm_nt(eye.cuda(), bb.cuda()).cpu(), bb.t().contiguous())
+    big = rnd(M, 3 * K, seed=8).cuda()                              # strided A view (fused-qkv style)
+    assert rel(ops.gemm_nt(big[:, K:2 * K], b.cuda()), (big[:, K:2 * K].float().cpu() @ b.float().t()).to(BF)) <= 1e-3
+
+
+def test_transpose_colsum_casts(ops):
+    x = rnd(300, 520, seed=9)
+    t = ops.transpose(x.cuda(), r_pad=320).cpu()
+    assert torch.equal(t[:, :300], x.t()) and float(t[:, 300:].abs().max()) == 0.0
+    assert rel(ops.colsum(x.cuda()), x.float().sum(0)) <= 1e-6
+    f = torch.randn(1001, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(ops.cast_f32_to_bf16(f.cuda()).cpu(), f.to(BF))
+
+
+@pytest.mark.parametrize("rows,D", [(37, 4096), (100, 64), (64, 1024), (33, 5120), (1, 128)])
+def test_rmsnorm_layernorm_vs_oracle(ops, rows, D):
+    x, w, b = rnd(rows, D, seed=10), (1 + 0.1 * rnd(D, seed=11).float()).to(BF), rnd(D, seed=12, scale=0.1)
+    y, rstd = ops.rmsnorm_fwd(x.cuda(), w.cuda(), 1e-6)
+    assert torch.equal(y.cpu(), R.rms_norm(x, w, 1e-6))             # bf16 op-by-op restatement: bit-exact
+    xf = x.float().requires_grad_(True); wf = w.float().requires_grad_(True)
+    dy, add = rnd(rows, D, seed=13), rnd(rows, D, seed=14)
+    R.rms_norm(xf, wf, 1e-6).backward(dy.float())
+    dx, dw = ops.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd, add=add.cuda())
+    assert rel(dx, (xf.grad + add.float()).to(BF)) <= 1e-3 and rel(dw, wf.grad) <= 3e-3
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5)
+    assert rel(ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-5), ref.to(BF)) <= 1e-3
+
+
+def test_rope_vs_oracle(ops):
+    H, dh, B, S = 4, 128, 2, 50
+    qkv = rnd(B * S, 3 * H * dh, seed=15)
+    cos, sin = R.rope_tables(dh, 64)
+    x = qkv.view(B, S, 3, H, dh)
+    q, k = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2)
+    qr, kr = R.apply_rope(q, k, cos[:S], sin[:S])                   # bf16 op-by-op like the reference
+    pos = torch.arange(S, dtype=torch.int32).repeat(B)
+    work = qkv.clone().cuda()
+    ops.rope_qk_(work, cos.to(BF).cuda(), sin.to(BF).cuda(), pos.cuda(), H, dh)
+    got = work.cpu().view(B, S, 3, H, dh)
+    assert torch.equal(got[:, :, 0].transpose(1, 2), qr) and torch.equal(got[:, :, 1].transpose(1, 2), kr)
+    assert torch.equal(got[:, :, 2], x[:, :, 2])                    # v untouched
+    ops.rope_qk_(work, cos.to(BF).cuda(), sin.to(BF).cuda(), pos.cuda(), H, dh, inverse=True)
+    assert rel(work, qkv) <= 5e-3                                   # rotation^T rotation = I up to bf16 rounding
+
+
+@pytest.mark.parametrize("B,S,H,dh,causal", [(2, 128, 2, 128, True), (1, 200, 3, 128, True), (2, 257, 4, 64, False),
+                                              (1, 64, 1, 64, True), (1, 33, 2, 128, True), (1, 50, 2, 128, False),
+                                              (2, 868, 2, 128, True), (1, 1, 1, 64, True)])
+def test_attention_fwd_bwd_vs_oracle(ops, B, S, H, dh, causal):
+    qkv = rnd(B * S, 3 * H * dh, seed=16, scale=0.7)
+    x = qkv.float().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = [t.contiguous().requires_grad_(True) for t in (x[0], x[1], x[2])]
+    ref = R.softmax_attention(q, k, v, causal, dh ** -0.5)
+    o, lse = ops.attn_fwd(qkv.cuda(), B, S, H, dh, causal, dh ** -0.5)
+    assert not torch.isnan(o).any()
+    assert rel(o.cpu().view(B, S, H, dh).permute(0, 2, 1, 3), ref) <= 4e-3
+    do = rnd(B * S, H * dh, seed=17)
+    ref.backward(do.float().view(B, S, H, dh).permute(0, 2, 1, 3))
+    dqkv = ops.attn_bwd(qkv.cuda(), o, do.cuda(), lse, B, S, H, dh, causal, dh ** -0.5)
+    d = dqkv.float().cpu().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
+    assert not torch.isnan(dqkv).any()
+    for got, want in zip(d, (q.grad, k.grad, v.grad)):
+        assert rel(got, want) <= 6e-3
+
+
+def test_attention_rescale_branch_is_exercised(ops):
+    """A key with a huge score late in the sequence forces the online-softmax running max to jump at a later
+    KV tile (guide rule 26): the result must still match the full-tensor reference."""
+    B, S, H, dh = 1, 256, 1, 128
+    qkv = rnd(B * S, 3 * H * dh, seed=18, scale=0.3)
+    qkv[200, dh:2 * dh] = qkv[255, :dh] * 40.0                        # k_200 aligned with q_255: a late spike
+    x = qkv.float().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
+    ref = R.softmax_attention(x[0], x[1], x[2], True, dh ** -0.5)
+    o, _ = ops.attn_fwd(qkv.cuda(), B, S, H, dh, True, dh ** -0.5)
+    assert rel(o.cpu().view(B, S, H, dh).permute(0, 2, 1, 3), ref) <= 4e-3
+
+
+def test_swiglu_vs_oracle(ops):
+    M, F = 77, 11008
+    gu = rnd(M, 2 * F, seed=19)
+    g, u = gu[:, :F], gu[:, F:]
+    assert torch.equal(ops.swiglu_fwd(gu.cuda()).cpu(), torch.nn.functional.silu(g) * u)      # bf16 op-by-op: bit-exact
+    gf, uf = g.float().requires_grad_(True), u.float().requires_grad_(True)
+    da = rnd(M, F, seed=20)
+    (torch.nn.functional.silu(gf) * uf).backward(da.float())
+    d = ops.swiglu_bwd(gu.cuda(), da.cuda())
+    assert rel(d[:, :F], gf.grad.to(BF)) <= 1e-3 and rel(d[:, F:], uf.grad.to(BF)) <= 1e-3
+
+
+def test_pool_vs_reference_golden_and_oracle(ops, golden):
+    g = golden("g1_pool.npz")                                          # produced by the REFERENCE
+    tok = T(g["tokens"]).float().to(BF)
+    out = ops.temporal_spatial_pool_fwd(tok.cuda().contiguous(), 1, 100, drop_cls=False)
+    assert rel(out, R.temporal_spatial_pool(tok.float()).to(BF)) <= 1e-3
+    assert rel(out, g["out"]) <= 4e-3                                  # fp16-stored input vs bf16 compute
+    tok257 = rnd(2, 100, 257, 64, seed=21)
+    out2 = ops.temporal_spatial_pool_fwd(tok257.cuda(), 2, 100, drop_cls=True)
+    assert rel(out2, R.temporal_spatial_pool(tok257[:, :, 1:].float()).to(BF)) <= 1e-3
+    tf = tok257[:, :, 1:].float().requires_grad_(True)
+    dout = rnd(2, 356, 64, seed=22)
+    R.temporal_spatial_pool(tf).backward(dout.float())
+    assert rel(ops.temporal_spatial_pool_bwd(dout.cuda(), 2, 100), tf.grad.to(BF)) <= 1e-3
+
+
+def test_splice_and_hand_posenc_vs_oracle(ops):
+    from helpers import bare_model as _bare_model
+    D, NV = 128, 356
+    m = _bare_model(D)
+    ids, labels, mask = synth.make_text_batch(2, 30, seed=9, n_hand=(4, 0), pad_tail=(0, 4))
+    embed, vis = rnd(32101, D, seed=23), rnd(2, NV, D, seed=24)
+    fh = T(np.random.RandomState(3).uniform(0, 1, (2, 2, 4, 2)).astype(np.float32))
+    plan = m.build_splice_plan(ids, labels, NV, 4, False, True)
+    x = ops.embed_splice_fwd(embed.cuda(), vis.cuda(), plan.src.cuda(), plan.hand_slot.cuda(), fh.cuda(),
+                             plan.hand_scale.cuda(), 2, plan.S, D, NV, 4)
+    x_ref, _, _ = R.splice_batch(ids, labels, mask, embed.float(), vis.float(), fh, False)
+    assert rel(x.cpu().view(2, plan.S, D), x_ref.to(BF)) <= 1e-3
+    rows_plain = (plan.hand_slot.view(2, -1) < 0)
+    assert torch.equal(x.cpu().view(2, plan.S, D)[rows_plain], x_ref.to(BF)[rows_plain])     # pure copies: bit-exact
+    # backward: scatter-add into the embedding table and the visual tokens
+    dx = rnd(2 * plan.S, D, seed=25)
+    de = torch.zeros(32101, D, device="cuda"); dv = torch.zeros(2, NV, D, dtype=BF, device="cuda")
+    ops.embed_splice_bwd(dx.cuda(), plan.src.cuda(), de, dv, 2, plan.S, D, NV)
+    ef = embed.float().requires_grad_(True); vf = vis.float().requires_grad_(True)
+    xr, _, _ = R.splice_batch(ids, labels, mask, ef, vf, fh, False)
+    xr.backward(dx.float().view(2, plan.S, D))
+    assert rel(de, ef.grad) <= 1e-6 and torch.equal(dv.cpu(), vf.grad.to(BF))
+
+
+def test_ce_and_hand_gather_vs_oracle(ops):
+    B, S, V, Vp, D = 2, 25, 32101, 32128, 128
+    logits = torch.zeros(B * S, Vp, dtype=BF)
+    logits[:, :V] = rnd(B * S, V, seed=26, scale=2.0)
+    logits[:, V:] = 50.0                                               # poisoned padding columns must be ignored
+    labels = T(np.random.RandomState(4).randint(0, V, (B, S)).astype(np.int64))
+    labels[0, :7] = -100; labels[1, -3:] = -100
+    lf = logits[:, :V].float().view(B, S, V).requires_grad_(True)
+    loss_ref = R.shifted_ce(lf, labels)
+    tg = torch.full((B, S), -100, dtype=torch.int32); tg[:, :-1] = labels[:, 1:].to(torch.int32)
+    acc, row_lse = ops.ce_fwd(logits.cuda(), tg.view(-1).cuda(), V)
+    assert abs(float(acc[0] / acc[1]) - float(loss_ref)) / float(loss_ref) <= 1e-5
+    loss_ref.backward()
+    gs = (1.0 / acc[1:2]).contiguous()
+    d = ops.ce_bwd_(logits.clone().cuda(), tg.view(-1).cuda(), row_lse, gs, V)
+    assert rel(d[:, :V], lf.grad.view(B * S, V)) <= 4e-3 and float(d[:, V:].abs().max()) == 0.0
+    hidden = rnd(B, S, D, seed=27)
+    lab2 = torch.full((B, S), -100, dtype=torch.int64); lab2[0, [10, 12, 14, 16]] = 32100
+    emb_ref, fv = R.hand_gather(hidden.float(), lab2, torch.ones(B, 2))
+    rows = torch.tensor([[9, 11, 13, 15], [-1, -1, -1, -1]], dtype=torch.int32).view(-1)
+    emb = ops.hand_gather_fwd(hidden.view(B * S, D).cuda(), rows.cuda(), B, D)
+    assert torch.equal(emb.cpu(), emb_ref) and float(fv[1].sum()) == 0
+
+
+def test_clip_tower_vs_reference_golden(ops, golden):
+    """CLIP tower (3 layers, d=64, 1 head -> dh=64) against hidden_states[-2][:,1:] produced by the reference."""
+    from hvlm.clip import CLIPVisionTower
+    from hvlm.config import CLIPVisionConfig
+    g = golden("g4_ops.npz")
+    tower = CLIPVisionTower(CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3,
+                                             num_attention_heads=1), "cuda:0")
+    tower.load_state_dict(synth.to_torch(synth.clip_params(synth.TINY)))
+    img = synth.make_images(1, 2, 2, 224, seed=31)[0]
+    feat = tower(img.to(BF).cuda())
+    assert feat.shape == (2, 256, 64)
+    assert rel(feat, g["clip_feat"]) <= 1.5e-2                         # 2 bf16 layers + bf16 pixels vs fp32 reference
+
+
+def test_llama_layer_dh128_vs_reference_golden(ops, golden):
+    """One decoder layer at head_dim 128 (D=256, H=2) forward+backward against transformers' LlamaDecoderLayer
+    output captured in g4_ops.npz."""
+    from hvlm.config import HandsOnVLMConfig
+    from hvlm.llama import LlamaStack
+    g = golden("g4_ops.npz")
+    cfg = HandsOnVLMConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2)
+    st = LlamaStack(cfg, "cuda:0", training=True)
+    p = synth.to_torch(synth.llama_params(dict(D=256, H=2, L=1, FFN=512, vocab=8, clip_d=64), seed=21))
+    st.load_hf(p, "model.")
+    st.norm_w.fill_(1.0)
+    x = T(g["x"]).to(BF).cuda().view(80, 256)
+    hidden, hs = st.forward(x, 2, 40, save=True, all_hidden=True)
+    y = st.final["x"]                                                   # layer output before the final norm
+    assert rel(y.view(2, 40, 256), g["y"]) <= 1e-2
+    # backward through the layer only: feed dy through the (identity-weight) final norm's input gradient
+    st.final["x"] = y
+    dy = T(g["dy"]).to(BF).cuda().view(80, 256)
+    # bypass the final norm: call the layer backward with dx = dy
+    import hvlm.ops as o
+    st_saved = st.saved
+    orig = o.rmsnorm_bwd
+    calls = {"n": 0}
+
+    def first_identity(dyy, xx, w, rstd, add=None, out=None):
+        calls["n"] += 1
+        if calls["n"] == 1:
+            return dyy, torch.zeros(256, dtype=BF, device="cuda")
+        return orig(dyy, xx, w, rstd, add=add, out=out)
+
+    o.rmsnorm_bwd = first_identity
+    try:
+        dx = st.backward(dy)
+    finally:
+        o.rmsnorm_bwd = orig
+    assert rel(dx.view(2, 40, 256), g["dx"]) <= 2e-2
+    lp = st.layers[0]
+    assert rel(lp.g["qkv"][:256], g["g_q"]) <= 2e-2
+    assert rel(lp.g["gu"][:512], g["g_gate"]) <= 2e-2
+    assert rel(lp.g["ln2"], g["g_ln2"]) <= 2e-2
+
+
+def test_adamw_vs_torch(ops):
+    R_, C = 300, 520
+    p0 = torch.randn(R_, C, generator=torch.Generator().manual_seed(5))
+    g = rnd(R_, C, seed=28, scale=0.1)
+    pm, m, v = p0.clone().cuda(), torch.zeros(R_, C, device="cuda"), torch.zeros(R_, C, device="cuda")
+    w = torch.empty(R_, C, dtype=BF, device="cuda"); wt = torch.empty(C, R_, dtype=BF, device="cuda")
+    pref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pref], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    for step in range(1, 4):
+        pref.grad = g.float() * 0.5
+        opt.step()
+        ops.adamw_step_(pm, m, v, g.cuda(), w, wt, 1e-2, 0.9, 0.999, 1e-8, 0.1, 0.5, step)
+    assert rel(pm, pref.detach()) <= 1e-6
+    assert torch.equal(w.cpu(), pm.cpu().to(BF)) and torch.equal(wt.cpu(), pm.cpu().to(BF).t())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full-size (7B shapes) property tests: no oracle at this size, so size-independent identities
+# ---------------------------------------------------------------------------------------------------------
+def test_fullsize_gemm_linearity_and_checksum(ops):
+    M, N, K = 13872, 4096, 4096
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = (torch.rand(M, K, device="cuda", generator=g) - 0.5).to(BF)
+    b = (torch.rand(N, K, device="cuda", generator=g) - 0.5).to(BF)
+    c = ops.gemm_nt(a, b, out_dtype=torch.float32)
+    # checksum of checksums: sum_ij C_ij == (sum_i a_i) . (sum_j b_j), accumulated in fp64
+    lhs = c.double().sum()
+    rhs = (a.double().sum(0) * b.double().sum(0)).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float(c.double().abs().sum())
+    # linearity in A: (2a) b^T == 2 (a b^T) exactly in floating point (power-of-two scaling)
+    c2 = ops.gemm_nt((a.float() * 2).to(BF), b, out_dtype=torch.float32)
+    assert torch.equal(c2, c * 2)
+    # a random row block against an fp32 reference
+    rows = torch.randint(0, M, (64,), device="cuda")
+    assert rel(c[rows], a[rows].float() @ b.float().t()) <= 1e-5
+
+
+def test_fullsize_attention_properties(ops):
+    B, S, H, dh = 2, 867, 32, 128
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = (torch.randn(B * S, 3 * H * dh, device="cuda", generator=g) * 0.5).to(BF)
+    qkv[:, 2 * H * dh:] = 1.0                                          # V = ones  =>  O = ones (rows of P sum to 1)
+    o, lse = ops.attn_fwd(qkv, B, S, H, dh, True, dh ** -0.5)
+    assert float((o.float() - 1.0).abs().max()) <= 8e-3
+    # first query of every sample attends only to itself: lse == its own score
+    q0 = qkv.view(B, S, 3, H, dh)[:, 0, 0].float(); k0 = qkv.view(B, S, 3, H, dh)[:, 0, 1].float()
+    assert float((lse[:, :, 0] - (q0 * k0).sum(-1) * dh ** -0.5).abs().max()) <= 1e-3
+
+
+def test_fullsize_rmsnorm_swiglu_pool_idempotence(ops):
+    x = (torch.randn(13872, 4096, device="cuda") * 3).to(BF)
+    w = torch.ones(4096, dtype=BF, device="cuda")
+    y, _ = ops.rmsnorm_fwd(x, w, 1e-6)
+    assert float((y.float().pow(2).mean(-1) - 1).abs().max()) <= 2e-2      # unit RMS rows
+    y2, _ = ops.rmsnorm_fwd(y, w, 1e-6)
+    assert rel(y2, y) <= 4e-3                                              # idempotent up to bf16 rounding
+    tok = torch.full((2, 100, 257, 1024), 0.5, dtype=BF, device="cuda")
+    assert torch.equal(ops.temporal_spatial_pool_fwd(tok, 2, 100, drop_cls=True), torch.full((2, 356, 1024), 0.5, dtype=BF, device="cuda"))
