@@ -190,7 +190,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +204,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ev.enabled = False
-    if world > 1:
+    if torch.distributed.is_initialized():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -256,7 +256,7 @@ def main():
             except Exception as ex:  # noqa
                 res["cpu_baseline"] = {"error": str(ex)[:200]}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -22,7 +22,8 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("HVLM_FORCE_DIST", "0") == "1"      # exercise the RCCL path even at world size 1
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -39,10 +40,11 @@ class GradBuckets:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("HVLM_FORCE_DIST", "0") == "1")
         self.handles: List = []
 
     def reduce_async(self, *tensors: torch.Tensor):
-        if self.world == 1:
+        if not self.active:
             return
         for t in tensors:
             self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
