@@ -72,7 +72,7 @@ def make_batch(cfg, B, T, unique, seed, device):
     ids, labels = make_text_batch_np(B, T, seed)
     g = torch.Generator(device=device).manual_seed(seed)
     base = torch.randn(B, unique, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
-    idx = (torch.arange(cfg.num_frames, device=device) * unique) // cfg.num_frames
+    idx = torch.arange(cfg.num_frames, device=device) % unique      # [f0..f9] x 10, epic_dataset.py:90-95
     image = base[:, idx].contiguous()
     fh = torch.rand(B, 2, 5, 2, device=device, generator=g)
     return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labels),

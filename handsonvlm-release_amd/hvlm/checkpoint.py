@@ -1,0 +1,104 @@
+"""Checkpoint I/O compatible with the reference.
+
+Reads the Hugging Face layout the reference produces and consumes (handsonvlm/model/builder.py:93,158 —
+`config.json` + `pytorch_model.bin` or sharded `pytorch_model-0000x-of-0000N.bin` with
+`pytorch_model.bin.index.json`; `safe_save_model_for_hf_trainer`, handsonvlm/train/train.py:101-136) and the LLaVA
+adapter file `mm_projector.bin` (llava/model/llava_arch.py:64-69).  Key names are the reference's;
+tensors the hot path does not use (time_embedding, bbox_to_feature, ...) are carried through untouched on save when
+they were present on load."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+from .config import CLIPVisionConfig, HandsOnVLMConfig
+
+INDEX = "pytorch_model.bin.index.json"
+_CFG_MAP = {"hidden_size": "hidden_size", "intermediate_size": "intermediate_size", "num_hidden_layers": "num_hidden_layers",
+            "num_attention_heads": "num_attention_heads", "vocab_size": "vocab_size", "rms_norm_eps": "rms_norm_eps",
+            "max_position_embeddings": "max_position_embeddings", "mm_hidden_size": "mm_hidden_size",
+            "mm_vision_select_layer": "mm_vision_select_layer", "mm_vision_select_feature": "mm_vision_select_feature",
+            "fuse_input_mode": "fuse_input_mode", "video_compress_mode": "video_compress_mode",
+            "lambda_traj": "lambda_traj", "lambda_traj_kl": "lambda_traj_kl", "hoi_lambda": "hoi_lambda",
+            "pad_token_id": "pad_token_id", "bos_token_id": "bos_token_id", "eos_token_id": "eos_token_id"}
+
+
+def config_from_json(path: str) -> HandsOnVLMConfig:
+    raw = json.load(open(os.path.join(path, "config.json")))
+    kw = {dst: raw[src] for src, dst in _CFG_MAP.items() if raw.get(src) is not None}
+    cfg = HandsOnVLMConfig(**kw)
+    if "vision_config" in raw:
+        cfg.vision = CLIPVisionConfig(**{k: v for k, v in raw["vision_config"].items() if k in CLIPVisionConfig.__dataclass_fields__})
+    return cfg
+
+
+def config_to_json(cfg: HandsOnVLMConfig, path: str):
+    raw = {src: getattr(cfg, dst) for src, dst in _CFG_MAP.items()}
+    raw.update(model_type="handsonvlm", architectures=["HandsOnVLMForCausalLM"], mm_vision_tower=cfg.mm_vision_tower,
+               vision_config={k: getattr(cfg.vision, k) for k in CLIPVisionConfig.__dataclass_fields__})
+    json.dump(raw, open(os.path.join(path, "config.json"), "w"), indent=1)
+
+
+def load_state(path: str) -> Dict[str, torch.Tensor]:
+    """Loads a (possibly sharded) HF .bin checkpoint directory into one CPU state dict."""
+    idx = os.path.join(path, INDEX)
+    if os.path.exists(idx):
+        files = sorted(set(json.load(open(idx))["weight_map"].values()))
+    else:
+        files = ["pytorch_model.bin"]
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        sd.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
+    return sd
+
+
+def save_state(sd: Dict[str, torch.Tensor], path: str, max_shard_bytes: int = 10 * 2 ** 30):
+    """Writes HF-style shards + index (gather-16bit-on-save semantics: tensors are saved in their current dtype)."""
+    os.makedirs(path, exist_ok=True)
+    shards, cur, size = [], {}, 0
+    for k, v in sd.items():
+        nb = v.numel() * v.element_size()
+        if cur and size + nb > max_shard_bytes:
+            shards.append(cur); cur, size = {}, 0
+        cur[k] = v.detach().cpu().contiguous(); size += nb
+    shards.append(cur)
+    if len(shards) == 1:
+        torch.save(shards[0], os.path.join(path, "pytorch_model.bin"))
+        return
+    wmap = {}
+    for i, sh in enumerate(shards):
+        name = f"pytorch_model-{i + 1:05d}-of-{len(shards):05d}.bin"
+        torch.save(sh, os.path.join(path, name))
+        wmap.update({k: name for k in sh})
+    json.dump({"metadata": {"total_size": sum(v.numel() * v.element_size() for v in sd.values())}, "weight_map": wmap},
+              open(os.path.join(path, INDEX), "w"), indent=1)
+
+
+def from_pretrained(path: str, device="cuda:0", training: bool = False, mm_projector_bin: Optional[str] = None, **cfg_overrides):
+    """load_pretrained_model (handsonvlm/model/builder.py:18) for the HIP model."""
+    from .model import HandsOnVLMForCausalLM
+    cfg = config_from_json(path)
+    for k, v in cfg_overrides.items():
+        setattr(cfg, k, v)
+    model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
+    sd = load_state(path)
+    if mm_projector_bin is not None:                           # initialize_vision_modules(pretrain_mm_mlp_adapter=...)
+        adapter = torch.load(mm_projector_bin, map_location="cpu", weights_only=True)
+        for k, v in adapter.items():
+            if "mm_projector" in k:
+                sd["model.mm_projector." + k.split("mm_projector.")[1]] = v
+    model.load_state_dict(sd)
+    model._extra_state = {k: v for k, v in sd.items() if k not in model.state_dict()
+                          and not k.startswith("model.vision_tower.")}
+    return model
+
+
+def save_pretrained(model, path: str, max_shard_bytes: int = 10 * 2 ** 30):
+    os.makedirs(path, exist_ok=True)
+    sd = dict(model.state_dict())
+    sd.update(getattr(model, "_extra_state", {}))
+    config_to_json(model.config, path)
+    save_state(sd, path, max_shard_bytes)

@@ -193,12 +193,19 @@ class HandsOnVLMForCausalLM:
         frames = image.reshape(B * T, *image.shape[2:])
         inv = None
         if cfg.dedup_frames:
-            # EK100 clips tile 10 frames x10 (handsonvlm/dataset/epic_dataset.py:90-95): encode unique frames once
-            flat = frames.reshape(B * T, -1)
-            keep = torch.ones(B * T, dtype=torch.bool, device=frames.device)
-            keep[1:] = (flat[1:] != flat[:-1]).any(dim=1)
-            inv = torch.cumsum(keep.to(torch.int64), 0) - 1
-            frames = frames[keep]
+            # EK100 clips repeat a 10-frame sequence 10x (handsonvlm/dataset/epic_dataset.py:90-95: [f0..f9]*10):
+            # encode each distinct frame once.  Frames are matched by a 64-bit hash and then VERIFIED bit-for-bit,
+            # so the result is identical to encoding all frames (falls back to no de-duplication otherwise).
+            flat = frames.reshape(B * T, -1).view(torch.int16)
+            gen = torch.Generator(device=flat.device).manual_seed(0x5EED)
+            wgt = torch.randint(1, 1 << 31, (flat.shape[1],), device=flat.device, generator=gen, dtype=torch.int64) | 1
+            key = (flat.to(torch.int64) * wgt).sum(dim=1)
+            uniq, inverse = torch.unique(key, return_inverse=True)
+            first = torch.full((uniq.numel(),), B * T, dtype=torch.int64, device=flat.device)
+            first.scatter_reduce_(0, inverse, torch.arange(B * T, device=flat.device), reduce="amin")
+            if bool(torch.equal(flat, flat[first[inverse]])):
+                inv = inverse
+                frames = frames[first]
         n = frames.shape[0]
         chunks = []
         for s in range(0, n, cfg.clip_chunk_frames):

@@ -102,8 +102,9 @@ def to_torch(p: dict, dtype=torch.float32) -> dict:
 
 
 def make_images(B: int, frames: int, unique: int, size: int, seed: int = 11) -> torch.Tensor:
-    """[B, frames, 3, size, size]: `unique` random frames tiled to `frames` (EK100 tiles 10 -> 100,
-    handsonvlm/dataset/epic_dataset.py:90-95)."""
+    """[B, frames, 3, size, size]: `unique` random frames, each repeated frames/unique times consecutively.
+    (The golden fixtures were generated with this pattern; EK100's own pattern is the sequence repeated,
+    `arange(frames) % unique`, which bench.py uses.)"""
     r = _rs(seed)
     base = r.standard_normal((B, unique, 3, size, size)).astype(np.float32)
     idx = (np.arange(frames) * unique) // frames
