@@ -83,6 +83,15 @@ __device__ __forceinline__ bf16x8 pack8(const float* p) {
 }
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// raw v_exp_f32 (arguments here are <= ~0 or -inf; the libm exp2f wrapper adds a denormal-range rescale:
+// v_cmp + v_cndmask + v_ldexp per element) and the lane^32 exchange without an LDS round trip.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xlane32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -90,7 +99,7 @@ constexpr float LN2 = 0.6931471805599453f;
 // forward
 // =================================================================================================
 template <int DH, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                        const bf16_t* __restrict__ vt,
                                                        bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, int S, int H, int ld,
@@ -172,16 +181,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
           s[kb][r] = t;
           mx = fmaxf(mx, t);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, xlane32(mx));
       const float mnew = fmaxf(m, mx);
-      const float alpha = exp2f(m - mnew);
+      const float alpha = fast_exp2(m - mnew);
       m = mnew;
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(s[kb][r] - mnew);
+          const float p = fast_exp2(s[kb][r] - mnew);
           s[kb][r] = p;
           psum += p;
         }
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     if (kb1) tile_body(std::integral_constant<int, 2>{});
     else tile_body(std::integral_constant<int, 1>{});
   }
-  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float ltot = lsum + xlane32(lsum);
   if (qi < S) {
     const float inv = 1.f / ltot;
     bf16_t* op = out + (tok0 + qi) * (long)(H * DH) + h * DH;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + kb * 32 + crow(r, hi);
-        float p = exp2f(s[kb][r] * scale_log2 - lse2);
+        float p = fast_exp2(s[kb][r] * scale_log2 - lse2);
         if (key >= S || (CAUSAL && key > qi)) p = 0.f;
         s[kb][r] = p * (dp[kb][r] - dlt) * scale;   // dS^T
       }
@@ -486,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
       for (int r = 0; r < 16; ++r) {
         const int ql = qb * 32 + crow(r, hi);
         const int q = qq0 + ql;
-        float p = exp2f(s[r] * scale_log2 - s_lse[ql]);
+        float p = fast_exp2(s[r] * scale_log2 - s_lse[ql]);
         if (q >= S || ki >= S || (CAUSAL && ki > q)) p = 0.f;
         pvals[r] = p;
         dsvals[r] = p * (dp[r] - s_dlt[ql]) * scale;

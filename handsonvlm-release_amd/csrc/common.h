@@ -20,19 +20,22 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 typedef unsigned short bf16_t;  // raw storage type used in kernel signatures
 
-// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ------------------------------------
+// ---- bf16 <-> f32 -----------------------------------------------------------------------------
+// f32 -> bf16 uses the gfx950 hardware conversion (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN
+// quieted) through clang's native __bf16 conversion; a software rounding sequence costs ~8 VALU and a
+// divergent NaN branch per element, which dominated the attention and GEMM epilogues.
 __device__ __forceinline__ float bf2f(bf16_t h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, h);
 }
 // two floats -> packed bf16x2 in one u32 (lo in low half)
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  const f32x2 v = {lo, hi};
+  const bf16x2 r = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(unsigned int, r);
 }
 __device__ __forceinline__ float bf_lo(unsigned int p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
