@@ -48,3 +48,17 @@ def main():
     print(json.dumps(res))
 
 main()
+
+def epilogue_bench():
+    os.environ["HVLM_GEMM_VARIANT"] = "6"
+    for (M, N, K, kind) in [(102800, 1024, 1024, "bias+res"), (102800, 4096, 1024, "bias+gelu"), (102800, 3072, 1024, "bias"),
+                            (13872, 4096, 4096, "res"), (13872, 4096, 11008, "res")]:
+        a = torch.rand(M, K, device=dev).sub_(0.5).to(BF); b = torch.rand(N, K, device=dev).sub_(0.5).to(BF)
+        bias = torch.rand(N, device=dev).to(BF); res = torch.rand(M, N, device=dev).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=dev)
+        kw = dict(bias=bias if "bias" in kind else None, residual=res if "res" in kind else None, act=1 if "gelu" in kind else 0)
+        ms = timeit(lambda: ops.gemm_nt(a, b, out=out, **kw), iters=8, warmup=2)
+        print(f"epi {M}x{N}x{K} {kind}: {2.0 * M * N * K / ms / 1e9:.1f} TF/s  {ms * 1e3:.0f} us", flush=True)
+
+if len(sys.argv) > 2 and sys.argv[2] == "epi":
+    epilogue_bench()
