@@ -42,7 +42,7 @@ struct GemmArgs {
   void* C;
   const bf16_t* bias;
   const bf16_t* res;
-  int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n;
+  int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
   auto tile_coords = [&](int vb, int& tm_, int& tn_) {
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int gsz = GROUP_M * p.tiles_n;
+    const int gsz = p.group_m * p.tiles_n;
     const int gid = swz / gsz;
-    const int first_m = gid * GROUP_M;
-    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gm = min(p.tiles_m - first_m, p.group_m);
     const int in = swz - gid * gsz;
     tm_ = first_m + in % gm;
     tn_ = in / gm;
@@ -497,6 +497,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
+  { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 6;
   int grid = p.tiles_m * p.tiles_n;

@@ -109,6 +109,15 @@ def test_sample_vs_reference_golden(golden):
     REPORT["g6_pred_hands_rel"] = r
     print("pred_hands rel", r, so.pred_hands.flatten().tolist(), g["pred_hands"].flatten().tolist())
     assert r < 5e-2     # bf16 hidden state feeding an fp32 head
+    # "eval traj ADE/FDE parity" (BASELINE.json metric): the metrics of the HIP trajectory vs those of the
+    # reference's trajectory against the same ground truth, with the reference's metric code semantics.
+    from hvlm.traj_eval import evaluate_traj_stochastic
+    gt = fh[:1, :, 1:].numpy()
+    valid = np.ones((1, 2), np.float32)
+    ours = evaluate_traj_stochastic(so.pred_hands.cpu().numpy()[:, None], gt, valid)
+    ref = R.evaluate_traj_stochastic(g["pred_hands"][:, None], gt, valid)
+    REPORT["g6_ade_fde_wde"] = dict(hip=[float(x) for x in ours], reference=[float(x) for x in ref])
+    np.testing.assert_allclose(ours, ref, rtol=1e-2)
 
 
 def test_cvae_head_bit_exact_given_identical_inputs(golden):

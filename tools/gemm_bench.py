@@ -62,3 +62,19 @@ def epilogue_bench():
 
 if len(sys.argv) > 2 and sys.argv[2] == "epi":
     epilogue_bench()
+
+
+def group_sweep():
+    os.environ["HVLM_GEMM_VARIANT"] = "6"
+    for (M, N, K) in [(13872, 12288, 4096), (13872, 4096, 4096), (13872, 4096, 11008), (4096, 4096, 13888), (102800, 4096, 1024), (102800, 1024, 4096)]:
+        a = torch.rand(M, K, device=dev).sub_(0.5).to(BF); b = torch.rand(N, K, device=dev).sub_(0.5).to(BF)
+        out = torch.empty(M, N, dtype=BF, device=dev)
+        row = {}
+        for gm in (1, 2, 4, 8, 16, 64):
+            os.environ["HVLM_GEMM_GROUP_M"] = str(gm)
+            ms = min(timeit(lambda: ops.gemm_nt(a, b, out=out), iters=8, warmup=2) for _ in range(2))
+            row[gm] = round(2.0 * M * N * K / ms / 1e9, 1)
+        print(f"group {M}x{N}x{K}", row, flush=True)
+
+if len(sys.argv) > 2 and sys.argv[2] == "group":
+    group_sweep()
