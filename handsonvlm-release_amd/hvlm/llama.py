@@ -81,6 +81,7 @@ class LlamaStack:
         self.sin = fr.sin().to(BF16).to(self.device).contiguous()
         self.saved: List[dict] = []
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
+        self._dec_tables = None
         self.on_layer_grad_ready: Optional[Callable[[int], None]] = None   # DP hook: bucket i is final
 
     # -- parameters -----------------------------------------------------------------------------
@@ -130,8 +131,36 @@ class LlamaStack:
         return self._pos_cache[key]
 
     # -- forward --------------------------------------------------------------------------------
+    def new_cache(self, max_len: Optional[int] = None) -> List[torch.Tensor]:
+        """Per-layer [max_len, 3D] buffers in the fused qkv layout (k at column D, v at 2D)."""
+        n = max_len or self.cfg.max_position_embeddings
+        return [torch.empty((n, 3 * self.D), dtype=BF16, device=self.device) for _ in range(self.L)]
+
+    def decode_step(self, x1: torch.Tensor, pos: int, cache: List[torch.Tensor]) -> torch.Tensor:
+        """One new token (x1 [1, D]) at position `pos` against the KV cache -> final-normed hidden [1, D].
+        HBM-bound (every weight is streamed once by the GEMV kernel); the 9 launches per layer are issued by one
+        native call (hvlm_llama_decode_step), not from Python."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        L = self.L
+        if self._dec_tables is None or self._dec_tables[0] is not cache:
+            arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
+            lw = lambda k: arr([lp.w[k] for lp in self.layers])  # noqa: E731
+            ws = torch.empty((lib.hvlm_llama_decode_ws_bytes(self.D, self.F),), dtype=torch.uint8, device=self.device)
+            self._dec_tables = (cache, lw("qkv"), lw("o"), lw("gu"), lw("down"), lw("ln1"), lw("ln2"), arr(cache), ws,
+                                self._positions(1, self.cfg.max_position_embeddings))
+        _, tq, to, tg, td, t1, t2, tc, ws, posv = self._dec_tables
+        hidden = torch.empty((1, self.D), dtype=BF16, device=self.device)
+        rc = lib.hvlm_llama_decode_step(tq, to, tg, td, t1, t2, tc, ops._p(self.norm_w), ops._p(self.cos), ops._p(self.sin),
+                                        ctypes.c_void_p(posv.data_ptr() + 4 * pos), ops._p(x1), ops._p(hidden), ops._p(ws), L,
+                                        self.D, self.F, self.H, self.dh, pos, cache[0].stride(0), self.cfg.rms_norm_eps,
+                                        ops._stream())
+        _lib.check(rc, "llama_decode_step")
+        return hidden
+
     def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
-                all_hidden: bool = False):
+                all_hidden: bool = False, cache: Optional[List[torch.Tensor]] = None):
         """x [B*S, D] bf16 -> final-normed hidden [B*S, D].  Saves activations for backward when
         save (default: self.training)."""
         save = self.training if save is None else save
@@ -143,10 +172,13 @@ class LlamaStack:
         eps = cfg.rms_norm_eps
         self.saved = []
         hs = [x] if all_hidden else None
-        for lp in self.layers:
+        for li, lp in enumerate(self.layers):
             xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
             qkv = ops.gemm_nt(xn, lp.w["qkv"])
             ops.rope_qk_(qkv, self.cos, self.sin, pos, self.H, self.dh)
+            if cache is not None:
+                assert B == 1
+                cache[li][:S].copy_(qkv)
             ao, lse = ops.attn_fwd(qkv, B, S, self.H, self.dh, True, scale, need_lse=save)
             h = ops.gemm_nt(ao, lp.w["o"], residual=x)
             hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)

@@ -435,6 +435,40 @@ class HandsOnVLMForCausalLM:
                 "image": kwargs.get("image"), "is_evaluate": True}
 
     @torch.no_grad()
+    def _prefill(self, input_ids, vis, fh, cache):
+        """Prompt pass of KV-cached generation: fills the per-layer caches, returns (last logits [1,V], length)."""
+        cfg = self.config
+        NV = vis.shape[1]
+        n_hands = 0 if fh is None else fh.shape[2]
+        plan = self.build_splice_plan(input_ids, None, NV, n_hands, True, fh is not None)
+        S = plan.S
+        hands_dev = None if fh is None else fh.detach().to(self.device, torch.float32).contiguous()
+        x = ops.embed_splice_fwd(self.embed, vis, plan.src, plan.hand_slot if hands_dev is not None else None, hands_dev,
+                                 plan.hand_scale if hands_dev is not None else None, 1, S, self.token_dim, NV, max(n_hands, 1))
+        hidden = self.stack.forward(x, 1, S, save=False, cache=cache)
+        self._last_hidden = hidden[S - 1:S].contiguous()
+        logits = ops.gemv(self.lm_head, self._last_hidden.view(-1))
+        return logits[: cfg.vocab_size].unsqueeze(0), S
+
+    @torch.no_grad()
+    def _decode(self, tok: int, hand: Optional[torch.Tensor], pos: int, cache):
+        """One KV-cached step: embed the token appended last (plus the sinusoidal encoding of the hand it produced,
+        handsonvlm.py:380-396), run the decoder on that single row, return logits [1,V]."""
+        cfg, dev = self.config, self.device
+        src = torch.tensor([tok], dtype=torch.int32, device=dev)
+        if hand is not None:
+            slot = torch.zeros(1, dtype=torch.int32, device=dev)
+            hands = hand.detach().to(dev, torch.float32).reshape(1, 2, 1, 2).contiguous()
+            sc = torch.ones(1, dtype=torch.float32, device=dev)
+            x1 = ops.embed_splice_fwd(self.embed, None, src, slot, hands, sc, 1, 1, self.token_dim, 0, 1)
+        else:
+            x1 = ops.embed_splice_fwd(self.embed, None, src, None, None, None, 1, 1, self.token_dim, 0, 1)
+        hidden = self.stack.decode_step(x1, pos, cache)
+        self._last_hidden = hidden
+        logits = ops.gemv(self.lm_head, hidden.view(-1))
+        return logits[: cfg.vocab_size].unsqueeze(0)
+
+    @torch.no_grad()
     def sample(self, input_ids, logits_processor=None, stopping_criteria=None, logits_warper=None, max_length=None,
                pad_token_id=None, eos_token_id=None, output_attentions=None, output_hidden_states=None,
                output_scores=None, return_dict_in_generate=None, synced_gpus=False, streamer=None, **model_kwargs):
@@ -457,11 +491,25 @@ class HandsOnVLMForCausalLM:
         pred_hands: List[torch.Tensor] = []
         scores = []
         n_new = 0
+        use_kv = model_kwargs.get("use_kv_cache", True)
+        cache = self.stack.new_cache(min(cfg.max_position_embeddings, input_ids.shape[1] + vis.shape[1] + 160)) if use_kv else None
+        cur_len = 0
         while True:
             fh = torch.stack(pred_hands, dim=2) if pred_hands else None
-            out = self.forward(input_ids=input_ids, image=image, future_hands=fh, is_evaluate=True, visual_tokens=vis,
-                               last_logits_only=True, output_hidden_states=False)
-            next_scores = out.logits[:, -1, :].float()
+            if not use_kv:
+                out = self.forward(input_ids=input_ids, image=image, future_hands=fh, is_evaluate=True, visual_tokens=vis,
+                                   last_logits_only=True, output_hidden_states=False)
+                logits_last = out.logits[:, -1, :]
+            elif n_new == 0:
+                logits_last, cur_len = self._prefill(input_ids, vis, fh, cache)
+            else:
+                tok_in = int(input_ids[0, -1])
+                hand_in = pred_hands[-1] if tok_in == HAND_TOKEN_ID and pred_hands else None
+                if cur_len + 1 > cache[0].shape[0]:
+                    raise RuntimeError("KV cache exhausted")
+                logits_last = self._decode(tok_in, hand_in, cur_len, cache)
+                cur_len += 1
+            next_scores = logits_last.float()
             for proc in procs:
                 next_scores = proc(input_ids, next_scores)
             if output_scores:

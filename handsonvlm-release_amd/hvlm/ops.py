@@ -188,6 +188,25 @@ def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=
     return dqkv
 
 
+def gemv(w: torch.Tensor, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out=None) -> torch.Tensor:
+    """y[N] = w[N,K] @ x[K] (+ residual)."""
+    _chk(w, BF16, "gemv.w"); _chk(x, BF16, "gemv.x")
+    N, K = w.shape
+    assert x.numel() == K and w.stride(1) == 1
+    y = torch.empty((N,), dtype=BF16, device=w.device) if out is None else out
+    check(_lib.load().hvlm_gemv_bf16(_p(w), _p(x), _p(y), _p(residual), N, K, w.stride(0), _stream()), "gemv")
+    return y
+
+
+def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, S: int, H: int, dh: int, scale: float):
+    _chk(q, BF16, "attn_decode.q")
+    assert k_cache.stride(1) == 1 and k_cache.stride(0) == v_cache.stride(0)
+    out = torch.empty((H * dh,), dtype=BF16, device=q.device)
+    check(_lib.load().hvlm_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(out), S, H, dh, k_cache.stride(0), scale,
+                                       _stream()), "attn_decode")
+    return out
+
+
 def swiglu_fwd(gu: torch.Tensor, out=None) -> torch.Tensor:
     _chk(gu, BF16, "swiglu.gu")
     assert gu.is_contiguous()

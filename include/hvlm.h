@@ -117,6 +117,26 @@ int hvlm_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                   void* ws, int B, int S, int H, int dh, int ld, int causal, float scale,
                   void* stream);
 
+/* Single-token decode (KV-cached generation, batch 1; the reference's sampling loop handsonvlm.py:543-647
+ * re-runs the full prefix per token — a cache is exact because appended tokens' input embeddings never change).
+ *   gemv: y[N] = W[N,K] @ x[K] (+ residual[N]); K % 8 == 0, K <= 32768.
+ *   attn_decode: q [H*dh] of the new token (already RoPE'd) against caches k/v [S, ld] (head h at column h*dh);
+ *                out [H*dh]. */
+int hvlm_gemv_bf16(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw,
+                   void* stream);
+int hvlm_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, int S, int H,
+                     int dh, int ld, float scale, void* stream);
+/* One decode step of the whole decoder stack from native code (replaces LlamaModel.forward for one new token at
+ * position `pos`): pointer tables are HOST arrays [L] of DEVICE pointers (fused weights as in hvlm/llama.py;
+ * kv_cache[l] is [max_len, cache_ld] in the fused qkv layout, row `pos` is written).  pos_dev points at a device
+ * int32 equal to pos.  ws: hvlm_llama_decode_ws_bytes(D, F) bytes.  hidden_out: final-normed hidden [D]. */
+size_t hvlm_llama_decode_ws_bytes(int D, int F);
+int hvlm_llama_decode_step(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
+                           const void* const* w_down, const void* const* ln1, const void* const* ln2,
+                           void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
+                           const int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D,
+                           int F, int H, int dh, int pos, int cache_ld, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * SwiGLU — transformers LlamaMLP: down(silu(gate(x)) * up(x)).  gu is the fused [M, 2F] output of
  * the concatenated gate|up projection (gate in columns [0,F), up in [F,2F)).

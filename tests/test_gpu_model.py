@@ -88,7 +88,10 @@ def test_forward_backward_vs_reference_golden(golden, project_after_pool):
         assert r[k] < 5e-2, (k, r[k])
 
 
-def test_sample_vs_reference_golden(golden):
+@pytest.mark.parametrize("use_kv_cache", [True, False])
+def test_sample_vs_reference_golden(golden, use_kv_cache):
+    """The reference's sample() re-runs the whole prefix per token (use_cache=False); both our cache-less loop and the
+    KV-cached loop (prefill + single-token decode kernels) must reproduce its trace."""
     g = golden("g6_sample.npz")
     m, cfg = tiny_model(training=False)
     ids, labels, mask, images, fh, fv = tiny_batch()
@@ -102,11 +105,11 @@ def test_sample_vs_reference_golden(golden):
 
     z = [2.0 * T(g["z"][i]) for i in range(g["z"].shape[0])]        # z_scale = 2
     so = m.sample(T(g["prompt"]), logits_processor=[force], max_length=n0 + len(forced), pad_token_id=0, eos_token_id=2,
-                  image=images[:1].to(torch.bfloat16), hand_noise=z)
+                  image=images[:1].to(torch.bfloat16), hand_noise=z, use_kv_cache=use_kv_cache)
     assert np.array_equal(so.sequences.cpu().numpy(), g["sequences"])
     assert so.pred_hands.shape == (1, 2, 4, 2)
     r = rel(so.pred_hands, g["pred_hands"])
-    REPORT["g6_pred_hands_rel"] = r
+    REPORT[f"g6_pred_hands_rel_kv{int(use_kv_cache)}"] = r
     print("pred_hands rel", r, so.pred_hands.flatten().tolist(), g["pred_hands"].flatten().tolist())
     assert r < 5e-2     # bf16 hidden state feeding an fp32 head
     # "eval traj ADE/FDE parity" (BASELINE.json metric): the metrics of the HIP trajectory vs those of the
@@ -116,7 +119,7 @@ def test_sample_vs_reference_golden(golden):
     valid = np.ones((1, 2), np.float32)
     ours = evaluate_traj_stochastic(so.pred_hands.cpu().numpy()[:, None], gt, valid)
     ref = R.evaluate_traj_stochastic(g["pred_hands"][:, None], gt, valid)
-    REPORT["g6_ade_fde_wde"] = dict(hip=[float(x) for x in ours], reference=[float(x) for x in ref])
+    REPORT[f"g6_ade_fde_wde_kv{int(use_kv_cache)}"] = dict(hip=[float(x) for x in ours], reference=[float(x) for x in ref])
     np.testing.assert_allclose(ours, ref, rtol=1e-2)
 
 
