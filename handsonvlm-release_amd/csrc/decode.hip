@@ -26,19 +26,36 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  for (int k = l * 8; k < K; k += 64 * 8) {
+  constexpr int UNR = 4;                         // ROWS*UNR 16-byte loads in flight per lane
+  const bf16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
+  int k = l * 8;
+  for (; k + (UNR - 1) * 512 < K; k += UNR * 512) {
+    u32x4 wv[UNR][ROWS];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k + u * 512);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[r] += bf_lo(wv[u][r][e]) * bf_lo(xv[e]) + bf_hi(wv[u][r][e]) * bf_hi(xv[e]);
+    }
+  }
+  for (; k < K; k += 512) {
     const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k);
-    u32x4 wv[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      const int n = min(n0 + r, N - 1);
-      wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + (size_t)n * ldw + k));
+      const u32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r] += bf_lo(wv[e]) * bf_lo(xv[e]) + bf_hi(wv[e]) * bf_hi(xv[e]);
     }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        acc[r] += bf_lo(wv[r][e]) * bf_lo(xv[e]) + bf_hi(wv[r][e]) * bf_hi(xv[e]);
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
@@ -52,53 +69,64 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
 }
 
 // One workgroup (256 threads) per head.  q [H*dh] (one token), K/V cache [S, ld] token-major.
-// Each wave takes keys w, w+4, ...; per key the 64 lanes hold dh/64 (1 or 2) channels each.
+// Phase 1: one key per thread (16-byte loads of its K row, q broadcast from LDS) -> scores in LDS;
+// phase 2: block softmax; phase 3: channel pairs x key groups stream V with coalesced 4-byte loads.
+// (A first version walked the keys serially per wave and was latency-bound: 7.6 ms per generated token.)
 template <int DH>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q,
                                                           const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ vc, bf16_t* __restrict__ out,
                                                           int S, int ld, float scale) {
-  constexpr int CPL = DH / 64;            // channels per lane
-  __shared__ float s_m[4], s_l[4];
-  __shared__ float s_o[4][DH];
-  const int h = blockIdx.x;
-  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float qv[CPL], o[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) { qv[c] = bf2f(q[h * DH + l * CPL + c]) * scale; o[c] = 0.f; }
-  float m = -INFINITY, lsum = 0.f;
-  for (int s = w; s < S; s += 4) {
-    const bf16_t* kp = kc + (size_t)s * ld + h * DH + l * CPL;
-    const bf16_t* vp = vc + (size_t)s * ld + h * DH + l * CPL;
-    float dot = 0.f, vv[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) { dot += qv[c] * bf2f(kp[c]); vv[c] = bf2f(vp[c]); }
-    dot = wave_sum(dot);
-    const float mn = fmaxf(m, dot);
-    const float a = __expf(m - mn), p = __expf(dot - mn);
-    lsum = lsum * a + p;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) o[c] = o[c] * a + p * vv[c];
-    m = mn;
-  }
-  if (l == 0) { s_m[w] = m; s_l[w] = lsum; }
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) s_o[w][l * CPL + c] = o[c];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);          // [DH]
+  float* red = qs + DH;                                  // [8]
+  float* part = red + 8;                                 // [G][DH] partial outputs
+  constexpr int CP = DH / 2;                             // channel pairs per key row
+  constexpr int G = 256 / CP;                            // key groups in phase 3
+  float* sc = part + G * DH;                             // [S] scores / probabilities
+  const int h = blockIdx.x, t = threadIdx.x;
+  if (t < DH) qs[t] = bf2f(q[h * DH + t]) * scale;
   __syncthreads();
-  if (w == 0) {
-    float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-    float L = 0.f, acc[CPL];
+  float mx = -INFINITY;
+  for (int s0 = t; s0 < S; s0 += 256) {
+    const bf16_t* kp = kc + (size_t)s0 * ld + h * DH;
+    float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) acc[c] = 0.f;
+    for (int c = 0; c < DH; c += 8) {
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float f = (s_m[i] == -INFINITY) ? 0.f : __expf(s_m[i] - M);
-      L += s_l[i] * f;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) acc[c] += s_o[i][l * CPL + c] * f;
+      for (int e = 0; e < 4; ++e) dot += bf_lo(kv[e]) * qs[c + 2 * e] + bf_hi(kv[e]) * qs[c + 2 * e + 1];
     }
+    sc[s0] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = block_max<4>(mx, red);
+  float sum = 0.f;
+  for (int s0 = t; s0 < S; s0 += 256) {
+    const float p = __expf(sc[s0] - mx);
+    sc[s0] = p;
+    sum += p;
+  }
+  sum = block_sum<4>(sum, red + 4);
+  __syncthreads();
+  const int cp = t % CP, g = t / CP;
+  float a0 = 0.f, a1 = 0.f;
+  const bf16_t* vbase = vc + h * DH + 2 * cp;
+#pragma unroll 8
+  for (int s0 = g; s0 < S; s0 += G) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(vbase + (size_t)s0 * ld);
+    const float p = sc[s0];
+    a0 += p * bf_lo(v);
+    a1 += p * bf_hi(v);
+  }
+  part[g * DH + 2 * cp] = a0;
+  part[g * DH + 2 * cp + 1] = a1;
+  __syncthreads();
+  if (t < DH) {
+    float acc = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) out[h * DH + l * CPL + c] = f2bf(acc[c] / L);
+    for (int i = 0; i < G; ++i) acc += part[i * DH + t];
+    out[h * DH + t] = f2bf(acc / sum);
   }
 }
 
@@ -112,7 +140,7 @@ extern "C" int hvlm_gemv_bf16(const void* W, const void* x, void* y, const void*
   HVLM_REQUIRE(W && x && y, "gemv: null pointer");
   HVLM_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw >= K && ldw % 8 == 0, "gemv: bad shape (K %% 8, ldw %% 8)");
   HVLM_REQUIRE(K * 2 <= 64 * 1024, "gemv: K too large for the LDS copy of x");
-  constexpr int ROWS = 4;
+  constexpr int ROWS = 2;
   const int waves = cdiv(N, ROWS);
   hipLaunchKernelGGL((gemv_kernel<ROWS>), dim3(cdiv(waves, 4)), dim3(256), K * 2, as_stream(stream), (const bf16_t*)W,
                      (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)residual, N, K, ldw);
@@ -124,11 +152,13 @@ extern "C" int hvlm_attn_decode(const void* q, const void* k_cache, const void* 
   HVLM_REQUIRE(q && k_cache && v_cache && out, "attn_decode: null pointer");
   HVLM_REQUIRE(S > 0 && H > 0 && ld >= H * dh, "attn_decode: bad shape");
   HVLM_REQUIRE(dh == 64 || dh == 128, "attn_decode: dh must be 64 or 128 (got %d)", dh);
+  const size_t lds = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + S) * 4;
+  HVLM_REQUIRE(lds <= 64 * 1024, "attn_decode: S=%d too long for the LDS score buffer", S);
   if (dh == 128)
-    hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(H), dim3(256), 0, as_stream(stream), (const bf16_t*)q,
+    hipLaunchKernelGGL((attn_decode_kernel<128>), dim3(H), dim3(256), lds, as_stream(stream), (const bf16_t*)q,
                        (const bf16_t*)k_cache, (const bf16_t*)v_cache, (bf16_t*)out, S, ld, scale);
   else
-    hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(H), dim3(256), 0, as_stream(stream), (const bf16_t*)q,
+    hipLaunchKernelGGL((attn_decode_kernel<64>), dim3(H), dim3(256), lds, as_stream(stream), (const bf16_t*)q,
                        (const bf16_t*)k_cache, (const bf16_t*)v_cache, (bf16_t*)out, S, ld, scale);
   return check_launch("attn_decode");
 }
