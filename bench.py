@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dedup", action="store_true", help="encode unique frames once (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
     return ap.parse_args()
 
@@ -161,6 +162,38 @@ def cpu_baseline(cfg, T):
                        "optimizer/pooling/splice not counted")}
 
 
+def eval_leg(model, cfg, T, device):
+    """Secondary number (never `value`): eval samples/s of the reference's decoding recipe (batch 1, one sample = CLIP on
+    100 frames + a T-token prompt + 12 generated tokens of which four are <hand_traj>, each decoded by the CVAE head),
+    with this build's KV cache.  Tokens are forced so the amount of work is fixed."""
+    from hvlm.synthetic import make_text_batch_np
+    ids, _ = make_text_batch_np(1, T, 7, n_hand=0)
+    ids = torch.from_numpy(ids)
+    g = torch.Generator(device=device).manual_seed(7)
+    base = torch.randn(1, 10, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
+    img = base[:, torch.arange(cfg.num_frames, device=device) % 10].contiguous()
+    forced = [11, 12, 32100, 13, 32100, 14, 32100, 15, 32100, 16, 17, 2]
+    n0 = ids.shape[1]
+
+    def force(input_ids, scores):
+        s = torch.full_like(scores, -1e9)
+        s[:, forced[input_ids.shape[1] - n0]] = 0.0
+        return s
+
+    def run():
+        return model.sample(ids, logits_processor=[force], max_length=n0 + len(forced), eos_token_id=2, image=img)
+    out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"samples_per_s": 1.0 / dt, "ms_per_sample": dt * 1e3, "new_tokens": len(forced), "hands_decoded": int(out.pred_hands.shape[2]),
+            "batch": 1, "kv_cache": True, "note": "reference recipe re-runs CLIP + full prefill per token (use_cache=False)"}
+
+
 def main():
     args = parse()
     from hvlm import dp as hdp
@@ -250,6 +283,11 @@ def main():
                                "traffic": None, "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}
+        if world == 1 and not args.no_eval:
+            try:
+                res["eval"] = eval_leg(model, cfg, T, device)
+            except Exception as ex:  # noqa
+                res["eval"] = {"error": str(ex)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(cfg, T)
