@@ -55,7 +55,7 @@ __device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_off, char* 
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 
 template <int VARIANT, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) void gemm_bf16_nt_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;            // waves per workgroup
   constexpr int FM = BM / WM / 32;       // 32-row A fragments per wave
   constexpr int FN = BN / WN / 32;       // 32-col B fragments per wave
@@ -339,7 +339,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void gemm_bf16_nt_kern
     auto stage_part = [&](int buf, int kt, int part) {
       const unsigned base = (unsigned)buf * STAGE_BYTES + dma_off;
       const int k0 = kt * BK;
-      if constexpr (PPW == 4) {
+      if constexpr (PPW == 8) {
+        glds16(ga[2 * part] + k0, base + (2 * part) * 1024u, smem);
+        glds16(ga[2 * part + 1] + k0, base + (2 * part + 1) * 1024u, smem);
+        glds16(gb[2 * part] + k0, base + TILE_BYTES + (2 * part) * 1024u, smem);
+        glds16(gb[2 * part + 1] + k0, base + TILE_BYTES + (2 * part + 1) * 1024u, smem);
+      } else if constexpr (PPW == 4) {
         glds16(ga[part] + k0, base + part * 1024u, smem);
         glds16(gb[part] + k0, base + TILE_BYTES + part * 1024u, smem);
       } else {   // PPW == 2: A pieces on even k-steps, B pieces on odd
@@ -527,6 +532,8 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 0: HVLM_LAUNCH_GEMM(0, 2, 4); break;
     case 2: HVLM_LAUNCH_GEMM(0, 4, 4); break;
     case 3: HVLM_LAUNCH_GEMM(1, 4, 4); break;
+    case 7: HVLM_LAUNCH_GEMM(1, 2, 2); break;
+    case 8: HVLM_LAUNCH_GEMM(0, 2, 2); break;
     case 4: HVLM_LAUNCH_GEMM(4, 2, 4); break;
     case 6: { const int full = grid; grid = grid < pgrid ? grid : pgrid; (void)full; HVLM_LAUNCH_GEMM(6, 2, 4); break; }
     case 5: HVLM_LAUNCH_GEMM(5, 2, 4); break;

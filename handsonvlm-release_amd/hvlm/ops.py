@@ -87,6 +87,32 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         out: Optional[torch.Tensor] = None, out_dtype=BF16) -> torch.Tensor:
+    """out[M,N] = act(opA(a) @ opB(b)^T + bias) + residual; trans_a: a is [K,M]; trans_b: b is [K,N]."""
+    if not trans_a and not trans_b:
+        return gemm_nt(a, b, bias=bias, residual=residual, act=act, out=out, out_dtype=out_dtype)
+    _chk(a, BF16, "gemm.a"); _chk(b, BF16, "gemm.b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    K, M = (a.shape[0], a.shape[1]) if trans_a else (a.shape[1], a.shape[0])
+    Kb, N = (b.shape[0], b.shape[1]) if trans_b else (b.shape[1], b.shape[0])
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    ldr = residual.stride(0) if residual is not None else 0
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_bf16(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), _p(bias),
+                                     _p(residual), ldr, act, 1 if out.dtype == torch.float32 else 0,
+                                     1 if trans_a else 0, 1 if trans_b else 0, _stream()), "gemm_bf16")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
 def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
     _chk(x, BF16, "transpose.x")

@@ -58,6 +58,16 @@ int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K
                       int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
                       int out_f32, void* stream);
 
+/* General form with K-strided operands (no transposed copies for the backward GEMMs):
+ *   trans_a: A is stored [K, M] (M contiguous, lda >= M); trans_b: B is stored [K, N] (ldb >= N).
+ *   dX = dY @ W  -> trans_b with B = W as stored;  dW = dY^T @ X -> trans_a + trans_b with A = dY, B = X as stored.
+ * Operand tiles are fetched through buffer descriptors (rows past the end read as zero): when both operands are
+ * K-strided K may be any positive value; otherwise K % 64 == 0.  Operands must be < 4 GiB each.
+ * trans_a = trans_b = 0 forwards to hvlm_gemm_bf16_nt. */
+int hvlm_gemm_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                   const void* bias, const void* residual, int ldr, int act, int out_f32, int trans_a,
+                   int trans_b, void* stream);
+
 /* out[C,R] = in[R,C]^T (bf16), LDS-tiled.  Rows r >= R_valid of `in` are treated as zero when
  * `R_pad` > R (out has leading dimension R_pad and its columns R..R_pad-1 are zero-filled): this
  * builds the K-padded transposed operands for the dW GEMMs. */

@@ -322,3 +322,18 @@ def test_fullsize_rmsnorm_swiglu_pool_idempotence(ops):
     assert rel(y2, y) <= 4e-3                                              # idempotent up to bf16 rounding
     tok = torch.full((2, 100, 257, 1024), 0.5, dtype=BF, device="cuda")
     assert torch.equal(ops.temporal_spatial_pool_fwd(tok, 2, 100, drop_cls=True), torch.full((2, 356, 1024), 0.5, dtype=BF, device="cuda"))
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(300, 520, 128, False, True), (1000, 1000, 520, True, True), (512, 768, 1000, True, True),
+                                         (384, 264, 192, True, False), (868, 4096, 1736, True, True)])
+def test_gemm_k_strided_operands_vs_oracle(ops, M, N, K, ta, tb):
+    """dX = dY @ W and dW = dY^T @ X on the operands as stored (hvlm_gemm_bf16 trans flags; ds_read_b64_tr_b16 fragments,
+    buffer-descriptor loads that zero the K tail when K is not a multiple of 64)."""
+    a, b = rnd(M, K, seed=40), rnd(N, K, seed=41)
+    ref = (a.float() @ b.float().t()).to(BF)
+    aa = a.t().contiguous() if ta else a
+    bb = b.t().contiguous() if tb else b
+    c = ops.gemm(aa.cuda(), bb.cuda(), trans_a=ta, trans_b=tb)
+    assert rel(c, ref) <= 1e-3
+    eye = torch.eye(256).to(BF); asym = rnd(256, 256, seed=42)
+    assert torch.equal(ops.gemm(eye.cuda(), asym.cuda(), trans_a=True, trans_b=True).cpu(), asym)      # I^T @ B as stored [K,N]
