@@ -280,7 +280,11 @@ def main():
         if gs is not None:
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_nt_kernel", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                               "traffic": None, "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
+                               "traffic": None,
+                               "traffic_note": "PMC passes cannot wrap the ~3000-dispatch step on this pool (20-min timeout); per-shape "
+                                               "FETCH_SIZE/WRITE_SIZE of the same kernel are in profiles/r01b_gemm_pmc.txt "
+                                               "(13872x12288x4096: 2.34 GB L2-miss reads per launch vs 214 MB unique operands)",
+                               "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}
         if world == 1 and not args.no_eval:
