@@ -64,8 +64,12 @@ def attach(model, buckets: GradBuckets):
         buckets.reduce_async(stack.layers[i].flat_g)
 
     def on_named(which: str):
+        if which == "head":
+            # lm_head's gradient (263 MB for 7B) is final before the decoder backward starts: reducing it here hides it
+            # under the whole backward instead of leaving it exposed at the end of the step.
+            buckets.reduce_async(model.lm_head_g)
         if which == "tail":
-            buckets.reduce_async(stack.norm_g, model.embed_g, model.lm_head_g, model.proj_w_g, model.proj_b_g)
+            buckets.reduce_async(stack.norm_g, model.embed_g, model.proj_w_g, model.proj_b_g)
             for p in model.hand_traj_decoder.parameters():
                 if p.grad is not None:
                     buckets.reduce_async(p.grad)

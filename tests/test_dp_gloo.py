@@ -54,6 +54,7 @@ def _worker(rank, world, port, ret):
     for i in range(3):
         ok &= bool(torch.allclose(m.stack.layers[i].flat_g, torch.full((1000,), 3.0 * (i + 1))))   # (1+2)*(i+1)
     ok &= bool(torch.allclose(m.embed_g, torch.full((16,), 3.0)))
+    ok &= bool(torch.allclose(m.lm_head_g, torch.full((16,), 1.0)))          # reduced at the 'head' hook
     ok &= bool(torch.allclose(m.stack.norm_g, torch.full((8,), 1.0)))
     ok &= bool(torch.allclose(m.hand_traj_decoder.w.grad, torch.full((4,), 2.0)))
     mean = m.stack.layers[0].flat_g * (1.0 / world)          # what AdamW(grad_scale=1/world) applies
