@@ -43,6 +43,8 @@ struct GemmArgs {
   const bf16_t* bias;
   const bf16_t* res;
   int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
+  int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
+  size_t slab;                  // elements between fp32 slabs
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -67,10 +69,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
   const int l31 = l & 31, hi = l >> 5;
 
   // ---- XCD-aware, grouped tile mapping ---------------------------------------------------
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int nwg = ntile * p.splits;
+  int ksl = 0;                           // K-slice of the tile being set up (split-K)
   auto tile_coords = [&](int vb, int& tm_, int& tn_) {
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    ksl = swz / ntile;
+    swz -= ksl * ntile;
     const int gsz = p.group_m * p.tiles_n;
     const int gid = swz / gsz;
     const int first_m = gid * p.group_m;
@@ -93,8 +99,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
       const int c = (l & 7) ^ ((row >> 1) & 7);            // source chunk for chunk position l&7
       const int ra = min(m0_ + row, p.M - 1);
       const int rb = min(n0_ + row, p.N - 1);
-      ga[i] = p.A + (size_t)ra * p.lda + c * 8;
-      gb[i] = p.B + (size_t)rb * p.ldb + c * 8;
+      ga[i] = p.A + (size_t)ra * p.lda + c * 8 + ksl * p.k_split;
+      gb[i] = p.B + (size_t)rb * p.ldb + c * 8 + ksl * p.k_split;
     }
   };
   set_pointers(m0, n0);
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   // ---- epilogue: lane holds row m, 4 consecutive columns per register quad ----------------
+  size_t c_slab = 0;                     // fp32 slab offset of the tile being written (split-K)
   auto epilogue_generic = [&](int m0, int n0) {
   #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
             }
           }
           if (p.out_f32) {
-            float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb;
+            float* cp = reinterpret_cast<float*>(p.C) + c_slab + (size_t)m * p.ldc + nb;
             if (full) {
               f32x4 o = {v[0], v[1], v[2], v[3]};
               *reinterpret_cast<f32x4*>(cp) = o;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
     }
   };
 
-  const int nk = p.K / BK;
+  const int nk = (p.splits > 1 ? p.k_split : p.K) / BK;
   if constexpr (VARIANT == 6) {
     // VARIANT 6: persistent workgroups.  Each workgroup walks output tiles vb = blockIdx.x + k*gridDim.x
     // (same XCD-aware order), running ONE flat K-tile pipeline across tile boundaries: the LDS-DMA of the
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
       const int cm0 = m0, cn0 = n0;
+      const size_t cslab = (size_t)ksl * p.slab;
       const int nvb = vb + (int)gridDim.x;
       const bool has_next = nvb < nwg;
       for (int kt = 0; kt < nk; ++kt, ++g) {
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
           __builtin_amdgcn_s_setprio(0);
         }
       }
+      c_slab = cslab;
       epilogue(cm0, cn0);
       if (!has_next) break;
       vb = nvb;
@@ -502,6 +511,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
+  p.splits = 1; p.k_split = K; p.slab = 0;
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 6;
@@ -547,4 +557,72 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   }
 #undef HVLM_LAUNCH_GEMM
   return check_launch("gemm_bf16_nt");
+}
+
+// ---- split-K for skinny problems (few output tiles, e.g. the batch-1 prefill M = 867) --------------------------
+namespace hvlm {
+namespace {
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ ws, int splits, size_t slab,
+                                                              const bf16_t* __restrict__ bias,
+                                                              const bf16_t* __restrict__ res, int ldr, int act,
+                                                              bf16_t* __restrict__ C, int ldc, int M, int N) {
+  const long total = (long)M * (N / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / (N / 4);
+    const int n = (int)(i - m * (N / 4)) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + m * (long)N + n);
+    for (int s = 1; s < splits; ++s) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(ws + s * slab + m * (long)N + n);
+      v += t;
+    }
+    float o[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (bias) o[e] += bf2f(bias[n + e]);
+      if (act == HVLM_ACT_QUICK_GELU) o[e] = quick_gelu(o[e]);
+      if (res) o[e] += bf2f(res[m * (long)ldr + n + e]);
+    }
+    u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(C + m * (long)ldc + n) = pk;
+  }
+}
+}  // namespace
+}  // namespace hvlm
+
+extern "C" size_t hvlm_gemm_splitk_ws_bytes(int M, int N, int splits) { return (size_t)splits * M * N * 4; }
+
+extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                                        int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
+                                        int splits, void* stream) {
+  HVLM_REQUIRE(A && B && C && ws, "gemm_splitk: null pointer");
+  HVLM_REQUIRE(M > 0 && N > 0 && K > 0 && splits >= 2, "gemm_splitk: bad shape / splits");
+  HVLM_REQUIRE(K % (BK * splits) == 0, "gemm_splitk: K=%d must be a multiple of %d*splits", K, BK);
+  HVLM_REQUIRE(N % 4 == 0 && lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
+               "gemm_splitk: bad leading dimensions (N %% 4)");
+  HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 7) == 0 && ((uintptr_t)ws & 15) == 0,
+               "gemm_splitk: alignment");
+  GemmArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
+  p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<6, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LDS_BYTES);
+    if (e != hipSuccess) { set_error("gemm_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
+    attr_done = true;
+  }
+  int dev = 0, cus = 256; hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  int grid = p.tiles_m * p.tiles_n * splits;
+  if (grid > (cus / 8) * 8) grid = (cus / 8) * 8;
+  hipLaunchKernelGGL((gemm_bf16_nt_kernel<6, 2, 4>), dim3(grid), dim3(512), LDS_BYTES, as_stream(stream), p);
+  int rc = check_launch("gemm_splitk");
+  if (rc) return rc;
+  const long total = (long)M * (N / 4);
+  int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, as_stream(stream), (const float*)ws, splits,
+                     (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, (bf16_t*)C, ldc, M, N);
+  return check_launch("gemm_splitk_finalize");
 }

@@ -79,6 +79,22 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     hook = _gemm_hook
     if hook is not None:
         hook(M, N, K, True)
+    # skinny problems (fewer output tiles than half the CUs): split K across workgroups
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles <= 96 and out.dtype == BF16 and N % 4 == 0 and K >= 1024:
+        splits = 1
+        for cand in (8, 4, 2):
+            if tiles * cand <= 288 and K % (64 * cand) == 0 and K // cand >= 512:
+                splits = cand
+                break
+        if splits > 1:
+            lib = _lib.load()
+            ws = torch.empty((lib.hvlm_gemm_splitk_ws_bytes(M, N, splits),), dtype=torch.uint8, device=a.device)
+            check(lib.hvlm_gemm_bf16_nt_splitk(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                               _p(bias), _p(residual), ldr, act, _p(ws), splits, _stream()), "gemm_splitk")
+            if hook is not None:
+                hook(M, N, K, False)
+            return out
     check(_lib.load().hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
                                         out.stride(0), _p(bias), _p(residual), ldr, act,
                                         1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")

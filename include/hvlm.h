@@ -58,6 +58,14 @@ int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K
                       int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
                       int out_f32, void* stream);
 
+/* Split-K variant for skinny problems (few 256x256 output tiles, e.g. the batch-1 prefill, M = 867): `splits` K-slices
+ * are computed by separate workgroups into fp32 slabs of `ws` (hvlm_gemm_splitk_ws_bytes) and summed, deterministically,
+ * by a finalize pass that applies bias / activation / residual and writes bf16 C.  K % (64*splits) == 0, N % 4 == 0. */
+size_t hvlm_gemm_splitk_ws_bytes(int M, int N, int splits);
+int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                             int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
+                             int splits, void* stream);
+
 /* General form with K-strided operands (no transposed copies for the backward GEMMs):
  *   trans_a: A is stored [K, M] (M contiguous, lda >= M); trans_b: B is stored [K, N] (ldb >= N).
  *   dX = dY @ W  -> trans_b with B = W as stored;  dW = dY^T @ X -> trans_a + trans_b with A = dY, B = X as stored.
