@@ -24,6 +24,7 @@
 //
 // Reference arithmetic replaced: every nn.Linear on the path (see include/hvlm.h).
 #include "common.h"
+#include "gemm_args.h"
 #include <stdlib.h>
 
 namespace hvlm {
@@ -35,17 +36,6 @@ constexpr int TILE_BYTES = BM * BK * 2;       // 32 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // A + B
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;    // 128 KiB, 2-deep ring
 constexpr int GROUP_M = 4;
-
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* B;
-  void* C;
-  const bf16_t* bias;
-  const bf16_t* res;
-  int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
-  int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
-  size_t slab;                  // elements between fp32 slabs
-};
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -514,7 +504,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.splits = 1; p.k_split = K; p.slab = 0;
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
-  const int variant = ve ? atoi(ve) : 6;
+  const int variant = ve ? atoi(ve) : 9;
   int grid = p.tiles_m * p.tiles_n;
   static int pgrid = 0;
   if (!pgrid) {
@@ -547,6 +537,11 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 4: HVLM_LAUNCH_GEMM(4, 2, 4); break;
     case 6: { const int full = grid; grid = grid < pgrid ? grid : pgrid; (void)full; HVLM_LAUNCH_GEMM(6, 2, 4); break; }
     case 5: HVLM_LAUNCH_GEMM(5, 2, 4); break;
+    case 9: {
+      const int rc = launch_gemm_pp(p, grid < pgrid ? grid : pgrid, as_stream(stream));
+      if (rc) return rc;
+      break;
+    }
     case 17: HVLM_LAUNCH_GEMM(17, 2, 4); break;
     case 129: HVLM_LAUNCH_GEMM(129, 2, 4); break;
     case 33: HVLM_LAUNCH_GEMM(33, 2, 4); break;
@@ -606,19 +601,17 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
   p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<6, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       LDS_BYTES);
-    if (e != hipSuccess) { set_error("gemm_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
-    attr_done = true;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    cus = (cus / 8) * 8;
   }
-  int dev = 0, cus = 256; hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
   int grid = p.tiles_m * p.tiles_n * splits;
-  if (grid > (cus / 8) * 8) grid = (cus / 8) * 8;
-  hipLaunchKernelGGL((gemm_bf16_nt_kernel<6, 2, 4>), dim3(grid), dim3(512), LDS_BYTES, as_stream(stream), p);
-  int rc = check_launch("gemm_splitk");
+  if (grid > cus) grid = cus;
+  int rc = launch_gemm_pp(p, grid, as_stream(stream));
+  if (rc) return rc;
+  rc = check_launch("gemm_splitk");
   if (rc) return rc;
   const long total = (long)M * (N / 4);
   int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;

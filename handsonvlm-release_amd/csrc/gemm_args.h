@@ -1,0 +1,21 @@
+// Argument block shared by the bf16 NT GEMM kernels (gemm.hip, gemm_pp.hip).
+#pragma once
+#include "common.h"
+
+namespace hvlm {
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const bf16_t* bias;
+  const bf16_t* res;
+  int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
+  int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
+  size_t slab;                  // elements between fp32 slabs
+};
+
+// gemm_pp.hip: 8-phase ping-pong kernel (persistent 256x256 tiles); grid = workgroups to launch.
+int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream);
+
+}  // namespace hvlm

@@ -1,0 +1,349 @@
+// bf16 NT GEMM, 8-phase "ping-pong" schedule for gfx950:  C[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.
+//
+// Same tile geometry and LDS image as gemm.hip (256x256 output tile, BK = 64, 8 waves, 128-B LDS rows with
+// the 16-B chunk permutation c ^ ((row>>1)&7), swapped-operand v_mfma_f32_32x32x16_bf16 so a lane owns one
+// output row and 4 consecutive columns), but a different schedule:
+//
+//   * the two wave groups (waves 0-3 / 4-7 = one wave of each group on every SIMD) run ONE BARRIER APART:
+//     while one group issues its MFMA cluster the other issues its LDS reads and LDS-DMA, then they swap.
+//     Every phase is  {ds_read sub-tile ; stage one half-tile ; s_waitcnt vmcnt(8) ; barrier ; MFMA ; barrier};
+//   * a K-tile is 4 phases = the 4 quadrants (64x32) of the wave's 128x64 output; the wave's rows / columns are
+//     split in two 64-row / 32-column halves 128 apart, so that quadrant order consumes the operand HALF-TILES
+//     (A rows 0-127 / 128-255, B rows 0-127 / 128-255; 16 KiB each) in the fixed order A0,B0 | B1 | A1 | -;
+//   * each phase re-stages ONE half-tile (2 LDS-DMA instructions per lane) two K-tiles ahead, into the slot
+//     whose last reader finished >= 2 phases earlier; 4 half-tiles (8 loads per lane) stay in flight across
+//     barriers and the wait is always the counted `vmcnt(8)`, never 0: every load gets a full K-tile of latency;
+//   * a half-tile is read one phase after the wait that retires it (both groups pass a barrier in between);
+//   * LDS-DMA uses buffer loads (`buffer_load_dwordx4 ... lds`): per-lane offsets are tile-independent 32-bit
+//     values, the tile base lives in the (scalar) descriptor, rows past M / N fall outside num_records;
+//   * persistent workgroups walk tiles in the XCD-aware grouped order of gemm.hip; the staging cursor runs across
+//     tile boundaries, so the epilogue of tile i overlaps the loads of tile i+1.  The two groups re-align at the
+//     epilogue (group 1 skips its last barrier, re-staggers after it) so both epilogues run concurrently.
+#include "common.h"
+#include "gemm_args.h"
+
+namespace hvlm {
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr unsigned HALF_BYTES = 128 * BK * 2;      // 16 KiB: 128 rows x 128 B
+constexpr unsigned TILE_BYTES = 2 * HALF_BYTES;    // one operand, one K-tile
+constexpr unsigned STAGE_BYTES = 2 * TILE_BYTES;   // A + B
+constexpr unsigned PP_LDS_BYTES = 2 * STAGE_BYTES; // 128 KiB
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ float quick_gelu_pp(float x) { return x / (1.f + __expf(-1.702f * x)); }
+
+#define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = l & 31, hi = l >> 5;
+  const int grp = w >> 2, wn = w & 3;    // grp: row half-pair AND ping-pong group; wn: column block
+
+  // ---- XCD-aware, grouped tile mapping (same order as gemm.hip) -------------------------------
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int nwg = ntile * p.splits;
+  auto tile_coords = [&](int vb, int& m0_, int& n0_, int& ksl_) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
+    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    ksl_ = swz / ntile;
+    swz -= ksl_ * ntile;
+    const int gsz = p.group_m * p.tiles_n;
+    const int gid = swz / gsz;
+    const int first_m = gid * p.group_m;
+    const int gm = min(p.tiles_m - first_m, p.group_m);
+    const int in = swz - gid * gsz;
+    m0_ = (first_m + in % gm) * BM;
+    n0_ = (in / gm) * BN;
+  };
+  const int nk = (p.splits > 1 ? p.k_split : p.K) / BK;
+
+  // ---- LDS-DMA: per-lane byte offsets inside an operand tile (tile independent) -----------------
+  // piece = 8 rows x 128 B written lane-linear; wave w feeds pieces 2w, 2w+1 of every half-tile.
+  unsigned voa[2][2], vob[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = h * 128 + (2 * w + i) * 8 + (l >> 3);
+      const int c = (l & 7) ^ ((row >> 1) & 7);              // source chunk for chunk position l&7
+      voa[h][i] = ((unsigned)row * (unsigned)p.lda + c * 8) * 2u;
+      vob[h][i] = ((unsigned)row * (unsigned)p.ldb + c * 8) * 2u;
+    }
+  const unsigned dma_off = (unsigned)(2 * w) * 1024u;
+
+  // staging cursor: descriptors of the tile being staged + K offset (bytes); all wave-uniform
+  struct Cursor {
+    __amdgpu_buffer_rsrc_t ra, rb;
+    unsigned koff;
+    int vb, kt;
+  };
+  auto make_desc = [&](Cursor& c) {
+    int m0_, n0_, ksl_;
+    tile_coords(c.vb, m0_, n0_, ksl_);
+    const size_t kbase = (size_t)ksl_ * p.k_split;
+    const size_t krem = (size_t)p.K - kbase;
+    const size_t ba = ((size_t)(p.M - m0_ - 1) * p.lda + krem) * 2;
+    const size_t bb = ((size_t)(p.N - n0_ - 1) * p.ldb + krem) * 2;
+    c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (size_t)m0_ * p.lda + kbase), 0,
+                                             ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
+    c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (size_t)n0_ * p.ldb + kbase), 0,
+                                             bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.kt == nk) {
+      c.kt = 0;
+      const int nv = c.vb + (int)gridDim.x;
+      if (nv < nwg) { c.vb = nv; make_desc(c); }
+      // else: past the last tile of this workgroup — keep loading this tile's K-tiles again (valid memory,
+      // slots nobody reads) so the counted vmcnt stays exact.
+    }
+    c.koff = (unsigned)c.kt * (BK * 2);
+  };
+  auto stage_a = [&](unsigned buf, int h, const Cursor& c) {
+    const unsigned base = buf * STAGE_BYTES + h * HALF_BYTES + dma_off;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(smem + base), 16, voa[h][0], c.koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(smem + base + 1024u), 16, voa[h][1], c.koff, 0, 0);
+  };
+  auto stage_b = [&](unsigned buf, int h, const Cursor& c) {
+    const unsigned base = buf * STAGE_BYTES + TILE_BYTES + h * HALF_BYTES + dma_off;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rb, (lds_ptr_t)(smem + base), 16, vob[h][0], c.koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rb, (lds_ptr_t)(smem + base + 1024u), 16, vob[h][1], c.koff, 0, 0);
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------
+  // A fragment i (32 rows): tile row (i>>1)*128 + grp*64 + (i&1)*32 + l31;  B fragment j: j*128 + wn*32 + l31
+  const int sw = (l31 >> 1) & 7;
+  unsigned koffl[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koffl[ks] = (unsigned)(((ks * 2 + hi) ^ sw) << 4);
+  const unsigned a_base = (unsigned)(grp * 64 + l31) * 128u;
+  const unsigned b_base = TILE_BYTES + (unsigned)(wn * 32 + l31) * 128u;
+  auto read_a = [&](unsigned sb, int i, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + koffl[ks]);
+  };
+  auto read_b = [&](unsigned sb, int j, bf16x8 (&f)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + (unsigned)j * HALF_BYTES + koffl[ks]);
+  };
+
+  f32x16 acc[2][4];                       // [column half j][row fragment i]
+
+  // ---- epilogues: lane holds row m, 4 consecutive columns per register quad -------------------
+  auto row_of = [&](int m0, int i) { return m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + l31; };
+  auto col_of = [&](int n0, int j, int g) { return n0 + j * 128 + wn * 32 + 8 * g + 4 * hi; };
+  auto epilogue_generic = [&](int m0, int n0, size_t c_slab) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = row_of(m0, i);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = col_of(n0, j, g);
+          if (nb >= p.N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+          const bool full = (nb + 3 < p.N);
+          if (p.bias) {
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(p.bias[nb + e]);
+          }
+          if (p.act == HVLM_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
+          }
+          if (p.res) {
+            const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(rp[e]);
+          }
+          if (p.out_f32) {
+            float* cp = reinterpret_cast<float*>(p.C) + c_slab + (size_t)m * p.ldc + nb;
+            if (full) {
+              f32x4 o = {v[0], v[1], v[2], v[3]};
+              *reinterpret_cast<f32x4*>(cp) = o;
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = v[e];
+            }
+          } else {
+            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
+            if (full) {
+              u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+              *reinterpret_cast<u32x2*>(cp) = o;
+            } else {
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = f2bf(v[e]);
+            }
+          }
+        }
+      }
+    }
+  };
+  // Fast path (tile inside N, bf16 output): bias preloaded once, the residual of one 32-row fragment fetched
+  // as ONE batch of 8-byte loads before it is consumed.
+  auto epilogue = [&](int m0, int n0, size_t c_slab) {
+    if (p.out_f32 || n0 + BN > p.N) { epilogue_generic(m0, n0, c_slab); return; }
+    u32x2 bias_r[2][4];
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_r[j][g] = *reinterpret_cast<const u32x2*>(p.bias + col_of(n0, j, g));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = row_of(m0, i);
+      const int mc = min(m, p.M - 1);
+      u32x2 res_r[2][4];
+      if (p.res) {
+        const bf16_t* rp = p.res + (size_t)mc * p.ldr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) res_r[j][g] = *reinterpret_cast<const u32x2*>(rp + col_of(n0, j, g));
+      }
+      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)mc * p.ldc;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+          if (p.bias) {
+            const u32x2 bb = bias_r[j][g];
+            v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+          }
+          if (p.act == HVLM_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
+          }
+          if (p.res) {
+            const u32x2 rr = res_r[j][g];
+            v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
+          }
+          if (m < p.M) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(cp + col_of(n0, j, g)) = o;
+          }
+        }
+    }
+  };
+
+  // ---- prologue: K-tile 0 (4 half-tiles) and A0,B0 of K-tile 1 in flight -------------------------
+  Cursor c1, c2;
+  c1.vb = blockIdx.x; c1.kt = 0; c1.koff = 0;
+  make_desc(c1);
+  stage_a(0, 0, c1); stage_b(0, 0, c1); stage_b(0, 1, c1); stage_a(0, 1, c1);
+  advance(c1);                            // c1 = K-tile 1 (its B1, A1 are staged in phases 0, 1 below)
+  stage_a(1, 0, c1); stage_b(1, 0, c1);
+  c2 = c1;
+  advance(c2);                            // c2 = K-tile 2
+  HVLM_VMCNT(8);                          // A0, B0 of K-tile 0 landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+
+  int vb = blockIdx.x;
+  unsigned g = 0;                         // running K-tile counter; K-tile g lives in LDS stage g & 1
+
+#define HVLM_MFMA_QUAD(J, I0, BF, AF0, AF1)                                                               \
+  do {                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));  /* pin: MFMAs stay inside this phase */    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
+      acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF0[ks], acc[J][I0], 0, 0, 0);         \
+      acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF1[ks], acc[J][I0 + 1], 0, 0, 0); \
+    }                                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+    asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
+#define HVLM_PHASE_SYNC()                 \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    HVLM_VMCNT(8);                        \
+    __builtin_amdgcn_s_barrier();         \
+  } while (0)
+
+  while (true) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+    for (int kt = 0; kt < nk; ++kt, ++g) {
+      const unsigned cb = g & 1u, ob = cb ^ 1u;
+      const unsigned sb = cb * STAGE_BYTES;
+      bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
+      // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
+      read_b(sb, 0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(sb, 0, fa0);
+      read_a(sb, 1, fa1);
+      stage_b(ob, 1, c1);
+      HVLM_PHASE_SYNC();
+      HVLM_MFMA_QUAD(0, 0, fb0, fa0, fa1);
+      __builtin_amdgcn_s_barrier();
+      // phase 1: quadrant (rows 0-63, cols 128-159) — reads B1; stages A1 of K-tile g+1
+      read_b(sb, 1, fb1);
+      stage_a(ob, 1, c1);
+      HVLM_PHASE_SYNC();
+      HVLM_MFMA_QUAD(1, 0, fb1, fa0, fa1);
+      __builtin_amdgcn_s_barrier();
+      // phase 2: quadrant (rows 128-191, cols 128-159) — reads A1; stages A0 of K-tile g+2 (slot read in phase 0)
+      read_a(sb, 2, fa0);
+      read_a(sb, 3, fa1);
+      stage_a(cb, 0, c2);
+      HVLM_PHASE_SYNC();
+      HVLM_MFMA_QUAD(1, 2, fb1, fa0, fa1);
+      __builtin_amdgcn_s_barrier();
+      // phase 3: quadrant (rows 128-191, cols 0-31) — B0 still in registers; stages B0 of K-tile g+2
+      stage_b(cb, 0, c2);
+      HVLM_PHASE_SYNC();
+      HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1);
+      c1 = c2;
+      advance(c2);
+      if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
+    }
+    int m0, n0, ksl;
+    tile_coords(vb, m0, n0, ksl);
+    epilogue(m0, n0, (size_t)ksl * p.slab);
+    // vmcnt(0) as a real S_WAITCNT (not inline asm) so the compiler's wait-count tracking sees the epilogue's
+    // loads retired; otherwise it guards the first ds_read of EVERY K-tile with its own vmcnt(0).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    vb += (int)gridDim.x;
+    if (vb >= nwg) break;
+  }
+  HVLM_VMCNT(0);
+#undef HVLM_MFMA_QUAD
+#undef HVLM_PHASE_SYNC
+}
+
+}  // namespace
+
+int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("gemm_pp: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return HVLM_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  return HVLM_OK;
+}
+
+}  // namespace hvlm
