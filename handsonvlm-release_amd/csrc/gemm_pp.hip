@@ -30,11 +30,23 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr unsigned HALF_BYTES = 128 * BK * 2;      // 16 KiB: 128 rows x 128 B
 constexpr unsigned TILE_BYTES = 2 * HALF_BYTES;    // one operand, one K-tile
 constexpr unsigned STAGE_BYTES = 2 * TILE_BYTES;   // A + B
-constexpr unsigned PP_LDS_BYTES = 2 * STAGE_BYTES; // 128 KiB
+constexpr unsigned RING_BYTES = 2 * STAGE_BYTES;    // 128 KiB operand ring
+constexpr unsigned EPI_BYTES = 4096;                // per-wave epilogue transpose buffer (one 32x32 fp32 fragment)
+constexpr unsigned PP_LDS_BYTES = RING_BYTES + 8 * EPI_BYTES;   // 160 KiB: the whole LDS of a CU
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ float quick_gelu_pp(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each; the result is rounded to bf16 anyway)
+__device__ __forceinline__ float quick_gelu_pp(float x) {
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+
+// 16-byte global store the compiler's wait-count tracking does not see (gfx9 reads store data at issue, so the
+// registers are free immediately).  With tracked stores pending at the top of the K loop the compiler guards every
+// first ds_read of a K-tile with its own `s_waitcnt vmcnt(0)` (it cannot order them against the LDS-DMA in flight).
+__device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+}
 
 #define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -74,7 +86,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
       const int row = h * 128 + (2 * w + i) * 8 + (l >> 3);
       const int c = (l & 7) ^ ((row >> 1) & 7);              // source chunk for chunk position l&7
       voa[h][i] = ((unsigned)row * (unsigned)p.lda + c * 8) * 2u;
-      vob[h][i] = ((unsigned)row * (unsigned)p.ldb + c * 8) * 2u;
+      // B tile row r holds output column (r&127 >> 5)*64 + (r>>7)*32 + (r&31): a wave's two 32-column fragments
+      // (one in each B half-tile) are ADJACENT in the output, 64 contiguous columns per wave.
+      const int rr = row & 127;
+      const int bcol = (rr >> 5) * 64 + h * 32 + (rr & 31);
+      vob[h][i] = ((unsigned)bcol * (unsigned)p.ldb + c * 8) * 2u;
     }
   const unsigned dma_off = (unsigned)(2 * w) * 1024u;
 
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
 
   // ---- epilogues: lane holds row m, 4 consecutive columns per register quad -------------------
   auto row_of = [&](int m0, int i) { return m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + l31; };
-  auto col_of = [&](int n0, int j, int g) { return n0 + j * 128 + wn * 32 + 8 * g + 4 * hi; };
+  auto col_of = [&](int n0, int j, int g) { return n0 + wn * 64 + j * 32 + 8 * g + 4 * hi; };
   auto epilogue_generic = [&](int m0, int n0, size_t c_slab) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -188,54 +204,119 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
       }
     }
   };
-  // Fast path (tile inside N, bf16 output): bias preloaded once, the residual of one 32-row fragment fetched
-  // as ONE batch of 8-byte loads before it is consumed.
+  // Fast path (tile inside N, bf16 output).  In the accumulator layout a lane owns ONE row and 4-column quads, so a
+  // direct store instruction touches 32 different cache lines with 8 bytes each; measured, that epilogue cost ~8 us
+  // per 256x256 tile (30 % of a K = 1024 GEMM).  Here every 32x32 fragment takes a round trip through a wave-private
+  // 4 KiB LDS buffer (fp32, 16-B chunks XOR-swizzled by row) and comes back with 8 consecutive columns per lane and
+  // 4 lanes per row: stores, residual and bias loads are 16 B per lane, 16 rows x 64 contiguous bytes per instruction.
+  char* const epi = smem + RING_BYTES + w * EPI_BYTES;
+  const int t_row = l >> 2, t_c = l & 3;                       // transposed layout: row (0..15) + 16*q, columns 8*t_c..+7
+  const bool fast_ok = !p.out_f32 && (p.ldc & 7) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+                       (!p.res || ((p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0));
   auto epilogue = [&](int m0, int n0, size_t c_slab) {
-    if (p.out_f32 || n0 + BN > p.N) { epilogue_generic(m0, n0, c_slab); return; }
-    u32x2 bias_r[2][4];
-    if (p.bias) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias_r[j][g] = *reinterpret_cast<const u32x2*>(p.bias + col_of(n0, j, g));
+    if (!fast_ok || n0 + BN > p.N) {
+      epilogue_generic(m0, n0, c_slab);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // tracked stores must not be pending at the top of the K loop (see above)
+      return;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = row_of(m0, i);
-      const int mc = min(m, p.M - 1);
-      u32x2 res_r[2][4];
-      if (p.res) {
-        const bf16_t* rp = p.res + (size_t)mc * p.ldr;
+    const int ncol0 = n0 + wn * 64 + 8 * t_c;
+    if (!p.res) {
+      // no residual: bias / activation in the accumulator layout, bf16 through LDS (80-B rows: conflict-free for the
+      // 8-B writes of 16 consecutive rows and for the 16-B reads of the transposed layout)
+      u32x2 bias_q[2][4];
+      if (p.bias) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) res_r[j][g] = *reinterpret_cast<const u32x2*>(rp + col_of(n0, j, g));
+          for (int g = 0; g < 4; ++g) bias_q[j][g] = *reinterpret_cast<const u32x2*>(p.bias + col_of(n0, j, g));
       }
-      bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)mc * p.ldc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mrow0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+            if (p.bias) {
+              const u32x2 bb = bias_q[j][g];
+              v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+            }
+            if (p.act == HVLM_ACT_QUICK_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
+            }
+            const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(epi + l31 * 80 + (2 * g + hi) * 8) = o;
+          }
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int r = t_row + 16 * q;
+            const u32x4 o = *reinterpret_cast<const u32x4*>(epi + r * 80 + t_c * 16);
+            const int m = mrow0 + 16 * q;
+            if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
+          }
+        }
+      }
+      return;
+    }
+    float bias_f[2][8];
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x4 bb = *reinterpret_cast<const u32x4*>(p.bias + ncol0 + j * 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias_f[j][2 * e] = bf_lo(bb[e]); bias_f[j][2 * e + 1] = bf_hi(bb[e]); }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mrow0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;   // + 16*q
+      u32x4 res_r[2][2];          // p.res != 0 on this path: loads and uses stay unconditional (see store16_untracked)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float v[4];
+        for (int q = 0; q < 2; ++q) {
+          const int mc = min(mrow0 + 16 * q, p.M - 1);
+          res_r[j][q] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + ncol0 + j * 32);
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+      for (int j = 0; j < 2; ++j) {
+        // accumulator layout -> LDS: row l31, 16-B chunk (2g + hi) at chunk position (2g + hi) ^ (l31 & 7)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+          *reinterpret_cast<f32x4*>(epi + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = o;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int r = t_row + 16 * q;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(epi + r * 128 + (((2 * t_c) ^ (r & 7)) << 4));
+          const f32x4 hi4 = *reinterpret_cast<const f32x4*>(epi + r * 128 + (((2 * t_c + 1) ^ (r & 7)) << 4));
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
           if (p.bias) {
-            const u32x2 bb = bias_r[j][g];
-            v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias_f[j][e];
           }
           if (p.act == HVLM_ACT_QUICK_GELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = quick_gelu_pp(v[e]);
           }
-          if (p.res) {
-            const u32x2 rr = res_r[j][g];
-            v[0] += bf_lo(rr[0]); v[1] += bf_hi(rr[0]); v[2] += bf_lo(rr[1]); v[3] += bf_hi(rr[1]);
+          {
+            u32x4 rr = res_r[j][q];
+            asm volatile("" : "+v"(rr));   // consume the load outside the `m < M` branch: nothing stays pending on any path
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rr[e]); v[2 * e + 1] += bf_hi(rr[e]); }
           }
+          const int m = mrow0 + 16 * q;
           if (m < p.M) {
-            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(cp + col_of(n0, j, g)) = o;
+            const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
           }
         }
+      }
     }
   };
 
@@ -318,10 +399,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     }
     int m0, n0, ksl;
     tile_coords(vb, m0, n0, ksl);
+    // vmcnt(0) as a real S_WAITCNT (not inline asm): the compiler's wait-count tracking then knows that no LDS-DMA
+    // is pending when the epilogue touches LDS; without it every ds_read at the top of the K loop gets a compiler
+    // vmcnt(0).  Placed BEFORE the epilogue so that only the prefetched K-tiles are waited for, not the stores.
     epilogue(m0, n0, (size_t)ksl * p.slab);
-    // vmcnt(0) as a real S_WAITCNT (not inline asm) so the compiler's wait-count tracking sees the epilogue's
-    // loads retired; otherwise it guards the first ds_read of EVERY K-tile with its own vmcnt(0).
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     vb += (int)gridDim.x;
     if (vb >= nwg) break;
   }
