@@ -221,8 +221,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     }
     const int ncol0 = n0 + wn * 64 + 8 * t_c;
     if (!p.res) {
-      // no residual: bias / activation in the accumulator layout, bf16 through LDS (80-B rows: conflict-free for the
-      // 8-B writes of 16 consecutive rows and for the 16-B reads of the transposed layout)
+      // no residual: bias / activation in the accumulator layout, bf16 through LDS.  Two 2 KiB buffers (64-B rows, the
+      // 16-B column pair p of row r stored at pair position p ^ ((r>>1)&3): 2-way conflicts on the 8-B writes, none on
+      // the 16-B reads of the transposed layout).
       u32x2 bias_q[2][4];
       if (p.bias) {
 #pragma unroll
@@ -230,11 +231,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) bias_q[j][g] = *reinterpret_cast<const u32x2*>(p.bias + col_of(n0, j, g));
       }
+      // software-pipelined over the 8 fragments f = (i, j):  write(f) ; store(f-1) ; read(f), alternating the two
+      // buffers: write(f) never targets the buffer read(f-1) may still be reading (issuing a write right behind an
+      // unfinished read of the same buffer produced wrong elements), and write(f+2) is ordered after read(f) through
+      // the registers store(f) consumed.
+      u32x4 o_prev[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int mrow0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int f = 0; f <= 8; ++f) {
+        const int i = f >> 1, j = f & 1;
+        if (f < 8) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float v[4];
@@ -249,14 +254,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
               for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
             }
             const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(epi + l31 * 80 + (2 * g + hi) * 8) = o;
+            *reinterpret_cast<u32x2*>(epi + (f & 1) * 2048 + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = o;
           }
+        }
+        if (f > 0) {
+          const int ip = (f - 1) >> 1, jp = (f - 1) & 1;
+          const int mrow0 = m0 + (ip >> 1) * 128 + grp * 64 + (ip & 1) * 32 + t_row;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int m = mrow0 + 16 * q;
+            if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + jp * 32, o_prev[q]);
+          }
+        }
+        if (f < 8) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int r = t_row + 16 * q;
-            const u32x4 o = *reinterpret_cast<const u32x4*>(epi + r * 80 + t_c * 16);
-            const int m = mrow0 + 16 * q;
-            if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
+            o_prev[q] = *reinterpret_cast<const u32x4*>(epi + (f & 1) * 2048 + r * 64 + ((t_c ^ ((r >> 1) & 3)) << 4));
           }
         }
       }
