@@ -146,17 +146,32 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   }
 }
 
-// out[d] = sum_r in[r][d]; one thread per column, rows strided over blockIdx.y slabs is not
-// needed here (rows <= 256): thread = column, loop rows.
+// out[d] = sum_r in[r][d] (fixed summation order: deterministic).  A block owns 64 columns; its 4 waves take rows
+// r = wave, wave+4, ... with 4 independent accumulators each (loads in flight), then combine through LDS.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ in,
                                                           void* __restrict__ out, int rows, int D,
                                                           int out_bf16) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += in[(size_t)r * D + d];
-  if (out_bf16) reinterpret_cast<bf16_t*>(out)[d] = f2bf(s);
-  else reinterpret_cast<float*>(out)[d] = s;
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (d < D) {
+    int r = rg;
+    for (; r + 12 < rows; r += 16) {
+      s0 += in[(size_t)r * D + d];
+      s1 += in[(size_t)(r + 4) * D + d];
+      s2 += in[(size_t)(r + 8) * D + d];
+      s3 += in[(size_t)(r + 12) * D + d];
+    }
+    for (; r < rows; r += 4) s0 += in[(size_t)r * D + d];
+  }
+  part[rg][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && d < D) {
+    const float s = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+    if (out_bf16) reinterpret_cast<bf16_t*>(out)[d] = f2bf(s);
+    else reinterpret_cast<float*>(out)[d] = s;
+  }
 }
 
 template <int TPR>
@@ -251,7 +266,7 @@ extern "C" int hvlm_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
 extern "C" int hvlm_reduce_rows_f32(const float* in, void* out, int rows, int D, int out_bf16,
                                     void* stream) {
   HVLM_REQUIRE(in && out && rows > 0 && D > 0, "reduce_rows: bad args");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(D, 256)), dim3(256), 0, as_stream(stream), in, out,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(D, 64)), dim3(256), 0, as_stream(stream), in, out,
                      rows, D, out_bf16);
   return check_launch("reduce_rows_f32");
 }

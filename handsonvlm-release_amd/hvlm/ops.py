@@ -17,7 +17,7 @@ from ._lib import check
 
 ACT_NONE = 0
 ACT_QUICK_GELU = 1
-NORM_BWD_BLOCKS = 256
+NORM_BWD_BLOCKS = 1024
 IGNORE_INDEX = -100
 BF16 = torch.bfloat16
 

@@ -91,7 +91,7 @@ int hvlm_colsum_bf16(const void* in, float* out, int R, int C, int ld_in, void* 
  *   bwd: dx = (add ? add : 0) + d(rmsnorm)/dx ; dw_partial[HVLM_NORM_BWD_BLOCKS, D] f32 partial
  *        sums of dy * xhat, reduced by hvlm_reduce_rows_f32.
  * ------------------------------------------------------------------------------------------ */
-#define HVLM_NORM_BWD_BLOCKS 256
+#define HVLM_NORM_BWD_BLOCKS 1024
 int hvlm_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int D, float eps,
                      void* stream);
 int hvlm_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""HBM-bound helper kernels on the bench shapes (GPU box): GB/s = (bytes read + bytes written) / time."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
+import torch
+from hvlm import ops
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+for (R, C) in [(13872, 4096), (13872, 12288), (13872, 22016), (13872, 11008)]:
+    x = torch.randn(R, C, device=dev).to(BF)
+    ms = timeit(lambda: ops.transpose(x))
+    y = ops.transpose(x)
+    ok = torch.equal(y[:, :R], x.t())
+    print(f"transpose {R}x{C}: {ms*1e3:.0f} us  {2*R*C*2/ms/1e6:.0f} GB/s  ok={ok}", flush=True)
+
+R, D = 13872, 4096
+x = torch.randn(R, D, device=dev).to(BF); w = torch.randn(D, device=dev).to(BF); dy = torch.randn(R, D, device=dev).to(BF)
+add = torch.randn(R, D, device=dev).to(BF)
+y, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+ms = timeit(lambda: ops.rmsnorm_fwd(x, w, 1e-6))
+print(f"rmsnorm_fwd {R}x{D}: {ms*1e3:.0f} us  {2*R*D*2/ms/1e6:.0f} GB/s")
+ms = timeit(lambda: ops.rmsnorm_bwd(dy, x, w, rstd, add=add))
+print(f"rmsnorm_bwd(+add, +reduce) {R}x{D}: {ms*1e3:.0f} us  {4*R*D*2/ms/1e6:.0f} GB/s")
