@@ -23,6 +23,7 @@
 // CLIPAttention (non-causal, dh = 64).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace hvlm {
 namespace {
@@ -30,8 +31,13 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_off, char* smem) {
-  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(smem + lds_off), 16, 0, 0);
+// LDS-DMA of 16 bytes per lane through a BUFFER load (base = wave-uniform pointer, per-lane 32-bit byte offset).
+// Not `global_load_lds`: that one is a FLAT-class instruction with an LDS memory operand, and while one is pending
+// the compiler's wait-count pass turns EVERY later lgkmcnt wait (i.e. every ds_read result) into `vmcnt(0) lgkmcnt(0)`
+// — the prefetch of the next tile, issued before the compute of the current one, was silently serialised.
+__device__ __forceinline__ void glds16(const bf16_t* base, unsigned byte_off, unsigned lds_off, char* smem) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, 0xffffffffu, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + lds_off), 16, byte_off, 0, 0, 0);
 }
 
 // byte offset of 16-byte chunk `c` (logical) of row `r` inside a swizzled [rows][COLS] bf16 tile
@@ -63,7 +69,7 @@ __device__ __forceinline__ void load_tile(char* smem, unsigned tile_off, const b
     const int cp = l % CPR;
     const int c = cp ^ swz_bits<COLS>(r);
     const int gr = min(row0 + r, row_lim - 1);
-    glds16(gbase + (long)gr * stride + c * 8, tile_off + (unsigned)pi * 1024u, smem);
+    glds16(gbase, (unsigned)(((long)gr * stride + c * 8) * 2), tile_off + (unsigned)pi * 1024u, smem);
   }
 }
 
@@ -234,6 +240,199 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         *reinterpret_cast<u32x2*>(op + d) = v;
       }
     if (lse && hi == 0) lse[((long)b * H + h) * S + qi] = m * LN2 + logf(ltot);
+  }
+}
+
+// =================================================================================================
+// forward, short non-causal sequences (CLIP: S = 257, dh = 64): K and V of one (batch, head) stay RESIDENT in LDS.
+//   One workgroup = one (batch, head), one wave per 32 queries (S = 257 -> 9 waves), K and V ([32*NKB rows][DH], row
+//   major, 16-B chunks XOR-swizzled by row) fetched ONCE by LDS-DMA, one barrier, no staging loop.  V is consumed
+//   through `ds_read_b64_tr_b16` (LDS transpose read: a 16-lane group reads a 4(key) x 16(d) block, lane q receives
+//   column d = q for the 4 keys), so the V^T pre-pass of the streaming kernel and its workspace traffic disappear.
+//   The streaming kernel pads S = 257 to 3 x 128 queries x 5 x 64 keys (1.86x the useful MFMA work); here the padding is
+//   9 x 32 by 9 x 32 (1.26x).  Same online-softmax body, 64 keys per step.
+// =================================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+template <int DH>
+__global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t* __restrict__ qkv,
+                                                                   bf16_t* __restrict__ out,
+                                                                   float* __restrict__ lse, int S, int H, int ld,
+                                                                   int nkb, int nitems, float scale_log2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = (int)blockDim.x >> 6;
+  const int l31 = l & 31, hi = l >> 5;
+  const int rows = nkb * 32;
+  const unsigned tile_bytes = (unsigned)rows * DH * 2;      // one of K / V
+  const unsigned buf_bytes = 2 * tile_bytes;                // K + V of one (batch, head)
+  constexpr int CPR = DH / 8;          // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;        // rows per wave-instruction (1 KiB piece)
+  constexpr unsigned ROWB = DH * 2;    // bytes per LDS row
+  const int qi = w * 32 + l31;
+
+  // PERSISTENT workgroup, two K/V buffers, one extra LOADER wave: the LDS-DMA of item i+1 is issued (by the loader) while
+  // the compute waves work on item i, so the fill latency is hidden.  The loader is a separate wave because the compiler
+  // guards LDS reads it cannot disambiguate (the ds_read_b64_tr_b16 of V) with a vmcnt wait for every LDS-DMA still
+  // pending IN THE SAME WAVE: issued by the compute waves, the prefetch was drained before the first P*V of each item.
+  auto issue_kv = [&](int item, unsigned buf) {
+    const int b = item / H, h = item - b * H;
+    const bf16_t* kbase = qkv + (long)b * S * ld + (long)H * DH + h * DH;
+    const bf16_t* vbase = kbase + (long)H * DH;
+    const int npiece = rows / RPI;
+    for (int pi = 0; pi < npiece; ++pi) {              // the loader wave alone (see below)
+      const int r = pi * RPI + l / CPR;
+      const int c = (l % CPR) ^ swz_bits<DH>(r);
+      const long gr = (long)min(r, S - 1) * ld + c * 8;
+      glds16(kbase, (unsigned)(gr * 2), buf + (unsigned)pi * 1024u, smem);
+      glds16(vbase, (unsigned)(gr * 2), buf + tile_bytes + (unsigned)pi * 1024u, smem);
+    }
+  };
+  auto load_q = [&](int item, bf16x8 (&q)[DH / 16]) {
+    const int b = item / H, h = item - b * H;
+    const bf16_t* qp = qkv + ((long)b * S + min(qi, S - 1)) * ld + h * DH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  };
+
+  // The loop is VALU-bound (32 quarter-rate v_exp_f32 per 16 MFMAs), so everything else is kept off the VALU:
+  //  * per-lane LDS offsets are loop invariants (the row swizzle only sees lane bits: key-block bases are multiples
+  //    of 16 rows), the key block enters as ONE add per step + instruction offsets;
+  //  * the score scale is folded into the exponent: p = exp2(fma(s, scale, -m)), the running max is taken on raw scores;
+  //  * O and the row sum are rescaled only when some lane's maximum moved (wave-uniform branch);
+  //  * the tail mask exists only in the code of the last, partial key tile; accumulators start from an inline 0.
+  // V fragments: lane p of a 16-lane group points at key (p>>2), d-chunk (p&3)*4 of a 4(key) x 16(d) block and
+  // receives d = db*32 + l31 for the 4 keys (ds_read_b64_tr_b16); two reads = the 8 k-slots of the P registers.
+  const int p16 = l & 15, g16 = l31 >> 4;
+  unsigned k_off[DH / 16], v_off[DH / 32][2];
+#pragma unroll
+  for (int ks = 0; ks < DH / 16; ++ks) k_off[ks] = tile_addr<DH>(l31, ks * 2 + hi);
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      v_off[db][hf] = tile_bytes + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const bool loader = (w == nw - 1);                   // wave-uniform
+  bf16x8 qf[DH / 16], qn[DH / 16];
+  int item = blockIdx.x;
+  if (loader) issue_kv(item, 0);
+  else load_q(item, qf);
+  for (unsigned it = 0; item < nitems; ++it, item += (int)gridDim.x) {
+    const unsigned base = (it & 1u) * buf_bytes;
+    // Loader: K/V of this item landed (a real S_WAITCNT, not inline asm: the compiler's wait-count pass must see it).
+    // Compute waves wait for nothing here: their next Q fragments were moved into place before the output stores of
+    // the previous item were issued, so those stores (write acknowledgements) are never waited for.
+    if (loader) __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();                                     // everyone is done with the other buffer
+    const int nitem = item + (int)gridDim.x;
+    if (loader) {
+      if (nitem < nitems) issue_kv(nitem, buf_bytes - base);
+      continue;
+    }
+    if (nitem < nitems) load_q(nitem, qn);
+    f32x16 o[DH / 32];
+#pragma unroll
+    for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+
+    auto v_frag = [&](int db, unsigned key_bytes) -> bf16x8 {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + base + v_off[db][0] + key_bytes));
+      const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + base + v_off[db][1] + key_bytes));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    auto tile_body = [&](int kv0, auto nkb_tag, auto mask_tag) {
+      constexpr int NKB = decltype(nkb_tag)::value;
+      constexpr bool MASK = decltype(mask_tag)::value;
+      const unsigned kvb = (unsigned)kv0 * ROWB;
+      f32x16 sc[NKB];
+#pragma unroll
+      for (int ks = 0; ks < DH / 16; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          const bf16x8 kf = lds_frag128(smem, base + k_off[ks] + kvb + (unsigned)(kb * 32) * ROWB);
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
+        }
+      if constexpr (MASK) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kv0 + kb * 32 + crow(r, hi) >= S) sc[kb][r] = -INFINITY;
+      }
+      float mx = sc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      mx = fmaxf(mx, xlane32(mx));
+      const float mnew = fmaxf(m, mx * scale_log2);
+      if (__builtin_amdgcn_ballot_w64(mnew > m)) {      // some lane's maximum moved: rescale (first tile: m = -inf -> 0)
+        const float alpha = fast_exp2(m - mnew);
+        lsum *= alpha;
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m = mnew;
+      }
+      float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = fast_exp2(__builtin_fmaf(sc[kb][r], scale_log2, -m));
+          const float p1 = fast_exp2(__builtin_fmaf(sc[kb][r + 1], scale_log2, -m));
+          sc[kb][r] = p0; sc[kb][r + 1] = p1;
+          psum0 += p0; psum1 += p1;
+        }
+      lsum += psum0 + psum1;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = sc[kb][8 * sp + j];
+          const bf16x8 pf = pack8(pv);
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db)
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db], 0, 0, 0);
+        }
+    };
+    {
+      const int nfull = S / 64;                     // key tiles without a tail
+      int kb0 = 0;
+      for (; kb0 < 2 * nfull; kb0 += 2) tile_body(kb0 * 32, std::integral_constant<int, 2>{}, std::false_type{});
+      if (kb0 + 1 < nkb) tile_body(kb0 * 32, std::integral_constant<int, 2>{}, std::true_type{});
+      else if (kb0 < nkb) tile_body(kb0 * 32, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    const float ltot = lsum + xlane32(lsum);
+    if (nitem < nitems) {                    // next item's Q: in place BEFORE the stores below (see the loop top)
+#pragma unroll
+      for (int ks = 0; ks < DH / 16; ++ks) qf[ks] = qn[ks];
+    }
+    if (qi < S) {
+      const int b = item / H, h = item - b * H;
+      const float inv = __builtin_amdgcn_rcpf(ltot);
+      bf16_t* op = out + ((long)b * S + qi) * (long)(H * DH) + h * DH;
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * hi;
+          u32x2 v = {pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                     pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+          *reinterpret_cast<u32x2*>(op + d) = v;
+        }
+      if (lse && hi == 0) lse[((long)b * H + h) * S + qi] = m * LN2 + logf(ltot);
+    }
   }
 }
 
@@ -553,7 +752,26 @@ static int launch_head_transpose(const bf16_t* src, bf16_t* dst, int B, int S, i
 template <int DH, bool CAUSAL>
 static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int B, int S, int H, int ld,
                     float scale, hipStream_t st) {
-  int rc = launch_head_transpose<DH>(qkv, ws, B, S, H, ld, 2 * H * DH, st);
+  int rc;
+  if constexpr (!CAUSAL && DH == 64) {
+    // short sequences: K/V resident in LDS, one workgroup per (batch, head), no V^T pre-pass
+    const int nkb = (S + 31) / 32;
+    if (nkb <= 9 && !getenv("HVLM_ATTN_NO_RESIDENT")) {
+      const int lds = 2 * 2 * nkb * 32 * DH * 2;       // two (K + V) buffers
+      rc = set_lds(attn_fwd_resident_kernel<DH>, lds, "attn_fwd_resident");
+      if (rc) return rc;
+      static int cus = 0;
+      if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      }
+      const int nitems = B * H;
+      hipLaunchKernelGGL((attn_fwd_resident_kernel<DH>), dim3(nitems < cus ? nitems : cus), dim3(64 * (nkb + 1)), lds, st, qkv, out, lse,
+                         S, H, ld, nkb, nitems, scale * LOG2E);
+      return check_launch("attn_fwd_resident");
+    }
+  }
+  rc = launch_head_transpose<DH>(qkv, ws, B, S, H, ld, 2 * H * DH, st);
   if (rc) return rc;
   constexpr int LDS = 2 * 2 * 64 * DH * 2;
   // rows per workgroup: 128 (4 waves) or 96 (3 waves) — whichever wastes fewer query rows (S=257 -> 96)
