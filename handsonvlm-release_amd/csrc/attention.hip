@@ -507,7 +507,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
     bf16_t* __restrict__ dqkv, int S, int H, int ld, int S_pad, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
-  const unsigned sK = 0, sV = KT, sKT = 2 * KT;
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
@@ -545,15 +544,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
   const bf16_t* vbase = qkv + tok0 * ld + 2L * H * DH + h * DH;
   const bf16_t* ktbase = kt_g + ((long)b * H + h) * DH * (long)S_pad;
 
+  // two LDS stages: the tiles of step kt+1 are in flight while step kt is computed (the single-stage version exposed
+  // the full fill latency on every step, with one workgroup of 4 waves per CU to hide it)
+  constexpr unsigned STAGE = 3 * KT;
+  auto stage = [&](int buf, int kt) {
+    const unsigned o = (unsigned)buf * STAGE;
+    load_tile<64, DH>(smem, o, kbase, ld, kt * 64, S, w, l);
+    load_tile<64, DH>(smem, o + KT, vbase, ld, kt * 64, S, w, l);
+    load_tile<DH, 64>(smem, o + 2 * KT, ktbase + kt * 64, S_pad, 0, DH, w, l);
+  };
+  stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * 64;
-    __syncthreads();   // previous tile fully consumed
-    load_tile<64, DH>(smem, sK, kbase, ld, kv0, S, w, l);
-    load_tile<64, DH>(smem, sV, vbase, ld, kv0, S, w, l);
-    load_tile<DH, 64>(smem, sKT, ktbase + kv0, S_pad, 0, DH, w, l);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();   // tile kt landed for everyone; everyone is done with tile kt-1
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     if (CAUSAL && kv0 > q0 + w * 32 + 31) continue;
+    const unsigned sK = (unsigned)(kt & 1) * STAGE, sV = sK + KT, sKT = sK + 2 * KT;
 
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -570,15 +577,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
         const bf16x8 vf = lds_frag128(smem, sV + a);
         dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
       }
+    // dS^T = P o (dP - delta); the softmax scale is applied once to dQ at the end.  The mask code exists only in
+    // the variant taken by boundary tiles (sequence tail / causal diagonal): wave-uniform choice.
+    const bool need_mask = (kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32);
+    if (need_mask) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kb * 32 + crow(r, hi);
-        float p = fast_exp2(s[kb][r] * scale_log2 - lse2);
-        if (key >= S || (CAUSAL && key > qi)) p = 0.f;
-        s[kb][r] = p * (dp[kb][r] - dlt) * scale;   // dS^T
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + crow(r, hi);
+          float p = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -lse2));
+          if (key >= S || (CAUSAL && key > qi)) p = 0.f;
+          s[kb][r] = p * (dp[kb][r] - dlt);
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -lse2)) * (dp[kb][r] - dlt);
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -604,7 +622,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 v = {pack_bf2(dq[db][4 * g], dq[db][4 * g + 1]), pack_bf2(dq[db][4 * g + 2], dq[db][4 * g + 3])};
+        u32x2 v = {pack_bf2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale),
+                   pack_bf2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale)};
         *reinterpret_cast<u32x2*>(op + d) = v;
       }
   }
@@ -621,9 +640,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
     int H, int ld, int S_pad, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
-  const unsigned sQ = 0, sDO = KT, sQT = 2 * KT, sDOT = 3 * KT;
-  float* s_lse = reinterpret_cast<float*>(smem + 4 * KT);   // [64] lse*log2e
-  float* s_dlt = s_lse + 64;                                // [64]
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
@@ -659,20 +675,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
   const float* lse_row = lse + ((long)b * H + h) * S;
   const float* dlt_row = delta + ((long)b * H + h) * S;
 
-  for (int qt = qt_begin; qt < nqt; ++qt) {
+  // two LDS stages (see the dQ kernel): tiles + the 64 lse / delta values of step qt+1 are fetched during step qt
+  constexpr unsigned STAGE = 4 * KT + 512;
+  float lse_n = 0.f, dlt_n = 0.f;               // wave 0: next step's lse*log2e / delta of query qq0 + tid
+  auto stage = [&](int buf, int qt) {
+    const unsigned o = (unsigned)buf * STAGE;
     const int qq0 = qt * 64;
-    __syncthreads();
-    load_tile<64, DH>(smem, sQ, qbase, ld, qq0, S, w, l);
-    load_tile<64, DH>(smem, sDO, dobase, (long)H * DH, qq0, S, w, l);
-    load_tile<DH, 64>(smem, sQT, qtbase + qq0, S_pad, 0, DH, w, l);
-    load_tile<DH, 64>(smem, sDOT, dotbase + qq0, S_pad, 0, DH, w, l);
+    load_tile<64, DH>(smem, o, qbase, ld, qq0, S, w, l);
+    load_tile<64, DH>(smem, o + KT, dobase, (long)H * DH, qq0, S, w, l);
+    load_tile<DH, 64>(smem, o + 2 * KT, qtbase + qq0, S_pad, 0, DH, w, l);
+    load_tile<DH, 64>(smem, o + 3 * KT, dotbase + qq0, S_pad, 0, DH, w, l);
     if (tid < 64) {
       const int q = min(qq0 + tid, S - 1);
-      s_lse[tid] = lse_row[q] * LOG2E;
-      s_dlt[tid] = dlt_row[q];
+      lse_n = lse_row[q] * LOG2E;
+      dlt_n = dlt_row[q];
     }
+  };
+  if (qt_begin < nqt) stage(0, qt_begin);
+  for (int qt = qt_begin; qt < nqt; ++qt) {
+    const int qq0 = qt * 64;
+    const unsigned sQ = (unsigned)((qt - qt_begin) & 1) * STAGE, sDO = sQ + KT, sQT = sQ + 2 * KT, sDOT = sQ + 3 * KT;
+    float* s_lse = reinterpret_cast<float*>(smem + sQ + 4 * KT);   // [64] lse*log2e
+    float* s_dlt = s_lse + 64;                                     // [64]
+    if (tid < 64) { s_lse[tid] = lse_n; s_dlt[tid] = dlt_n; }       // this stage's slot: nobody reads it before the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();   // step qt landed for everyone; everyone is done with step qt-1
+    if (qt + 1 < nqt) stage(((qt + 1 - qt_begin) & 1), qt + 1);
     // tile fully masked for this wave: all queries of the tile precede all of the wave's keys
     if (CAUSAL && qq0 + 63 < k0 + w * 32) continue;
 
@@ -689,20 +717,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
         const bf16x8 dofr = lds_frag128(smem, sDO + a);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], dp, 0, 0, 0);
       }
-      float pvals[16], dsvals[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = qb * 32 + crow(r, hi);
-        const int q = qq0 + ql;
-        float p = fast_exp2(s[r] * scale_log2 - s_lse[ql]);
-        if (q >= S || ki >= S || (CAUSAL && ki > q)) p = 0.f;
-        pvals[r] = p;
-        dsvals[r] = p * (dp[r] - s_dlt[ql]) * scale;
-      }
+      // dS = P o (dP - delta); the softmax scale is applied once to dK at the end.  The kernel sits at the 256-VGPR
+      // limit: 8 elements in flight at a time, and no second (unmasked) code variant — it spilled.
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
-        const bf16x8 pf = pack8(pvals + 8 * sp);
-        const bf16x8 dsf = pack8(dsvals + 8 * sp);
+        float pvals[8], dsvals[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * sp + j;
+          const int ql = qb * 32 + crow(r, hi);
+          float pj = fast_exp2(__builtin_fmaf(s[r], scale_log2, -s_lse[ql]));
+          {
+            const int q = qq0 + ql;
+            if (q >= S || ki >= S || (CAUSAL && ki > q)) pj = 0.f;
+          }
+          pvals[j] = pj;
+          dsvals[j] = pj * (dp[r] - s_dlt[ql]);
+        }
+        const bf16x8 pf = pack8(pvals);
+        const bf16x8 dsf = pack8(dsvals);
         const int c1 = qb * 4 + 2 * sp;
 #pragma unroll
         for (int db = 0; db < DH / 32; ++db) {
@@ -724,7 +757,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 a = {pack_bf2(dk[db][4 * g], dk[db][4 * g + 1]), pack_bf2(dk[db][4 * g + 2], dk[db][4 * g + 3])};
+        u32x2 a = {pack_bf2(dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale),
+                   pack_bf2(dk[db][4 * g + 2] * scale, dk[db][4 * g + 3] * scale)};
         u32x2 c = {pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3])};
         *reinterpret_cast<u32x2*>(kp + d) = a;
         *reinterpret_cast<u32x2*>(vp + d) = c;
@@ -811,7 +845,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = check_launch("attn_delta"))) return rc;
   }
   {
-    constexpr int LDS = 3 * 64 * DH * 2;
+    constexpr int LDS = 2 * 3 * 64 * DH * 2;            // two stages of (K, V, K^T)
     if ((rc = set_lds(attn_bwd_dq_kernel<DH, CAUSAL>, LDS, "attn_bwd_dq"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)kT,
@@ -819,7 +853,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = check_launch("attn_bwd_dq"))) return rc;
   }
   {
-    constexpr int LDS = 4 * 64 * DH * 2 + 512;
+    constexpr int LDS = 2 * (4 * 64 * DH * 2 + 512);    // two stages of (Q, dO, Q^T, dO^T, lse, delta)
     if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
