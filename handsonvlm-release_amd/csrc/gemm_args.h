@@ -17,5 +17,7 @@ struct GemmArgs {
 
 // gemm_pp.hip: 8-phase ping-pong kernel (persistent 256x256 tiles); grid = workgroups to launch.
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream);
+// same kernel, both operands K-strided (A is [K, M], B is [K, N]; lda / ldb = row strides of those): dW = dY^T X
+int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream);
 
 }  // namespace hvlm

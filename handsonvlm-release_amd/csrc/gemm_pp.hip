@@ -21,6 +21,7 @@
 //     epilogue (group 1 skips its last barrier, re-staggers after it) so both epilogues run concurrently.
 #include "common.h"
 #include "gemm_args.h"
+#include <type_traits>
 
 namespace hvlm {
 
@@ -50,7 +51,18 @@ __device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
 
 #define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
+// TN = both operands K-strided: A is [K, M] (element (m,k) at A[k*lda + m]), B is [K, N].  This is dW = dY^T X on the
+// activations exactly as the forward / backward passes left them (token-major): no transposed copies.  What changes:
+//   * a half-tile is 64 k-rows x 128 columns (256-B LDS rows), a DMA piece = 4 k-rows;
+//   * MFMA fragments (8 consecutive k for one column) are gathered with `ds_read_b64_tr_b16` (a 16-lane group reads a
+//     4(k) x 16(col) block, lane q receives column q): two reads per fragment, same LDS bytes as the NT path's b128;
+//   * the 64-B segment of a row is XOR-ed with (k & 3): the four k-rows of one transpose read sit in four bank quarters;
+//   * the descriptor is re-based every K-tile and num_records ends at row K, so the K tail (K = tokens, any
+//     multiple of 8... any value) reads as zeros; columns past M / N read neighbouring data that is never stored.
+// (a __device__ template under two plain __global__ wrappers: instantiating a __global__ TEMPLATE whose body holds
+// inline asm with AMDGPU register constraints fails silently in the host pass and leaves its launch stub undefined)
+template <bool TN>
+__device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int l = tid & 63;
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
     m0_ = (first_m + in % gm) * BM;
     n0_ = (in / gm) * BN;
   };
-  const int nk = (p.splits > 1 ? p.k_split : p.K) / BK;
+  const int nk = TN ? (p.K + BK - 1) / BK : (p.splits > 1 ? p.k_split : p.K) / BK;
 
   // ---- LDS-DMA: per-lane byte offsets inside an operand tile (tile independent) -----------------
   // piece = 8 rows x 128 B written lane-linear; wave w feeds pieces 2w, 2w+1 of every half-tile.
@@ -83,14 +95,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = h * 128 + (2 * w + i) * 8 + (l >> 3);
-      const int c = (l & 7) ^ ((row >> 1) & 7);              // source chunk for chunk position l&7
-      voa[h][i] = ((unsigned)row * (unsigned)p.lda + c * 8) * 2u;
-      // B tile row r holds output column (r&127 >> 5)*64 + (r>>7)*32 + (r&31): a wave's two 32-column fragments
-      // (one in each B half-tile) are ADJACENT in the output, 64 contiguous columns per wave.
-      const int rr = row & 127;
-      const int bcol = (rr >> 5) * 64 + h * 32 + (rr & 31);
-      vob[h][i] = ((unsigned)bcol * (unsigned)p.ldb + c * 8) * 2u;
+      if constexpr (!TN) {
+        const int row = h * 128 + (2 * w + i) * 8 + (l >> 3);
+        const int c = (l & 7) ^ ((row >> 1) & 7);              // source chunk for chunk position l&7
+        voa[h][i] = ((unsigned)row * (unsigned)p.lda + c * 8) * 2u;
+        // B tile row r holds output column (r&127 >> 5)*64 + (r>>7)*32 + (r&31): a wave's two 32-column fragments
+        // (one in each B half-tile) are ADJACENT in the output, 64 contiguous columns per wave.
+        const int rr = row & 127;
+        const int bcol = (rr >> 5) * 64 + h * 32 + (rr & 31);
+        vob[h][i] = ((unsigned)bcol * (unsigned)p.ldb + c * 8) * 2u;
+      } else {
+        // piece = 4 k-rows x 256 B; lane -> k-row l>>4, chunk position l&15 holding source chunk cp ^ ((k&3)<<2)
+        const int krow = (2 * w + i) * 4 + (l >> 4);
+        const int c = (l & 15) ^ ((krow & 3) << 2);
+        voa[h][i] = ((unsigned)krow * (unsigned)p.lda + h * 128 + c * 8) * 2u;
+        const int bcol = (c >> 2) * 64 + h * 32 + (c & 3) * 8;  // same column permutation as the NT path
+        vob[h][i] = ((unsigned)krow * (unsigned)p.ldb + bcol) * 2u;
+      }
     }
   const unsigned dma_off = (unsigned)(2 * w) * 1024u;
 
@@ -103,24 +124,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   auto make_desc = [&](Cursor& c) {
     int m0_, n0_, ksl_;
     tile_coords(c.vb, m0_, n0_, ksl_);
-    const size_t kbase = (size_t)ksl_ * p.k_split;
-    const size_t krem = (size_t)p.K - kbase;
-    const size_t ba = ((size_t)(p.M - m0_ - 1) * p.lda + krem) * 2;
-    const size_t bb = ((size_t)(p.N - n0_ - 1) * p.ldb + krem) * 2;
-    c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (size_t)m0_ * p.lda + kbase), 0,
-                                             ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
-    c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (size_t)n0_ * p.ldb + kbase), 0,
-                                             bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
+    if constexpr (!TN) {
+      const size_t kbase = (size_t)ksl_ * p.k_split;
+      const size_t krem = (size_t)p.K - kbase;
+      const size_t ba = ((size_t)(p.M - m0_ - 1) * p.lda + krem) * 2;
+      const size_t bb = ((size_t)(p.N - n0_ - 1) * p.ldb + krem) * 2;
+      c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (size_t)m0_ * p.lda + kbase), 0,
+                                               ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
+      c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (size_t)n0_ * p.ldb + kbase), 0,
+                                               bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
+    } else {
+      // base = &A[kt*64][m0]; valid bytes = up to the end of row K-1 (rows >= K are out of range -> zeros)
+      const size_t k0 = (size_t)c.kt * BK;
+      const size_t ba = (((size_t)p.K - k0) * p.lda - m0_) * 2;
+      const size_t bb = (((size_t)p.K - k0) * p.ldb - n0_) * 2;
+      c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + k0 * p.lda + m0_), 0,
+                                               ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
+      c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + k0 * p.ldb + n0_), 0,
+                                               bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
+    }
   };
   auto advance = [&](Cursor& c) {
     if (++c.kt == nk) {
       c.kt = 0;
       const int nv = c.vb + (int)gridDim.x;
-      if (nv < nwg) { c.vb = nv; make_desc(c); }
+      if (nv < nwg) c.vb = nv;
       // else: past the last tile of this workgroup — keep loading this tile's K-tiles again (valid memory,
       // slots nobody reads) so the counted vmcnt stays exact.
+      make_desc(c);
+    } else if constexpr (TN) {
+      make_desc(c);                          // re-base on the next 64 k-rows
     }
-    c.koff = (unsigned)c.kt * (BK * 2);
+    c.koff = TN ? 0u : (unsigned)c.kt * (BK * 2);
   };
   auto stage_a = [&](unsigned buf, int h, const Cursor& c) {
     const unsigned base = buf * STAGE_BYTES + h * HALF_BYTES + dma_off;
@@ -141,16 +176,62 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   for (int ks = 0; ks < 4; ++ks) koffl[ks] = (unsigned)(((ks * 2 + hi) ^ sw) << 4);
   const unsigned a_base = (unsigned)(grp * 64 + l31) * 128u;
   const unsigned b_base = TILE_BYTES + (unsigned)(wn * 32 + l31) * 128u;
-  auto read_a = [&](unsigned sb, int i, bf16x8 (&f)[4]) {
+  // TN: lane p of a 16-lane group addresses k-row (p>>2) [+ 8*hi + 4*rr + 16*ks], columns (p&3)*4.. of its 16-column
+  // block and receives column l31 of the fragment; the 16-B chunk index is XOR-ed with ((k&3)<<2)
+  const int p16 = l & 15, g16 = l31 >> 4;
+  unsigned ta_off[2], tb_off;
+  {
+    const unsigned rowb = (unsigned)((p16 >> 2) + 8 * hi) * 256u + (unsigned)((p16 & 1) * 8);
+    const unsigned x = (unsigned)((p16 >> 2) & 3) << 2;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + koffl[ks]);
-  };
-  auto read_b = [&](unsigned sb, int j, bf16x8 (&f)[4]) {
+    for (int e = 0; e < 2; ++e)
+      ta_off[e] = rowb + (((unsigned)(grp * 8 + e * 4 + g16 * 2 + ((p16 & 3) >> 1)) ^ x) << 4);
+    tb_off = TILE_BYTES + rowb + (((unsigned)(wn * 4 + g16 * 2 + ((p16 & 3) >> 1)) ^ x) << 4);
+  }
+  // The transpose reads are issued by inline asm: the `ds_read_tr16_b64` builtin is modelled as a may-store LDS access,
+  // and the compiler guards every such access with `s_waitcnt vmcnt(0)` while an LDS-DMA of the same wave is pending —
+  // which is always, in this pipeline.  The wait for their results is the explicit lgkmcnt(0) in HVLM_MFMA_QUAD.
+  typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+#define HVLM_TR2(DST, ADDR, IMM)                                                                            \
+  do {                                                                                                      \
+    s16x4_t lo_, hi_;                                                                                       \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"              \
+                 : "=&v"(lo_), "=&v"(hi_) : "v"(ADDR), "n"(IMM), "n"((IMM) + 1024) : "memory");             \
+    const s16x8_t v_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                    \
+    DST = __builtin_bit_cast(bf16x8, v_);                                                                   \
+  } while (0)
+  auto read_a = [&](unsigned sb, auto i_tag, bf16x8 (&f)[4]) {
+    constexpr int i = decltype(i_tag)::value;
+    if constexpr (!TN) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + (unsigned)j * HALF_BYTES + koffl[ks]);
+      for (int ks = 0; ks < 4; ++ks)
+        f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + koffl[ks]);
+    } else {
+      const unsigned ad = lds0 + sb + ta_off[i & 1];
+      HVLM_TR2(f[0], ad, (i >> 1) * 16384 + 0 * 4096);
+      HVLM_TR2(f[1], ad, (i >> 1) * 16384 + 1 * 4096);
+      HVLM_TR2(f[2], ad, (i >> 1) * 16384 + 2 * 4096);
+      HVLM_TR2(f[3], ad, (i >> 1) * 16384 + 3 * 4096);
+    }
   };
+  auto read_b = [&](unsigned sb, auto j_tag, bf16x8 (&f)[4]) {
+    constexpr int j = decltype(j_tag)::value;
+    if constexpr (!TN) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + (unsigned)j * HALF_BYTES + koffl[ks]);
+    } else {
+      const unsigned ad = lds0 + sb + tb_off;
+      HVLM_TR2(f[0], ad, j * 16384 + 0 * 4096);
+      HVLM_TR2(f[1], ad, j * 16384 + 1 * 4096);
+      HVLM_TR2(f[2], ad, j * 16384 + 2 * 4096);
+      HVLM_TR2(f[3], ad, j * 16384 + 3 * 4096);
+    }
+  };
+  using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
 
   f32x16 acc[2][4];                       // [column half j][row fragment i]
 
@@ -352,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
 #define HVLM_MFMA_QUAD(J, I0, BF, AF0, AF1)                                                               \
   do {                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
+    if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* asm transpose reads landed */ \
     asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));  /* pin: MFMAs stay inside this phase */    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
@@ -382,23 +464,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
       const unsigned sb = cb * STAGE_BYTES;
       bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
-      read_b(sb, 0, fb0);
+      read_b(sb, T0{}, fb0);
       __builtin_amdgcn_sched_barrier(0);
-      read_a(sb, 0, fa0);
-      read_a(sb, 1, fa1);
+      read_a(sb, T0{}, fa0);
+      read_a(sb, T1{}, fa1);
       stage_b(ob, 1, c1);
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(0, 0, fb0, fa0, fa1);
       __builtin_amdgcn_s_barrier();
       // phase 1: quadrant (rows 0-63, cols 128-159) — reads B1; stages A1 of K-tile g+1
-      read_b(sb, 1, fb1);
+      read_b(sb, T1{}, fb1);
       stage_a(ob, 1, c1);
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(1, 0, fb1, fa0, fa1);
       __builtin_amdgcn_s_barrier();
       // phase 2: quadrant (rows 128-191, cols 128-159) — reads A1; stages A0 of K-tile g+2 (slot read in phase 0)
-      read_a(sb, 2, fa0);
-      read_a(sb, 3, fa1);
+      read_a(sb, T2{}, fa0);
+      read_a(sb, T3{}, fa1);
       stage_a(cb, 0, c2);
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(1, 2, fb1, fa0, fa1);
@@ -422,23 +504,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) {
   }
   HVLM_VMCNT(0);
 #undef HVLM_MFMA_QUAD
+#undef HVLM_TR2
 #undef HVLM_PHASE_SYNC
 }
 
-}  // namespace
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true>(p); }
 
-int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
+template <bool TN>
+int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
+  const void* kfn = TN ? (const void*)gemm_pp_tn_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
       set_error("gemm_pp: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return HVLM_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  if (TN) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   return HVLM_OK;
 }
+
+}  // namespace
+
+int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<false>(p, grid, stream); }
+int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<true>(p, grid, stream); }
 
 }  // namespace hvlm

@@ -15,6 +15,8 @@
 //     k-rows past the end of the matrix read as ZERO: K need not be a multiple of 64 when both operands are
 //     K-strided (K = number of tokens), and no zero-padded copies are needed.
 #include "common.h"
+#include "gemm_args.h"
+#include <stdlib.h>
 
 namespace hvlm {
 namespace {
@@ -292,6 +294,17 @@ extern "C" int hvlm_gemm_bf16(const void* A, const void* B, void* C, int M, int 
   int grid = p.tiles_m * p.tiles_n;
   if (grid > pgrid) grid = pgrid;
   hipStream_t st = as_stream(stream);
+  if (trans_a && trans_b && !getenv("HVLM_GEMM_TN_OLD")) {
+    // both operands K-strided (dW = dY^T X): the 8-phase ping-pong kernel with transpose reads (gemm_pp.hip)
+    GemmArgs q;
+    q.A = p.A; q.B = p.B; q.C = C; q.bias = p.bias; q.res = p.res;
+    q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldr = ldr; q.act = act; q.out_f32 = out_f32;
+    q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.group_m = 4;
+    q.splits = 1; q.k_split = K; q.slab = 0;
+    const int rc = launch_gemm_pp_tn(q, grid, st);
+    if (rc) return rc;
+    return check_launch("gemm_pp_tn");
+  }
   if (trans_a && trans_b) return launch<true, true>(p, grid, st);
   if (trans_a) return launch<true, false>(p, grid, st);
   return launch<false, true>(p, grid, st);
