@@ -430,16 +430,23 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   int vb = blockIdx.x;
   unsigned g = 0;                         // running K-tile counter; K-tile g lives in LDS stage g & 1
 
-#define HVLM_MFMA_QUAD(J, I0, BF, AF0, AF1)                                                               \
+  // W0..W3 (TN only): lgkmcnt that retires the transpose reads feeding k-step 0..3 of this phase (reads are issued
+  // k-step major); the wait asm takes the fragments as operands so the MFMAs cannot be scheduled above it.
+#define HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, KS, W)                                                        \
+  do {                                                                                                    \
+    if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(" #W ")" : "+v"(BF[KS]), "+v"(AF0[KS]), "+v"(AF1[KS])); \
+    acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0);           \
+    acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0);   \
+  } while (0)
+#define HVLM_MFMA_QUAD(J, I0, BF, AF0, AF1, W0, W1, W2, W3)                                               \
   do {                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* asm transpose reads landed */ \
     asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));  /* pin: MFMAs stay inside this phase */    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
-      acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF0[ks], acc[J][I0], 0, 0, 0);         \
-      acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[ks], AF1[ks], acc[J][I0 + 1], 0, 0, 0); \
-    }                                                                                                     \
+    HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, 0, W0);                                                           \
+    HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, 1, W1);                                                           \
+    HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, 2, W2);                                                           \
+    HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, 3, W3);                                                           \
     __builtin_amdgcn_s_setprio(0);                                                                        \
     asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -464,31 +471,46 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       const unsigned sb = cb * STAGE_BYTES;
       bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
-      read_b(sb, T0{}, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_a(sb, T0{}, fa0);
-      read_a(sb, T1{}, fa1);
+      const unsigned adb = lds0 + sb + tb_off, ada0 = lds0 + sb + ta_off[0], ada1 = lds0 + sb + ta_off[1];   // TN
+      if constexpr (!TN) {
+        read_b(sb, T0{}, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(sb, T0{}, fa0);
+        read_a(sb, T1{}, fa1);
+      } else {
+        HVLM_TR2(fb0[0], adb, 0 * 4096); HVLM_TR2(fa0[0], ada0, 0 * 4096); HVLM_TR2(fa1[0], ada1, 0 * 4096);
+        HVLM_TR2(fb0[1], adb, 1 * 4096); HVLM_TR2(fa0[1], ada0, 1 * 4096); HVLM_TR2(fa1[1], ada1, 1 * 4096);
+        HVLM_TR2(fb0[2], adb, 2 * 4096); HVLM_TR2(fa0[2], ada0, 2 * 4096); HVLM_TR2(fa1[2], ada1, 2 * 4096);
+        HVLM_TR2(fb0[3], adb, 3 * 4096); HVLM_TR2(fa0[3], ada0, 3 * 4096); HVLM_TR2(fa1[3], ada1, 3 * 4096);
+      }
       stage_b(ob, 1, c1);
       HVLM_PHASE_SYNC();
-      HVLM_MFMA_QUAD(0, 0, fb0, fa0, fa1);
+      HVLM_MFMA_QUAD(0, 0, fb0, fa0, fa1, 15, 12, 6, 0);
       __builtin_amdgcn_s_barrier();
       // phase 1: quadrant (rows 0-63, cols 128-159) — reads B1; stages A1 of K-tile g+1
       read_b(sb, T1{}, fb1);
       stage_a(ob, 1, c1);
       HVLM_PHASE_SYNC();
-      HVLM_MFMA_QUAD(1, 0, fb1, fa0, fa1);
+      HVLM_MFMA_QUAD(1, 0, fb1, fa0, fa1, 6, 4, 2, 0);
       __builtin_amdgcn_s_barrier();
       // phase 2: quadrant (rows 128-191, cols 128-159) — reads A1; stages A0 of K-tile g+2 (slot read in phase 0)
-      read_a(sb, T2{}, fa0);
-      read_a(sb, T3{}, fa1);
+      if constexpr (!TN) {
+        read_a(sb, T2{}, fa0);
+        read_a(sb, T3{}, fa1);
+      } else {
+        HVLM_TR2(fa0[0], ada0, 16384 + 0 * 4096); HVLM_TR2(fa1[0], ada1, 16384 + 0 * 4096);
+        HVLM_TR2(fa0[1], ada0, 16384 + 1 * 4096); HVLM_TR2(fa1[1], ada1, 16384 + 1 * 4096);
+        HVLM_TR2(fa0[2], ada0, 16384 + 2 * 4096); HVLM_TR2(fa1[2], ada1, 16384 + 2 * 4096);
+        HVLM_TR2(fa0[3], ada0, 16384 + 3 * 4096); HVLM_TR2(fa1[3], ada1, 16384 + 3 * 4096);
+      }
       stage_a(cb, 0, c2);
       HVLM_PHASE_SYNC();
-      HVLM_MFMA_QUAD(1, 2, fb1, fa0, fa1);
+      HVLM_MFMA_QUAD(1, 2, fb1, fa0, fa1, 12, 8, 4, 0);
       __builtin_amdgcn_s_barrier();
       // phase 3: quadrant (rows 128-191, cols 0-31) — B0 still in registers; stages B0 of K-tile g+2
       stage_b(cb, 0, c2);
       HVLM_PHASE_SYNC();
-      HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1);
+      HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1, 15, 15, 15, 15);
       c1 = c2;
       advance(c2);
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
@@ -504,6 +526,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   }
   HVLM_VMCNT(0);
 #undef HVLM_MFMA_QUAD
+#undef HVLM_MFMA_STEP
 #undef HVLM_TR2
 #undef HVLM_PHASE_SYNC
 }
