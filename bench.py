@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dedup", action="store_true", help="encode unique frames once (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
     return ap.parse_args()
@@ -100,15 +101,25 @@ class GemmEvents:
         else:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            self.pairs.append((self._cur, e, 2.0 * M * N * K))
+            self.pairs.append((self._cur, e, 2.0 * M * N * K, (M, N, K)))
 
     def summary(self):
         if not self.pairs:
             return None
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.pairs)
-        fl = sum(f for _, _, f in self.pairs)
+        ms = sum(a.elapsed_time(b) for a, b, _, _ in self.pairs)
+        fl = sum(f for _, _, f, _ in self.pairs)
         return dict(launches=len(self.pairs), total_ms=ms, total_flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
                     avg_us=ms * 1e3 / len(self.pairs))
+
+
+    def by_shape(self):
+        """[(M, N, K, launches, total_ms, TFLOP/s)] sorted by time — for gpurun_out/gemm_by_shape.json (--gemm-table)."""
+        agg = {}
+        for a, b, f, shp in self.pairs:
+            t = agg.setdefault(shp, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += a.elapsed_time(b); t[2] += f
+        return sorted(((*k, v[0], round(v[1], 3), round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in agg.items()),
+                      key=lambda r: -r[4])
 
 
 def cpu_baseline(cfg, T):
@@ -243,6 +254,10 @@ def main():
         dt = float(tmax.item())
     loss = float(out.loss.detach())
     gs = ev.summary()
+    if args.gemm_table and rank == 0 and gs:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/gemm_by_shape.json", "w") as f:
+            json.dump([dict(M=r[0], N=r[1], K=r[2], launches=r[3], total_ms=r[4], tflops=r[5]) for r in ev.by_shape()], f, indent=0)
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
     if rank == 0:

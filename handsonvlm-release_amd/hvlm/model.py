@@ -408,6 +408,7 @@ class HandsOnVLMForCausalLM:
             (c["head_loss"] * grad_scale).backward()
         ops.hand_gather_bwd_(c["emb"].grad.contiguous(), plan.hand_rows, dhidden, B, self.token_dim)
         if self.on_grads_ready is not None:
+            self.stack._join_side()              # lm_head's gradient was computed on the side stream
             self.on_grads_ready("head")
         dx = self.stack.backward(dhidden)
         self.embed_g32.zero_()
@@ -423,6 +424,7 @@ class HandsOnVLMForCausalLM:
             self.stack._dw(dtok, sv["feats"], self.proj_w_g, _round_up(dtok.shape[0], 64))
             ops.cast_f32_to_bf16(ops.colsum(dtok), out=self.proj_b_g)
         self._vis_saved = None
+        self.stack._join_side()                  # every weight gradient is final on the main stream from here on
         if self.on_grads_ready is not None:
             self.on_grads_ready("tail")
 
