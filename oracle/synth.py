@@ -141,3 +141,40 @@ def make_hands(B: int, seed: int = 5):
     fh = r.uniform(0.05, 0.95, size=(B, 2, 5, 2)).astype(np.float32)
     fv = np.ones((B, 2), dtype=np.float32)
     return torch.from_numpy(fh), torch.from_numpy(fv)
+
+
+# ---- stand-in tokenizer + conversations for the prompt-plumbing fixtures (g8) --------------------------------------
+class StandInTokenizer:
+    """Deterministic character-level tokenizer with the three properties the reference's masking arithmetic relies on:
+    a BOS in front of every call, "</s>" and "<hand_traj>" as single tokens, right padding with id 0."""
+    bos_token_id, eos_token_id, pad_token_id, model_max_length = 1, 2, 0, 2048
+
+    def _ids(self, text):
+        ids, i = [self.bos_token_id], 0
+        while i < len(text):
+            if text.startswith("</s>", i):
+                ids.append(self.eos_token_id); i += 4
+            elif text.startswith("<hand_traj>", i):
+                ids.append(32100); i += 11
+            else:
+                ids.append(3 + ord(text[i]) % 997); i += 1
+        return ids
+
+    def __call__(self, text, return_tensors=None, padding=None, max_length=None, truncation=None, add_special_tokens=True):
+        import types as _t
+        import torch as _torch
+        if isinstance(text, str):
+            return _t.SimpleNamespace(input_ids=self._ids(text))
+        rows = [self._ids(t)[:max_length] for t in text]
+        n = max(len(r) for r in rows)
+        return _t.SimpleNamespace(input_ids=_torch.tensor([r + [self.pad_token_id] * (n - len(r)) for r in rows], dtype=_torch.long))
+
+
+PROMPT_SOURCES = [
+    ([[{"from": "human", "value": "<image>\nWhere should my hand move to if I want to open the drawer?"},
+       {"from": "gpt", "value": "Sure! Here is the hand trajectory <hand_traj><hand_traj><hand_traj><hand_traj>."}]], True),
+    ([[{"from": "human", "value": "<image>\nWhat is happening?"}, {"from": "gpt", "value": "A person cuts an onion."},
+       {"from": "human", "value": "And then?"}, {"from": "gpt", "value": "They put it in the pan <hand_traj>."}]], True),
+    ([[{"from": "human", "value": "Describe a kitchen."}, {"from": "gpt", "value": "It has a sink."}],
+      [{"from": "human", "value": "Hi"}, {"from": "gpt", "value": "Hello there, how can I help you today?"}]], False),
+]

@@ -58,3 +58,23 @@ def test_config_json_roundtrip(tmp_path):
     assert raw["model_type"] == "handsonvlm" and raw["hidden_size"] == 5120 and raw["video_compress_mode"] == "temporal_spatial_pool"
     back = checkpoint.config_from_json(str(tmp_path))
     assert (back.hidden_size, back.num_hidden_layers, back.lambda_traj_kl, back.vision.hidden_size) == (5120, 40, 5e-3, 1024)
+
+
+def test_prompt_plumbing_vs_reference_golden(golden):
+    """tokenizer_image_token / preprocess_v1 (v1 template, label masking incl. the reference's off-by-two and the
+    multi-round and padded cases) against vectors produced by the reference functions with the same stand-in
+    tokenizer (oracle/gen_golden_prompt.py)."""
+    import numpy as np
+    from hvlm import prompt as P
+    from oracle.synth import PROMPT_SOURCES, StandInTokenizer
+    g = golden("g8_prompt.npz")
+    tok = StandInTokenizer()
+    assert P.tokenizer_image_token("A <image> b <image><image> c", tok) == g["tit"].tolist()
+    for n, (sources, has_image) in enumerate(PROMPT_SOURCES):
+        r = P.preprocess_v1(sources, tok, has_image=has_image)
+        assert np.array_equal(r["input_ids"].numpy(), g[f"ids{n}"])
+        assert np.array_equal(r["labels"].numpy(), g[f"labels{n}"])
+        assert (r["labels"] != P.IGNORE_INDEX).any()          # the fixtures exercise the supervised branch, not "ignored"
+    # image placeholder and hand tokens land where the splice / hand gather expect them
+    ids = P.preprocess_v1(PROMPT_SOURCES[0][0], tok, has_image=True)["input_ids"][0]
+    assert int((ids == P.IMAGE_TOKEN_INDEX).sum()) == 1 and int((ids == 32100).sum()) == 4
