@@ -501,7 +501,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  p.splits = 1; p.k_split = K; p.slab = 0;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f;
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 9;
@@ -600,7 +600,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -618,4 +618,68 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, as_stream(stream), (const float*)ws, splits,
                      (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, (bf16_t*)C, ldc, M, N);
   return check_launch("gemm_splitk_finalize");
+}
+
+// ---- fp8 (OCP e4m3) operands: CDNA4 v_mfma_scale_f32_32x32x64_f8f6f4 ------------------------------------------------
+namespace hvlm {
+namespace {
+// out[i] = e4m3(clamp(x[i] * scale, -448, 448)); 8 elements per thread
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ out,
+                                                           const float* __restrict__ scale_ptr, float scale_imm, long n8) {
+  const float sc = scale_ptr ? *scale_ptr : scale_imm;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = bf_lo(v[e]) * sc; f[2 * e + 1] = bf_hi(v[e]) * sc; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], -448.f), 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    const u32x2 o = {lo, hi};
+    reinterpret_cast<u32x2*>(out)[i] = o;
+  }
+}
+}  // namespace
+}  // namespace hvlm
+
+extern "C" int hvlm_quantize_fp8(const void* x, void* out, const float* scale_dev, float scale, long n, void* stream) {
+  HVLM_REQUIRE(x && out && n > 0 && n % 8 == 0, "quantize_fp8: n must be a positive multiple of 8");
+  HVLM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0, "quantize_fp8: alignment");
+  const long n8 = n / 8;
+  long grid = (n8 + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(quantize_fp8_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                     (unsigned char*)out, scale_dev, scale, n8);
+  return check_launch("quantize_fp8");
+}
+
+extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                float alpha, const void* bias, const void* residual, int ldr, int act, int out_f32,
+                                void* stream) {
+  HVLM_REQUIRE(A && B && C, "gemm_fp8: null operand");
+  HVLM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128", K);
+  HVLM_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 4 == 0, "gemm_fp8: bad leading dimensions");
+  HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_fp8: 16-byte alignment");
+  HVLM_REQUIRE(!residual || (ldr >= N && ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0), "gemm_fp8: bad residual");
+  HVLM_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0, "gemm_fp8: bias must be 8-byte aligned");
+  HVLM_REQUIRE(act == HVLM_ACT_NONE || act == HVLM_ACT_QUICK_GELU, "gemm_fp8: unknown act %d", act);
+  GemmArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)residual;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
+  p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    cus = (cus / 8) * 8;
+  }
+  int grid = p.tiles_m * p.tiles_n;
+  if (grid > cus) grid = cus;
+  const int rc = launch_gemm_pp_fp8(p, grid, as_stream(stream));
+  if (rc) return rc;
+  return check_launch("gemm_fp8_nt");
 }

@@ -61,8 +61,19 @@ __device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
 //     multiple of 8... any value) reads as zeros; columns past M / N read neighbouring data that is never stored.
 // (a __device__ template under two plain __global__ wrappers: instantiating a __global__ TEMPLATE whose body holds
 // inline asm with AMDGPU register constraints fails silently in the host pass and leaves its launch stub undefined)
-template <bool TN>
+//
+// FP8 = both operands are OCP e4m3 bytes ([M, K] / [N, K], K contiguous), C = alpha * A B^T (+ epilogue): the CDNA4
+// `v_mfma_scale_f32_32x32x64_f8f6f4` path (K = 64 per instruction at twice the bf16 rate; block scales fixed to 2^0 —
+// per-tensor scaling enters through `alpha`).  A K-tile is 128 fp8 = the same 128 LDS bytes per row as 64 bf16, so the
+// LDS image, the DMA pieces, the swizzle and the whole 8-phase schedule are unchanged; a fragment is two ds_read_b128
+// (32 k-bytes per lane), 4 MFMAs of 64 cycles per phase instead of 8 of 32.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <bool TN, bool FP8>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
+  static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
+  constexpr int ES = FP8 ? 1 : 2;          // operand element size in bytes
+  constexpr int NKS = FP8 ? 2 : 4;         // MFMA k-steps per K-tile
+  using frag_t = std::conditional_t<FP8, i32x8, bf16x8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int l = tid & 63;
@@ -86,7 +97,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     m0_ = (first_m + in % gm) * BM;
     n0_ = (in / gm) * BN;
   };
-  const int nk = TN ? (p.K + BK - 1) / BK : (p.splits > 1 ? p.k_split : p.K) / BK;
+  constexpr int BKE = BK * 2 / ES;          // K-tile in elements: 64 bf16 or 128 fp8 (128 bytes either way)
+  const int nk = TN ? (p.K + BK - 1) / BK : (p.splits > 1 ? p.k_split : p.K) / BKE;
 
   // ---- LDS-DMA: per-lane byte offsets inside an operand tile (tile independent) -----------------
   // piece = 8 rows x 128 B written lane-linear; wave w feeds pieces 2w, 2w+1 of every half-tile.
@@ -98,12 +110,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       if constexpr (!TN) {
         const int row = h * 128 + (2 * w + i) * 8 + (l >> 3);
         const int c = (l & 7) ^ ((row >> 1) & 7);              // source chunk for chunk position l&7
-        voa[h][i] = ((unsigned)row * (unsigned)p.lda + c * 8) * 2u;
+        voa[h][i] = (unsigned)row * (unsigned)p.lda * ES + c * 16u;
         // B tile row r holds output column (r&127 >> 5)*64 + (r>>7)*32 + (r&31): a wave's two 32-column fragments
         // (one in each B half-tile) are ADJACENT in the output, 64 contiguous columns per wave.
         const int rr = row & 127;
         const int bcol = (rr >> 5) * 64 + h * 32 + (rr & 31);
-        vob[h][i] = ((unsigned)bcol * (unsigned)p.ldb + c * 8) * 2u;
+        vob[h][i] = (unsigned)bcol * (unsigned)p.ldb * ES + c * 16u;
       } else {
         // piece = 4 k-rows x 256 B; lane -> k-row l>>4, chunk position l&15 holding source chunk cp ^ ((k&3)<<2)
         const int krow = (2 * w + i) * 4 + (l >> 4);
@@ -127,12 +139,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     if constexpr (!TN) {
       const size_t kbase = (size_t)ksl_ * p.k_split;
       const size_t krem = (size_t)p.K - kbase;
-      const size_t ba = ((size_t)(p.M - m0_ - 1) * p.lda + krem) * 2;
-      const size_t bb = ((size_t)(p.N - n0_ - 1) * p.ldb + krem) * 2;
-      c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (size_t)m0_ * p.lda + kbase), 0,
-                                               ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
-      c.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (size_t)n0_ * p.ldb + kbase), 0,
-                                               bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
+      const size_t ba = ((size_t)(p.M - m0_ - 1) * p.lda + krem) * ES;
+      const size_t bb = ((size_t)(p.N - n0_ - 1) * p.ldb + krem) * ES;
+      char* pa = const_cast<char*>(reinterpret_cast<const char*>(p.A)) + ((size_t)m0_ * p.lda + kbase) * ES;
+      char* pb = const_cast<char*>(reinterpret_cast<const char*>(p.B)) + ((size_t)n0_ * p.ldb + kbase) * ES;
+      c.ra = __builtin_amdgcn_make_buffer_rsrc(pa, 0, ba > 0xffffffffull ? 0xffffffffu : (unsigned)ba, 0x00020000);
+      c.rb = __builtin_amdgcn_make_buffer_rsrc(pb, 0, bb > 0xffffffffull ? 0xffffffffu : (unsigned)bb, 0x00020000);
     } else {
       // base = &A[kt*64][m0]; valid bytes = up to the end of row K-1 (rows >= K are out of range -> zeros)
       const size_t k0 = (size_t)c.kt * BK;
@@ -202,9 +214,24 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     const s16x8_t v_ = {lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};                    \
     DST = __builtin_bit_cast(bf16x8, v_);                                                                   \
   } while (0)
-  auto read_a = [&](unsigned sb, auto i_tag, bf16x8 (&f)[4]) {
+  // fp8: the 32 k-bytes of a lane are the two 16-B chunks (ks*4 + hi*2, +1) of its row
+  unsigned koff8[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) koff8[ks][e] = (unsigned)(((ks * 4 + hi * 2 + e) ^ sw) << 4);
+  auto read8 = [&](unsigned base, int ks) -> i32x8 {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base + koff8[ks][0]);
+    const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + base + koff8[ks][1]);
+    const i32x8 v = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+    return v;
+  };
+  auto read_a = [&](unsigned sb, auto i_tag, frag_t (&f)[NKS]) {
     constexpr int i = decltype(i_tag)::value;
-    if constexpr (!TN) {
+    if constexpr (FP8) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u, ks);
+    } else if constexpr (!TN) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + koffl[ks]);
@@ -216,9 +243,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       HVLM_TR2(f[3], ad, (i >> 1) * 16384 + 3 * 4096);
     }
   };
-  auto read_b = [&](unsigned sb, auto j_tag, bf16x8 (&f)[4]) {
+  auto read_b = [&](unsigned sb, auto j_tag, frag_t (&f)[NKS]) {
     constexpr int j = decltype(j_tag)::value;
-    if constexpr (!TN) {
+    if constexpr (FP8) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + b_base + (unsigned)j * HALF_BYTES, ks);
+    } else if constexpr (!TN) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
         f[ks] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base + (unsigned)j * HALF_BYTES + koffl[ks]);
@@ -434,9 +464,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   // k-step major); the wait asm takes the fragments as operands so the MFMAs cannot be scheduled above it.
 #define HVLM_MFMA_STEP(J, I0, BF, AF0, AF1, KS, W)                                                        \
   do {                                                                                                    \
-    if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(" #W ")" : "+v"(BF[KS]), "+v"(AF0[KS]), "+v"(AF1[KS])); \
-    acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0);           \
-    acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0);   \
+    if constexpr (KS < NKS) {                                                                             \
+      if constexpr (TN) asm volatile("s_waitcnt lgkmcnt(" #W ")" : "+v"(BF[KS]), "+v"(AF0[KS]), "+v"(AF1[KS])); \
+      if constexpr (FP8) {                                                                                \
+        acc[J][I0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0, SCALE1, 0, SCALE1); \
+        acc[J][I0 + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0, SCALE1, 0, SCALE1); \
+      } else {                                                                                            \
+        acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0);       \
+        acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
   } while (0)
 #define HVLM_MFMA_QUAD(J, I0, BF, AF0, AF1, W0, W1, W2, W3)                                               \
   do {                                                                                                    \
@@ -469,7 +506,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     for (int kt = 0; kt < nk; ++kt, ++g) {
       const unsigned cb = g & 1u, ob = cb ^ 1u;
       const unsigned sb = cb * STAGE_BYTES;
-      bf16x8 fb0[4], fb1[4], fa0[4], fa1[4];
+      frag_t fb0[NKS], fb1[NKS], fa0[NKS], fa1[NKS];
+      constexpr int SCALE1 = 0x7f7f7f7f;        // e8m0 block scales = 2^0
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
       const unsigned adb = lds0 + sb + tb_off, ada0 = lds0 + sb + ta_off[0], ada1 = lds0 + sb + ta_off[1];   // TN
       if constexpr (!TN) {
@@ -517,6 +555,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     }
     int m0, n0, ksl;
     tile_coords(vb, m0, n0, ksl);
+    if constexpr (FP8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][i][r] *= p.alpha;
+    }
     // vmcnt(0) as a real S_WAITCNT (not inline asm): the compiler's wait-count tracking then knows that no LDS-DMA
     // is pending when the epilogue touches LDS; without it every ds_read at the top of the K loop gets a compiler
     // vmcnt(0).  Placed BEFORE the epilogue so that only the prefetched K-tiles are waited for, not the stores.
@@ -531,13 +577,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #undef HVLM_PHASE_SYNC
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false, false>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true, false>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true>(p); }
 
-template <bool TN>
+template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = TN ? (const void*)gemm_pp_tn_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -546,14 +593,16 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
     }
     attr_done = true;
   }
-  if (TN) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 2) hipLaunchKernelGGL(gemm_pp_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   return HVLM_OK;
 }
 
 }  // namespace
 
-int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<false>(p, grid, stream); }
-int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<true>(p, grid, stream); }
+int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<0>(p, grid, stream); }
+int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<1>(p, grid, stream); }
+int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<2>(p, grid, stream); }
 
 }  // namespace hvlm

@@ -129,6 +129,42 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return out
 
 
+def quantize_fp8(x: torch.Tensor, scale) -> torch.Tensor:
+    """bf16 -> OCP e4m3 bytes (uint8 storage): out = e4m3(clamp(x * scale, +-448)).  `scale` is a python float or a
+    1-element fp32 GPU tensor (read on the device: no host sync)."""
+    _chk(x, BF16, "quantize_fp8.x")
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    if isinstance(scale, torch.Tensor):
+        assert scale.dtype == torch.float32 and scale.numel() == 1 and scale.is_cuda
+        check(_lib.load().hvlm_quantize_fp8(_p(x), _p(out), _p(scale), 0.0, x.numel(), _stream()), "quantize_fp8")
+    else:
+        check(_lib.load().hvlm_quantize_fp8(_p(x), _p(out), None, float(scale), x.numel(), _stream()), "quantize_fp8")
+    return out
+
+
+def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, alpha: float, bias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+                out_dtype=BF16) -> torch.Tensor:
+    """out[M,N] = act(alpha * a8[M,K] @ b8[N,K]^T + bias) + residual on e4m3 operands (uint8 storage), K % 128 == 0."""
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.is_cuda and b8.is_cuda
+    assert a8.dim() == 2 and b8.dim() == 2 and a8.shape[1] == b8.shape[1] and a8.stride(1) == 1 and b8.stride(1) == 1
+    M, K = a8.shape
+    N = b8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    ldr = residual.stride(0) if residual is not None else 0
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_fp8_nt(_p(a8), _p(b8), _p(out), M, N, K, a8.stride(0), b8.stride(0), out.stride(0),
+                                       float(alpha), _p(bias), _p(residual), ldr, act,
+                                       1 if out.dtype == torch.float32 else 0, _stream()), "gemm_fp8_nt")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
 def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
     _chk(x, BF16, "transpose.x")

@@ -66,6 +66,17 @@ int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int M, int N
                              int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
                              int splits, void* stream);
 
+/* fp8 (OCP e4m3) operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, block scales fixed to 1):
+ *   C[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual, A / B one byte per element, K % 128 == 0,
+ *   lda / ldb % 16 == 0; alpha = 1 / (scale_a * scale_b) for per-tensor scaled operands (BASELINE config 5: fp8 forward).
+ * hvlm_quantize_fp8: out[i] = e4m3(clamp(x[i] * scale, +-448)), scale from *scale_dev when non-NULL (no host sync)
+ * else from `scale`; n % 8 == 0.  Reference arithmetic replaced: none in the reference (it has no fp8 path); the
+ * parity test compares against the same product computed in fp32 from the de-quantised operands. */
+int hvlm_quantize_fp8(const void* x, void* out, const float* scale_dev, float scale, long n, void* stream);
+int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     float alpha, const void* bias, const void* residual, int ldr, int act, int out_f32,
+                     void* stream);
+
 /* General form with K-strided operands (no transposed copies for the backward GEMMs):
  *   trans_a: A is stored [K, M] (M contiguous, lda >= M); trans_b: B is stored [K, N] (ldb >= N).
  *   dX = dY @ W  -> trans_b with B = W as stored;  dW = dY^T @ X -> trans_a + trans_b with A = dY, B = X as stored.

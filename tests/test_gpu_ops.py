@@ -356,3 +356,44 @@ def test_gemm_splitk_vs_oracle(ops, M, N, K, epi):
     assert torch.equal(c1, c2)
     err = (c1.float().cpu() - ref).norm() / ref.norm()
     assert err < 3e-3, float(err)      # one bf16 rounding of the output (2^-9 relative per element)
+
+
+def _e4m3_decode(u8: torch.Tensor) -> torch.Tensor:
+    """OCP e4m3fn bytes -> fp32 (bias 7, no infinities, S.1111.111 = NaN); written out so the test does not depend on
+    torch's float8 support."""
+    u = u8.to(torch.int32)
+    sign = torch.where((u & 0x80) != 0, -1.0, 1.0)
+    e = (u >> 3) & 0xF
+    m = (u & 7).float()
+    normal = (1.0 + m / 8.0) * torch.pow(2.0, (e - 7).float())
+    sub = (m / 8.0) * 2.0 ** -6
+    return sign * torch.where(e == 0, sub, normal)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(300, 520, 128, False), (1000, 1024, 512, True), (868, 4096, 4096, True), (257, 64, 256, False)])
+def test_gemm_fp8_vs_dequantised_product(ops, M, N, K, epi):
+    """fp8 (e4m3) GEMM on the scaled MFMA: quantise bf16 operands with per-tensor scales, multiply, compare with the
+    SAME product computed in fp32 from the de-quantised bytes (exact up to fp32 accumulation order) and, loosely,
+    with the unquantised product (e4m3 has 3 mantissa bits: a few percent)."""
+    a, b = rnd(M, K, seed=70).cuda(), rnd(N, K, seed=71).cuda()
+    sa, sb = 448.0 / float(a.abs().max()), 448.0 / float(b.abs().max())
+    a8 = ops.quantize_fp8(a, sa)
+    b8 = ops.quantize_fp8(b, torch.tensor([sb], dtype=torch.float32, device="cuda"))
+    ad, bd = _e4m3_decode(a8), _e4m3_decode(b8)
+    # quantisation itself: round-to-nearest e4m3 of the scaled value -> relative error <= 2^-4 for normal numbers
+    big = (a.float().abs() * sa) > 2.0 ** -6
+    assert float(((ad - a.float() * sa).abs() / (a.float().abs() * sa + 1e-30))[big].max()) <= 2.0 ** -4 + 1e-6
+    bias = rnd(N, seed=72).cuda() if epi else None
+    res = rnd(M, N, seed=73).cuda() if epi else None
+    alpha = 1.0 / (sa * sb)
+    c = ops.gemm_fp8_nt(a8, b8, alpha, bias=bias, residual=res, out_dtype=torch.float32 if not epi else BF)
+    ref = ((ad.double().cpu() @ bd.double().cpu().t()) * alpha).float()     # exact products, fp64 accumulation
+    if epi:
+        ref = ref + bias.float().cpu() + res.float().cpu()
+    # fp32 output: the matrix pipe's accumulation of 64 exact products per instruction is not bit-identical to a
+    # sequential fp32 sum; 1e-4 relative L2 is ~10x what was measured.  bf16 output: one bf16 rounding.
+    assert rel(c, ref if not epi else ref.to(BF)) <= (1e-4 if not epi else 1e-3)
+    full = a.float() @ b.float().t()
+    if epi:
+        full = full + bias.float() + res.float()
+    assert rel(c, full) <= 6e-2
