@@ -176,6 +176,9 @@ class LlamaStack:
         hs = [x] if all_hidden else None
         for li, lp in enumerate(self.layers):
             xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
+            probe = getattr(self, "_fp8_probe", None)
+            if probe is not None:
+                probe[li]["qkv"] = float(xn.abs().max())
             qkv = ops.gemm_nt(xn, lp.w["qkv"])
             ops.rope_qk_(qkv, self.cos, self.sin, pos, self.H, self.dh)
             if cache is not None:
@@ -186,6 +189,8 @@ class LlamaStack:
             hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
             gu = ops.gemm_nt(hn, lp.w["gu"])
             act = ops.swiglu_fwd(gu)
+            if probe is not None:
+                probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
             xo = ops.gemm_nt(act, lp.w["down"], residual=h)
             if save:
                 self.saved.append(dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn,
@@ -200,6 +205,49 @@ class LlamaStack:
         if all_hidden:
             hs[-1] = hidden
             return hidden, hs
+        return hidden
+
+    # -- fp8 inference forward (BASELINE config 5) -----------------------------------------------
+    FP8_MAX = 448.0
+
+    def fp8_prepare(self, x: torch.Tensor, B: int, S: int, margin: float = 1.25) -> None:
+        """Quantises the four GEMM weights of every layer to e4m3 with per-tensor scales (once) and calibrates static
+        per-tensor ACTIVATION scales from one bf16 forward of `x` (amax * margin): no amax pass at run time."""
+        with torch.no_grad():
+            self._fp8_w = []
+            for lp in self.layers:
+                ent = {}
+                for k in ("qkv", "o", "gu", "down"):
+                    w = lp.w[k]
+                    sw = self.FP8_MAX / max(float(w.abs().max()), 1e-12)
+                    ent[k] = (ops.quantize_fp8(w.contiguous(), sw), sw)
+                self._fp8_w.append(ent)
+            amax = [dict() for _ in self.layers]
+            self._fp8_probe = amax
+            self.forward(x, B, S, save=False)
+            self._fp8_probe = None
+            self._fp8_a = [{k: self.FP8_MAX / max(v * margin, 1e-12) for k, v in d.items()} for d in amax]
+
+    def forward_fp8(self, x: torch.Tensor, B: int, S: int) -> torch.Tensor:
+        """Same function as forward() with the QKV / O / gate|up / down GEMMs on e4m3 operands (scaled MFMA, fp32
+        accumulation, bf16 outputs); norms, RoPE, attention, SwiGLU and the residual stream stay bf16."""
+        assert getattr(self, "_fp8_w", None) is not None, "call fp8_prepare() first"
+        pos = self._positions(B, S)
+        scale = self.dh ** -0.5
+        eps = self.cfg.rms_norm_eps
+        for lp, w8, sa in zip(self.layers, self._fp8_w, self._fp8_a):
+            def mm(inp, key, residual=None):
+                q = ops.quantize_fp8(inp, sa[key])
+                return ops.gemm_fp8_nt(q, w8[key][0], 1.0 / (sa[key] * w8[key][1]), residual=residual)
+            xn, _ = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=False)
+            qkv = mm(xn, "qkv")
+            ops.rope_qk_(qkv, self.cos, self.sin, pos, self.H, self.dh)
+            ao, _ = ops.attn_fwd(qkv, B, S, self.H, self.dh, True, scale, need_lse=False)
+            h = mm(ao, "o", residual=x)
+            hn, _ = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=False)
+            act = ops.swiglu_fwd(mm(hn, "gu"))
+            x = mm(act, "down", residual=h)
+        hidden, _ = ops.rmsnorm_fwd(x, self.norm_w, eps, save_rstd=False)
         return hidden
 
     # -- backward -------------------------------------------------------------------------------

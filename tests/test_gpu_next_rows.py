@@ -87,3 +87,28 @@ def test_evaluation_harness_metrics_and_failed_generations():
     V = np.ones((5, 2), np.float32); V[3] = 0
     a, f, w = R.evaluate_traj_stochastic(P, G, V)
     assert np.allclose([res["ade"], res["fde"], res["wde"]], [a, f, w], rtol=1e-6) and res["n"] == 5
+
+
+def test_fp8_forward_close_to_bf16_forward():
+    """BASELINE config 5 (fp8 MFMA forward): the decoder stack with e4m3 QKV/O/FFN GEMMs (per-tensor static scales,
+    calibrated on the input) against the bf16 forward of the same weights.  e4m3 keeps 3 mantissa bits, so this is a
+    closeness check (stated bound), not bit parity; the fp8 GEMM itself is pinned exactly in test_gpu_ops.py."""
+    import torch
+    from hvlm.config import HandsOnVLMConfig
+    from hvlm.llama import LlamaStack
+    cfg = HandsOnVLMConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4)
+    st = LlamaStack(cfg, device="cuda:0", training=False)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for lp in st.layers:
+        for k in ("qkv", "o", "gu", "down"):
+            lp.w[k].copy_((torch.randn(lp.w[k].shape, device="cuda", generator=g) * 0.03).to(torch.bfloat16))
+        lp.w["ln1"].fill_(1.0); lp.w["ln2"].fill_(1.0)
+    st.norm_w.fill_(1.0)
+    B, S = 2, 256
+    x = (torch.randn(B * S, 512, device="cuda", generator=g)).to(torch.bfloat16)
+    ref = st.forward(x, B, S, save=False).float()
+    st.fp8_prepare(x, B, S)
+    got = st.forward_fp8(x, B, S).float()
+    r = float((got - ref).norm() / ref.norm())
+    print("fp8 vs bf16 forward rel", r)
+    assert float(ref.norm()) > 1.0 and 1e-4 < r < 8e-2 and torch.isfinite(got).all()
