@@ -122,6 +122,26 @@ class GemmEvents:
                       key=lambda r: -r[4])
 
 
+def pmc_traffic(ev, args):
+    """roofline.traffic: L2-miss (fabric / HBM side) bytes per GEMM launch from PMC counters.  A `--pmc` pass cannot wrap
+    the ~3000-dispatch step on this pool, so the counters were collected per distinct GEMM shape in isolation
+    (tools/gemm_traffic.py: FETCH_SIZE and WRITE_SIZE alone in their passes, FETCH_SIZE x2 on gfx950) and are committed in
+    profiles/r01k_gemm_traffic.json; here they are weighted by the launches of THIS run.  null when the run contains a
+    shape that was not measured (other model / batch)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_gemm_traffic.json")
+    if not ev.pairs or not os.path.exists(path):
+        return None, "no PMC table (profiles/r01k_gemm_traffic.json)"
+    table = {(r["M"], r["N"], r["K"]): r["fetch_bytes"] + r["write_bytes"] for r in json.load(open(path))["per_shape"]}
+    tot = 0.0
+    for _, _, _, shp in ev.pairs:
+        if shp not in table:
+            return None, f"GEMM shape {shp} of this run is not in profiles/r01k_gemm_traffic.json"
+        tot += table[shp]
+    return tot / len(ev.pairs), ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, collected per GEMM shape in isolation "
+                                 "(tools/gemm_traffic.py -> profiles/r01k_gemm_traffic.json), weighted by this run's launches; "
+                                 "algorithmic operand+output bytes per launch: 0.70 GB")
+
+
 def cpu_baseline(cfg, T):
     """Times the CPU oracle (port of the reference's eager fp32 path) on a bounded sample and scales it to
     SFT samples/s: one Vicuna decoder layer fwd+bwd at full width on ONE sample (S = T+355), one CLIP layer
@@ -292,13 +312,11 @@ def main():
         }
         if args.layers is not None:
             res["INVALID_debug_layers"] = args.layers
+        traffic, traffic_note = pmc_traffic(ev, args)
         if gs is not None:
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                               "traffic": None,
-                               "traffic_note": "PMC passes cannot wrap the ~3000-dispatch step on this pool (20-min timeout); per-shape "
-                                               "FETCH_SIZE/WRITE_SIZE of the same kernel are in profiles/r01b_gemm_pmc.txt "
-                                               "(13872x12288x4096: 2.34 GB L2-miss reads per launch vs 214 MB unique operands)",
+                               "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}
