@@ -81,6 +81,13 @@ def load(path: os.PathLike | None = None) -> ctypes.CDLL:
         raise HvlmError(
             f"{p} not found: build it with `make -C {_PKG_ROOT}` (or __graft_entry__.build()). "
             "There is no CPU/PyTorch fallback for the HIP path.")
+    # The library must share the HIP runtime PyTorch brings (torch/lib/libamdhip64.so): whichever copy is mapped first
+    # serves both by soname, and with the system copy mapped first a later torch.cuda initialisation left this library
+    # without a device ("no ROCm-capable device is detected" at the first launch).  Import torch before dlopen.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(str(p))
     protos = parse_header()
     for name, (restype, argtypes) in protos.items():
