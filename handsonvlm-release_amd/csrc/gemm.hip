@@ -501,7 +501,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0;
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 9;
@@ -538,6 +538,9 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 6: { const int full = grid; grid = grid < pgrid ? grid : pgrid; (void)full; HVLM_LAUNCH_GEMM(6, 2, 4); break; }
     case 5: HVLM_LAUNCH_GEMM(5, 2, 4); break;
     case 9: {
+      // dynamic tile scheduling needs >= 3 units per workgroup: every workgroup commits to three units when it starts,
+      // so with fewer the first arrivals would take everything (256 tiles on 256 CUs: 1383 -> 917 TFLOP/s)
+      p.dyn = (K / BK >= 3 && pgrid <= 512 && grid >= 3 * pgrid && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
       const int rc = launch_gemm_pp(p, grid < pgrid ? grid : pgrid, as_stream(stream));
       if (rc) return rc;
       break;
@@ -600,7 +603,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -609,6 +612,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   }
   int grid = p.tiles_m * p.tiles_n * splits;
   if (grid > cus) grid = cus;
+  p.dyn = (p.k_split / BK >= 3 && cus <= 512 && p.tiles_m * p.tiles_n * splits >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
   int rc = launch_gemm_pp(p, grid, as_stream(stream));
   if (rc) return rc;
   rc = check_launch("gemm_splitk");
@@ -670,7 +674,7 @@ extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, in
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -679,6 +683,7 @@ extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, in
   }
   int grid = p.tiles_m * p.tiles_n;
   if (grid > cus) grid = cus;
+  p.dyn = (K / 128 >= 3 && cus <= 512 && p.tiles_m * p.tiles_n >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
   const int rc = launch_gemm_pp_fp8(p, grid, as_stream(stream));
   if (rc) return rc;
   return check_launch("gemm_fp8_nt");

@@ -13,6 +13,7 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
   int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
   size_t slab;                  // elements between fp32 slabs
+  int dyn;                      // gemm_pp: dynamic tile scheduling (needs K >= 3 K-tiles, grid <= 512, one stream)
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
 };
 

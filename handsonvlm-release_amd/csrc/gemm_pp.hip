@@ -49,6 +49,17 @@ __device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
 }
 
+// Dynamic tile scheduling state (GemmArgs::dyn): one tile counter per XCD chunk of the swizzled tile order, a completion
+// counter (the last workgroup to finish resets everything for the next launch) and, per workgroup, a 4-deep ring of
+// fetched tile indices through which wave 0 hands its fetches to the other waves one tile ahead of their use.
+// Launches that use it must be serialised on one stream.
+struct PPSched {
+  unsigned ctr[8][32];      // [xcd][0], 128 B apart
+  unsigned done[32];
+  int slots[512][4];
+};
+__device__ PPSched g_pp;
+
 #define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // TN = both operands K-strided: A is [K, M] (element (m,k) at A[k*lda + m]), B is [K, N].  This is dW = dY^T X on the
@@ -84,9 +95,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   // ---- XCD-aware, grouped tile mapping (same order as gemm.hip) -------------------------------
   const int ntile = p.tiles_m * p.tiles_n;
   const int nwg = ntile * p.splits;
-  auto tile_coords = [&](int vb, int& m0_, int& n0_, int& ksl_) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, idx = vb >> 3;
-    int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  // unit index in the swizzled order (workgroup b -> XCD b%8 gets a contiguous chunk) and its coordinates
+  const int ch_q = nwg >> 3, ch_r = nwg & 7;
+  auto chunk_start = [&](int x) { return x < ch_r ? x * (ch_q + 1) : ch_r * (ch_q + 1) + (x - ch_r) * ch_q; };
+  auto swz_of = [&](int vb) { return chunk_start(vb & 7) + (vb >> 3); };
+  auto tile_coords = [&](int swz, int& m0_, int& n0_, int& ksl_) {
     ksl_ = swz / ntile;
     swz -= ksl_ * ntile;
     const int gsz = p.group_m * p.tiles_n;
@@ -97,6 +110,21 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     m0_ = (first_m + in % gm) * BM;
     n0_ = (in / gm) * BN;
   };
+  // ---- dynamic scheduling (p.dyn): the next unit comes from the XCD's counter, then from the other XCDs' (stealing),
+  // so a workgroup that starts late — CUs held by another stream, e.g. an RCCL all-reduce — simply takes fewer tiles.
+  // With the static assignment (b, b+grid, ...) 8 busy CUs out of 256 cost this kernel 17-42 % (tools/contention_bench.py).
+  const bool dyn = p.dyn != 0;
+  const int my_xcd = (int)blockIdx.x & 7;
+  auto fetch_unit = [&]() -> int {          // one lane
+    for (int a = 0; a < 8; ++a) {
+      const int x = (my_xcd + a) & 7;
+      const int cnt = ch_q + (x < ch_r ? 1 : 0);
+      const unsigned i = __hip_atomic_fetch_add(&g_pp.ctr[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)i < cnt) return chunk_start(x) + (int)i;
+    }
+    return -1;
+  };
+  int t_cur, t_nxt;                        // swizzled unit index of the tile being computed / the one after (-1: none)
   constexpr int BKE = BK * 2 / ES;          // K-tile in elements: 64 bf16 or 128 fp8 (128 bytes either way)
   const int nk = TN ? (p.K + BK - 1) / BK : (p.splits > 1 ? p.k_split : p.K) / BKE;
 
@@ -131,11 +159,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   struct Cursor {
     __amdgpu_buffer_rsrc_t ra, rb;
     unsigned koff;
-    int vb, kt;
+    int vb, kt;        // vb: static mode: launch-order index of its tile; dynamic mode: 0 / 1 = on t_cur / t_nxt
+    int t;             // swizzled unit index of its tile
   };
   auto make_desc = [&](Cursor& c) {
     int m0_, n0_, ksl_;
-    tile_coords(c.vb, m0_, n0_, ksl_);
+    tile_coords(c.t, m0_, n0_, ksl_);
     if constexpr (!TN) {
       const size_t kbase = (size_t)ksl_ * p.k_split;
       const size_t krem = (size_t)p.K - kbase;
@@ -159,10 +188,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   auto advance = [&](Cursor& c) {
     if (++c.kt == nk) {
       c.kt = 0;
-      const int nv = c.vb + (int)gridDim.x;
-      if (nv < nwg) c.vb = nv;
-      // else: past the last tile of this workgroup — keep loading this tile's K-tiles again (valid memory,
-      // slots nobody reads) so the counted vmcnt stays exact.
+      if (dyn) {
+        if (c.vb == 0 && t_nxt >= 0) { c.vb = 1; c.t = t_nxt; }      // (nk >= 3: a cursor is never two tiles ahead)
+      } else {
+        const int nv = c.vb + (int)gridDim.x;
+        if (nv < nwg) { c.vb = nv; c.t = swz_of(nv); }
+      }
+      // past the last tile of this workgroup: keep loading this tile's K-tiles again (valid memory, slots nobody
+      // reads) so the counted vmcnt stays exact.
       make_desc(c);
     } else if constexpr (TN) {
       make_desc(c);                          // re-base on the next 64 k-rows
@@ -446,8 +479,32 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   };
 
   // ---- prologue: K-tile 0 (4 half-tiles) and A0,B0 of K-tile 1 in flight -------------------------
+  unsigned it = 0;                        // tiles done by this workgroup
+  if (dyn) {
+    // wave 0 draws the first three units; the first two are needed by everyone right away (through LDS, free now)
+    int* lq = reinterpret_cast<int*>(smem);
+    if (w == 0 && l == 0) {
+      const int u0 = fetch_unit(), u1 = fetch_unit(), u2 = fetch_unit();
+      lq[0] = u0; lq[1] = u1;
+      g_pp.slots[blockIdx.x][2] = u2;
+    }
+    __syncthreads();
+    t_cur = __builtin_amdgcn_readfirstlane(lq[0]);
+    t_nxt = __builtin_amdgcn_readfirstlane(lq[1]);
+    __syncthreads();
+    if (t_cur < 0) {                      // more workgroups than units (cannot happen with grid <= units; kept for safety)
+      if (w == 0 && l == 0 && __hip_atomic_fetch_add(&g_pp.done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        for (int x = 0; x < 8; ++x) g_pp.ctr[x][0] = 0;
+        g_pp.done[0] = 0;
+      }
+      return;
+    }
+  } else {
+    t_cur = swz_of((int)blockIdx.x);
+    t_nxt = -1;
+  }
   Cursor c1, c2;
-  c1.vb = blockIdx.x; c1.kt = 0; c1.koff = 0;
+  c1.vb = dyn ? 0 : (int)blockIdx.x; c1.t = t_cur; c1.kt = 0; c1.koff = 0;
   make_desc(c1);
   stage_a(0, 0, c1); stage_b(0, 0, c1); stage_b(0, 1, c1); stage_a(0, 1, c1);
   advance(c1);                            // c1 = K-tile 1 (its B1, A1 are staged in phases 0, 1 below)
@@ -457,7 +514,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   HVLM_VMCNT(8);                          // A0, B0 of K-tile 0 landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();
 
-  int vb = blockIdx.x;
+  int vb = blockIdx.x;                    // static mode: launch-order index of the tile being computed
   unsigned g = 0;                         // running K-tile counter; K-tile g lives in LDS stage g & 1
 
   // W0..W3 (TN only): lgkmcnt that retires the transpose reads feeding k-step 0..3 of this phase (reads are issued
@@ -554,7 +611,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
     }
     int m0, n0, ksl;
-    tile_coords(vb, m0, n0, ksl);
+    tile_coords(t_cur, m0, n0, ksl);
+    // dynamic mode: wave 0 draws the unit three tiles ahead and parks it in this workgroup's ring (an untracked store, see
+    // store16_untracked); every wave picks up the unit two tiles ahead, parked one tile ago (L1-bypassing load)
+    int t_aft_v = -1, u_fetched = 0;
+    if (dyn) {
+      if (w == 0 && l == 0) u_fetched = fetch_unit();          // result is only needed after the epilogue
+      t_aft_v = __hip_atomic_load(&g_pp.slots[blockIdx.x][(it + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (FP8) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -563,12 +627,33 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][i][r] *= p.alpha;
     }
-    // vmcnt(0) as a real S_WAITCNT (not inline asm): the compiler's wait-count tracking then knows that no LDS-DMA
-    // is pending when the epilogue touches LDS; without it every ds_read at the top of the K loop gets a compiler
-    // vmcnt(0).  Placed BEFORE the epilogue so that only the prefetched K-tiles are waited for, not the stores.
     epilogue(m0, n0, (size_t)ksl * p.slab);
-    vb += (int)gridDim.x;
-    if (vb >= nwg) break;
+    int t_aft = -1;
+    if (dyn) {
+      if (w == 0 && l == 0) {
+        int* sp = &g_pp.slots[blockIdx.x][(it + 3) & 3];
+        asm volatile("global_store_dword %0, %1, off" ::"v"(sp), "v"(u_fetched) : "memory");
+      }
+      t_aft = __builtin_amdgcn_readfirstlane(t_aft_v);
+    }
+    ++it;
+    if (dyn) {
+      if (t_nxt < 0) break;
+      t_cur = t_nxt; t_nxt = t_aft;
+      if (c1.vb == 1) c1.vb = 0;          // the cursors that already crossed into the new current tile
+      if (c2.vb == 1) c2.vb = 0;
+    } else {
+      vb += (int)gridDim.x;
+      if (vb >= nwg) break;
+      t_cur = swz_of(vb);
+    }
+  }
+  if (dyn && w == 0 && l == 0) {
+    // everyone's fetches precede their increment of `done`: the last one resets the counters for the next launch
+    if (__hip_atomic_fetch_add(&g_pp.done[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      for (int x = 0; x < 8; ++x) __hip_atomic_store(&g_pp.ctr[x][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&g_pp.done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   HVLM_VMCNT(0);
 #undef HVLM_MFMA_QUAD

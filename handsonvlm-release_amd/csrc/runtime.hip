@@ -45,3 +45,29 @@ extern "C" int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char*
   }
   return HVLM_OK;
 }
+
+// ---- diagnostic: occupy `workgroups` CUs for ~`cycles` clock cycles (64 KiB of LDS each, so that a workgroup
+// of the persistent GEMM cannot share the CU).  Stands in for an RCCL collective running beside the compute stream when
+// measuring how the GEMM behaves with fewer CUs than it was launched for (tools/contention_bench.py).
+namespace hvlm {
+namespace {
+__global__ __launch_bounds__(256) void occupy_kernel(long cycles, unsigned* sink) {
+  __shared__ unsigned pad[16384];
+  pad[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const long t0 = __builtin_readcyclecounter();
+  unsigned acc = pad[(threadIdx.x * 7) & 16383];
+  while ((long)__builtin_readcyclecounter() - t0 < cycles) {
+    __builtin_amdgcn_s_sleep(32);
+    acc += pad[acc & 16383];
+  }
+  if (acc == 0xdeadbeefu && sink) *sink = acc;
+}
+}  // namespace
+}  // namespace hvlm
+
+extern "C" int hvlm_debug_occupy(int workgroups, long cycles, void* stream) {
+  HVLM_REQUIRE(workgroups > 0 && cycles > 0, "debug_occupy: bad args");
+  hipLaunchKernelGGL(hvlm::occupy_kernel, dim3(workgroups), dim3(256), 0, hvlm::as_stream(stream), cycles, (unsigned*)nullptr);
+  return hvlm::check_launch("debug_occupy");
+}

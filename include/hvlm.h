@@ -42,6 +42,9 @@ int hvlm_abi_version(void);
 const char* hvlm_last_error(void);
 /* Fills CU count, LDS bytes per workgroup and the gcnArchName of `device`. */
 int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
+/* Diagnostic: keeps `workgroups` CUs busy (64 KiB LDS each) for about `cycles` shader clocks on `stream` — a stand-in
+ * for a collective running beside the compute stream (tools/contention_bench.py). */
+int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * GEMM (MFMA, bf16 in, fp32 accumulate)
