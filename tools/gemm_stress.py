@@ -14,6 +14,8 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 bad = 0
 for case in range(n_cases):
     M = int(torch.randint(1, 3000, (1,), generator=g)) if case % 3 else int(torch.randint(256, 9000, (1,), generator=g))
+    if case % 7 == 0:
+        M = int(torch.randint(9000, 30000, (1,), generator=g))      # >= 3 tiles per workgroup: dynamic tile scheduling
     N = int(torch.randint(1, 700, (1,), generator=g)) * 8
     K = int(torch.randint(1, 40, (1,), generator=g)) * 64
     use_bias, use_res, use_act = [bool(torch.randint(0, 2, (1,), generator=g)) for _ in range(3)]
