@@ -106,7 +106,18 @@ class GemmEvents:
     def summary(self):
         if not self.pairs:
             return None
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in self.pairs)
+        # kernel-busy time = length of the UNION of the launch intervals (GEMMs issued on two streams may overlap; summing
+        # their durations would count the shared time twice); with one stream the union is the plain sum
+        ref = self.pairs[0][0]
+        iv = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b, _, _ in self.pairs)
+        ms, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+        for s0, e0 in iv[1:]:
+            if s0 > cur_e:
+                ms += cur_e - cur_s
+                cur_s, cur_e = s0, e0
+            else:
+                cur_e = max(cur_e, e0)
+        ms += cur_e - cur_s
         fl = sum(f for _, _, f, _ in self.pairs)
         return dict(launches=len(self.pairs), total_ms=ms, total_flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
                     avg_us=ms * 1e3 / len(self.pairs))

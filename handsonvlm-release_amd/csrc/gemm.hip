@@ -540,7 +540,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
     case 9: {
       // dynamic tile scheduling needs >= 3 units per workgroup: every workgroup commits to three units when it starts,
       // so with fewer the first arrivals would take everything (256 tiles on 256 CUs: 1383 -> 917 TFLOP/s)
-      p.dyn = (K / BK >= 3 && pgrid <= 512 && grid >= 3 * pgrid && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
+      p.dyn = (K / BK >= 3 && pgrid <= 512 && grid >= 3 * pgrid && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
       const int rc = launch_gemm_pp(p, grid < pgrid ? grid : pgrid, as_stream(stream));
       if (rc) return rc;
       break;
@@ -612,7 +612,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   }
   int grid = p.tiles_m * p.tiles_n * splits;
   if (grid > cus) grid = cus;
-  p.dyn = (p.k_split / BK >= 3 && cus <= 512 && p.tiles_m * p.tiles_n * splits >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
+  p.dyn = (p.k_split / BK >= 3 && cus <= 512 && p.tiles_m * p.tiles_n * splits >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
   int rc = launch_gemm_pp(p, grid, as_stream(stream));
   if (rc) return rc;
   rc = check_launch("gemm_splitk");
@@ -683,7 +683,7 @@ extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, in
   }
   int grid = p.tiles_m * p.tiles_n;
   if (grid > cus) grid = cus;
-  p.dyn = (K / 128 >= 3 && cus <= 512 && p.tiles_m * p.tiles_n >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 : 0;
+  p.dyn = (K / 128 >= 3 && cus <= 512 && p.tiles_m * p.tiles_n >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
   const int rc = launch_gemm_pp_fp8(p, grid, as_stream(stream));
   if (rc) return rc;
   return check_launch("gemm_fp8_nt");

@@ -13,12 +13,15 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, ldr, act, out_f32, tiles_m, tiles_n, group_m;
   int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
   size_t slab;                  // elements between fp32 slabs
-  int dyn;                      // gemm_pp: dynamic tile scheduling (needs K >= 3 K-tiles, grid <= 512, one stream)
+  int dyn;                      // gemm_pp: 0 = static tile assignment, s+1 = dynamic scheduling on state slot s (pp_sched_slot)
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
 };
 
 // gemm_pp.hip: 8-phase ping-pong kernel (persistent 256x256 tiles); grid = workgroups to launch.
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream);
+// Dynamic-scheduling state slot of `stream` (launches on one stream are serialised, so they can share a slot; kernels
+// on different streams may overlap and must not): the first 8 distinct streams get their own slot, -1 after that.
+int pp_sched_slot(hipStream_t stream);
 // same kernel, both operands K-strided (A is [K, M], B is [K, N]; lda / ldb = row strides of those): dW = dY^T X
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream);
 // same kernel on OCP e4m3 operands (A, B point at bytes; lda / ldb in bytes = elements), C = alpha * A B^T (+ epilogue)

@@ -58,7 +58,8 @@ struct PPSched {
   unsigned done[32];
   int slots[512][4];
 };
-__device__ PPSched g_pp;
+constexpr int PP_NSCHED = 8;             // one state per stream that launches this kernel (gemm_args.h: pp_sched_slot)
+__device__ PPSched g_pp_all[PP_NSCHED];
 
 #define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   // so a workgroup that starts late — CUs held by another stream, e.g. an RCCL all-reduce — simply takes fewer tiles.
   // With the static assignment (b, b+grid, ...) 8 busy CUs out of 256 cost this kernel 17-42 % (tools/contention_bench.py).
   const bool dyn = p.dyn != 0;
+  PPSched& g_pp = g_pp_all[dyn ? p.dyn - 1 : 0];
   const int my_xcd = (int)blockIdx.x & 7;
   auto fetch_unit = [&]() -> int {          // one lane
     for (int a = 0; a < 8; ++a) {
@@ -685,6 +687,16 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+int pp_sched_slot(hipStream_t stream) {
+  static hipStream_t known[PP_NSCHED];
+  static int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (known[i] == stream) return i;
+  if (n == PP_NSCHED) return -1;
+  known[n] = stream;
+  return n++;
+}
 
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<0>(p, grid, stream); }
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<1>(p, grid, stream); }
