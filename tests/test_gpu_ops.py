@@ -7,6 +7,8 @@ Tolerances (bf16 kernels, fp32 oracle evaluated on the SAME bf16-rounded inputs)
   * rel-L2 <= 4e-3 against the fp32 oracle for ops with internal bf16 roundings the oracle does not make
     (attention P in bf16, fused backward kernels);  bit-exact for integer / index / copy work.
 Run with `pytest -m gpu` on the MI355X box."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -397,3 +399,33 @@ def test_gemm_fp8_vs_dequantised_product(ops, M, N, K, epi):
     if epi:
         full = full + bias.float() + res.float()
     assert rel(c, full) <= 6e-2
+
+
+def test_gemm_dynamic_scheduling_under_contention(ops):
+    """A GEMM with >= 3 tiles per workgroup takes its tiles from the per-XCD atomic counters; with some CUs held by
+    another stream (the situation of an RCCL all-reduce beside the backward pass) late workgroups take fewer tiles and
+    others steal — the result must not depend on who computed which tile: bit-identical to the quiet run and to the
+    static assignment."""
+    import ctypes
+    from hvlm import _lib
+    M, N, K = 16384, 3328, 512            # 64 x 13 = 832 tiles >= 3 x 256
+    a, b = rnd(M, K, seed=80).cuda(), rnd(N, K, seed=81).cuda()
+    bias = rnd(N, seed=82).cuda()
+    quiet = ops.gemm_nt(a, b, bias=bias)
+    side = torch.cuda.Stream()
+    lib = _lib.load()
+    for occ in (8, 40, 120):
+        torch.cuda.synchronize()
+        _lib.check(lib.hvlm_debug_occupy(occ, 4_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
+        torch.cuda._sleep(100_000)
+        busy = ops.gemm_nt(a, b, bias=bias)
+        torch.cuda.synchronize()
+        assert torch.equal(busy, quiet), occ
+    os.environ["HVLM_GEMM_STATIC"] = "1"
+    try:
+        static = ops.gemm_nt(a, b, bias=bias)
+    finally:
+        del os.environ["HVLM_GEMM_STATIC"]
+    assert torch.equal(static, quiet)
+    ref = a.float() @ b.float().t() + bias.float()
+    assert rel(quiet, ref.to(BF)) <= 1e-3
