@@ -30,6 +30,8 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 // LDS-DMA of 16 bytes per lane through a BUFFER load (base = wave-uniform pointer, per-lane 32-bit byte offset).
 // Not `global_load_lds`: that one is a FLAT-class instruction with an LDS memory operand, and while one is pending
@@ -252,8 +254,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 //   The streaming kernel pads S = 257 to 3 x 128 queries x 5 x 64 keys (1.86x the useful MFMA work); here the padding is
 //   9 x 32 by 9 x 32 (1.26x).  Same online-softmax body, 64 keys per step.
 // =================================================================================================
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 template <int DH>
 __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t* __restrict__ qkv,
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // backward, dQ  (one query per lane)
 // =================================================================================================
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt_g /*K^T [B,H,DH,S_pad]*/,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dqkv, int S, int H, int ld, int S_pad, float scale) {
@@ -542,17 +542,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
   const int nkt = CAUSAL ? min(nkt_all, min(q0 + 127, S - 1) / 64 + 1) : nkt_all;
   const bf16_t* kbase = qkv + tok0 * ld + (long)H * DH + h * DH;
   const bf16_t* vbase = qkv + tok0 * ld + 2L * H * DH + h * DH;
-  const bf16_t* ktbase = kt_g + ((long)b * H + h) * DH * (long)S_pad;
 
   // two LDS stages: the tiles of step kt+1 are in flight while step kt is computed (the single-stage version exposed
-  // the full fill latency on every step, with one workgroup of 4 waves per CU to hide it)
-  constexpr unsigned STAGE = 3 * KT;
+  // the full fill latency on every step).  A stage holds K and V only: the K^T fragments of dQ^T = K^T dS^T are gathered
+  // from the row-major K tile with `ds_read_b64_tr_b16` (a 16-lane group reads a 4(key) x 16(d) block, lane q receives
+  // d = q) — no K^T tile, no K^T pre-pass, 64 KiB of LDS = two workgroups per CU.  Those reads are inline asm: the
+  // builtin is modelled as a may-store LDS access and gets a compiler `vmcnt(0)` while the prefetch is pending.
+  constexpr unsigned STAGE = 2 * KT;
   auto stage = [&](int buf, int kt) {
     const unsigned o = (unsigned)buf * STAGE;
     load_tile<64, DH>(smem, o, kbase, ld, kt * 64, S, w, l);
     load_tile<64, DH>(smem, o + KT, vbase, ld, kt * 64, S, w, l);
-    load_tile<DH, 64>(smem, o + 2 * KT, ktbase + kt * 64, S_pad, 0, DH, w, l);
   };
+  const int p16 = l & 15, g16 = l31 >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  unsigned kt_off[DH / 32][2];          // lane offsets of the two 4-key groups (keys +0..3 / +8..11 of its half) per d block
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      kt_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int kv0 = kt * 64;
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
     __syncthreads();   // tile kt landed for everyone; everyone is done with tile kt-1
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     if (CAUSAL && kv0 > q0 + w * 32 + 31) continue;
-    const unsigned sK = (unsigned)(kt & 1) * STAGE, sV = sK + KT, sKT = sK + 2 * KT;
+    const unsigned sK = (unsigned)(kt & 1) * STAGE, sV = sK + KT;
 
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -605,13 +614,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
         const bf16x8 dsf = pack8(pv);
-        const int c1 = kb * 4 + 2 * sp;
+        // keys kv-local (kb*32 + 16*sp) + {4hi + 0..3, 8 + 4hi + 0..3}: the k-slot order of the dS registers
+        const unsigned kbytes = sK + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
+        s16x4_t lo[DH / 32], hi4[DH / 32];
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db)
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+                       : "=&v"(lo[db]), "=&v"(hi4[db]) : "v"(kt_off[db][0] + kbytes), "v"(kt_off[db][1] + kbytes) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int db = 0; db < DH / 32; ++db) {
-          const int r = db * 32 + l31;
-          const bf16x8 ktf = lds_frag64x2(smem, sKT + tile_addr<64>(r, c1) + 8u * hi,
-                                          sKT + tile_addr<64>(r, c1 + 1) + 8u * hi);
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq[db], 0, 0, 0);
+          s16x8_t kv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
+          asm volatile("" : "+v"(kv));       // the MFMA below must stay behind the lgkmcnt wait
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kv), dsf, dq[db], 0, 0, 0);
         }
       }
   }
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(
 // backward, dK / dV  (one key per lane)
 // =================================================================================================
 template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
+__global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt_g /*Q^T*/,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ dot_g /*dO^T*/,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
@@ -670,32 +685,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
   const int qt_begin = CAUSAL ? (k0 / 64) : 0;
   const bf16_t* qbase = qkv + tok0 * ld + h * DH;
   const bf16_t* dobase = dout + tok0 * (long)(H * DH) + h * DH;
-  const bf16_t* qtbase = qt_g + ((long)b * H + h) * DH * (long)S_pad;
-  const bf16_t* dotbase = dot_g + ((long)b * H + h) * DH * (long)S_pad;
   const float* lse_row = lse + ((long)b * H + h) * S;
   const float* dlt_row = delta + ((long)b * H + h) * S;
 
-  // two LDS stages (see the dQ kernel): tiles + the 64 lse / delta values of step qt+1 are fetched during step qt
-  constexpr unsigned STAGE = 4 * KT + 512;
+  // two LDS stages (see the dQ kernel): tiles + the 64 lse / delta values of step qt+1 are fetched during step qt.  A stage
+  // holds Q and dO only; the Q^T / dO^T fragments of dK^T = Q^T dS and dV^T = dO^T P come from those tiles through
+  // `ds_read_b64_tr_b16` (inline asm, see the dQ kernel): no Q^T / dO^T tiles, no pre-passes, two workgroups per CU.
+  constexpr unsigned STAGE = 2 * KT + 512;
   float lse_n = 0.f, dlt_n = 0.f;               // wave 0: next step's lse*log2e / delta of query qq0 + tid
   auto stage = [&](int buf, int qt) {
     const unsigned o = (unsigned)buf * STAGE;
     const int qq0 = qt * 64;
     load_tile<64, DH>(smem, o, qbase, ld, qq0, S, w, l);
     load_tile<64, DH>(smem, o + KT, dobase, (long)H * DH, qq0, S, w, l);
-    load_tile<DH, 64>(smem, o + 2 * KT, qtbase + qq0, S_pad, 0, DH, w, l);
-    load_tile<DH, 64>(smem, o + 3 * KT, dotbase + qq0, S_pad, 0, DH, w, l);
     if (tid < 64) {
       const int q = min(qq0 + tid, S - 1);
       lse_n = lse_row[q] * LOG2E;
       dlt_n = dlt_row[q];
     }
   };
+  const int p16 = l & 15, g16 = l31 >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  unsigned tr_off[DH / 32][2];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      tr_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
   if (qt_begin < nqt) stage(0, qt_begin);
   for (int qt = qt_begin; qt < nqt; ++qt) {
     const int qq0 = qt * 64;
-    const unsigned sQ = (unsigned)((qt - qt_begin) & 1) * STAGE, sDO = sQ + KT, sQT = sQ + 2 * KT, sDOT = sQ + 3 * KT;
-    float* s_lse = reinterpret_cast<float*>(smem + sQ + 4 * KT);   // [64] lse*log2e
+    const unsigned sQ = (unsigned)((qt - qt_begin) & 1) * STAGE, sDO = sQ + KT;
+    float* s_lse = reinterpret_cast<float*>(smem + sQ + 2 * KT);   // [64] lse*log2e
     float* s_dlt = s_lse + 64;                                     // [64]
     if (tid < 64) { s_lse[tid] = lse_n; s_dlt[tid] = dlt_n; }       // this stage's slot: nobody reads it before the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -736,15 +757,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(
         }
         const bf16x8 pf = pack8(pvals);
         const bf16x8 dsf = pack8(dsvals);
-        const int c1 = qb * 4 + 2 * sp;
+        // queries (qb*32 + 16*sp) + {4hi + 0..3, 8 + 4hi + 0..3}: the k-slot order of the P / dS registers
+        const unsigned qbytes = (unsigned)(qb * 32 + 16 * sp) * (DH * 2);
 #pragma unroll
         for (int db = 0; db < DH / 32; ++db) {
-          const int r = db * 32 + l31;
-          const unsigned a0 = tile_addr<64>(r, c1) + 8u * hi, a1 = tile_addr<64>(r, c1 + 1) + 8u * hi;
-          const bf16x8 dotf = lds_frag64x2(smem, sDOT + a0, sDOT + a1);
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv[db], 0, 0, 0);
-          const bf16x8 qtf = lds_frag64x2(smem, sQT + a0, sQT + a1);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk[db], 0, 0, 0);
+          s16x4_t d0, d1, q0r, q1r;
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(d0), "=&v"(d1), "=&v"(q0r), "=&v"(q1r)
+                       : "v"(tr_off[db][0] + sDO + qbytes), "v"(tr_off[db][1] + sDO + qbytes), "v"(tr_off[db][0] + sQ + qbytes),
+                         "v"(tr_off[db][1] + sQ + qbytes)
+                       : "memory");
+          const s16x8_t dotv = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+          const s16x8_t qtv = {q0r[0], q0r[1], q0r[2], q0r[3], q1r[0], q1r[1], q1r[2], q1r[3]};
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dotv), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qtv), dsf, dk[db], 0, 0, 0);
         }
       }
     }
@@ -834,10 +860,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   bf16_t* kT = reinterpret_cast<bf16_t*>(ws + tsz);
   bf16_t* doT = reinterpret_cast<bf16_t*>(ws + 2 * tsz);
   float* delta = reinterpret_cast<float*>(ws + 3 * tsz);
-  int rc;
-  if ((rc = launch_head_transpose<DH>(qkv, qT, B, S, H, ld, 0, st))) return rc;
-  if ((rc = launch_head_transpose<DH>(qkv, kT, B, S, H, ld, H * DH, st))) return rc;
-  if ((rc = launch_head_transpose<DH>(dout, doT, B, S, H, H * DH, 0, st))) return rc;
+  int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
   {
     const long total = (long)B * S * H * (DH / 8);
     hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out,
@@ -845,7 +868,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = check_launch("attn_delta"))) return rc;
   }
   {
-    constexpr int LDS = 2 * 3 * 64 * DH * 2;            // two stages of (K, V, K^T)
+    constexpr int LDS = 2 * 2 * 64 * DH * 2;            // two stages of (K, V)
     if ((rc = set_lds(attn_bwd_dq_kernel<DH, CAUSAL>, LDS, "attn_bwd_dq"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)kT,
@@ -853,7 +876,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = check_launch("attn_bwd_dq"))) return rc;
   }
   {
-    constexpr int LDS = 2 * (4 * 64 * DH * 2 + 512);    // two stages of (Q, dO, Q^T, dO^T, lse, delta)
+    constexpr int LDS = 2 * (2 * 64 * DH * 2 + 512);    // two stages of (Q, dO, lse, delta)
     if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
