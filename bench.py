@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--text-len", type=int, default=512, help="prompt tokens T; S = T + 355")
     ap.add_argument("--unique-frames", type=int, default=10, help="EK100 tiles 10 frames x10 -> 100")
     ap.add_argument("--dedup", action="store_true", help="encode unique frames once (reported separately)")
+    ap.add_argument("--image-size", type=int, default=224,
+                    help="frame size: 224 = the only geometry the reference accepts (default); 336 = the build's generalisation "
+                         "(24x24 patches, 676 visual tokens, S = T + 675)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
@@ -64,6 +67,7 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
+    cfg.vision.image_size = args.image_size
     return cfg
 
 
@@ -292,7 +296,7 @@ def main():
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
     if rank == 0:
-        S = T + 355
+        S = T + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
         n_frames = B * cfg.num_frames if not args.dedup else B * args.unique_frames
         flops_llm = 3.0 * model.stack.flops_forward(B, S, cfg.vocab_size)
         flops_clip = n_frames * model.tower.flops_per_frame()
@@ -310,7 +314,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"sft_step_{args.model}_b{B}_T{T}_S{S}_{cfg.num_frames}x224px"
+            "config": {"workload": f"sft_step_{args.model}_b{B}_T{T}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
                                    + ("_dedupclip" if args.dedup else "_refequiv"),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "frames_through_clip_per_sample": n_frames // B,

@@ -59,15 +59,17 @@ __device__ __forceinline__ int sel_frame(int k, int T) {
   return (int)rintf((float)k * (float)(T - 1) / 3.0f);
 }
 
-// One work item = 8 channels of one output row.  grid-strided.
-//   out row r < T     : mean over the 256 patches of frame r
-//   out row r >= T    : j = r-T; frame sel(j/64); (oy,ox) = ((j%64)/8, j%8); mean of the 2x2 patches
+// One work item = 8 channels of one output row.  grid-strided.  G = patches per side (16 at the reference's 224 px,
+// 24 at 336 px), G2 = G*G, H = G/2, P2 = H*H pooled cells per selected frame.
+//   out row r < T     : mean over the G2 patches of frame r
+//   out row r >= T    : j = r-T; frame sel(j/P2); (oy,ox) = ((j%P2)/H, j%H); mean of the 2x2 patches
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ tok,
-                                                       bf16_t* __restrict__ out, int B, int T, int D,
-                                                       int tpf /*tokens per frame incl. cls*/,
+                                                       bf16_t* __restrict__ out, int B, int T, int D, int G,
                                                        int skip /*1 if cls is dropped*/) {
   const int dv = D / 8;
-  const int rows = T + 256;
+  const int G2 = G * G, H = G / 2, P2 = H * H;
+  const int tpf = G2 + skip;
+  const int rows = T + 4 * P2;
   const long total = (long)B * rows * dv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % dv) * 8;
@@ -80,22 +82,23 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
     float scale;
     if (r < T) {
       const bf16_t* base = tok + ((b * T + r) * (long)tpf + skip) * D + c;
-      for (int p = 0; p < 256; ++p) {
+      for (int p = 0; p < G2; ++p) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
       }
-      scale = 1.f / 256.f;
+      scale = 1.f / (float)G2;
     } else {
       const int j = r - T;
-      const int f = sel_frame(j >> 6, T);
-      const int oy = (j & 63) >> 3, ox = j & 7;
+      const int f = sel_frame(j / P2, T);
+      const int jj = j % P2;
+      const int oy = jj / H, ox = jj % H;
       const bf16_t* base = tok + ((b * T + f) * (long)tpf + skip) * D + c;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-          const int p = (2 * oy + dy) * 16 + 2 * ox + dx;
+          const int p = (2 * oy + dy) * G + 2 * ox + dx;
           const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
@@ -109,30 +112,31 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
-// dtokens[b,t,p,:] = dout[b,t,:]/256 + sum_{k: sel(k)==t} dout[b, T + k*64 + (py/2)*8 + px/2, :]/4
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const bf16_t* __restrict__ dout,
-                                                       bf16_t* __restrict__ dtok, int B, int T, int D) {
+                                                       bf16_t* __restrict__ dtok, int B, int T, int D, int G) {
   const int dv = D / 8;
-  const int rows = T + 256;
-  const long total = (long)B * T * 256 * dv;
+  const int G2 = G * G, H = G / 2, P2 = H * H;
+  const int rows = T + 4 * P2;
+  const float inv = 1.f / (float)G2;
+  const long total = (long)B * T * G2 * dv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % dv) * 8;
     const long rr = i / dv;
-    const int p = (int)(rr & 255);
-    const long bt = rr >> 8;
+    const int p = (int)(rr % G2);
+    const long bt = rr / G2;
     const int t = (int)(bt % T);
     const long b = bt / T;
     float acc[8];
     {
       const u32x4 v = *reinterpret_cast<const u32x4*>(dout + (b * rows + t) * (long)D + c);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] = bf_lo(v[e]) * (1.f / 256.f); acc[2 * e + 1] = bf_hi(v[e]) * (1.f / 256.f); }
+      for (int e = 0; e < 4; ++e) { acc[2 * e] = bf_lo(v[e]) * inv; acc[2 * e + 1] = bf_hi(v[e]) * inv; }
     }
-    const int py = p >> 4, px = p & 15;
+    const int py = p / G, px = p % G;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (sel_frame(k, T) == t) {
-        const int j = k * 64 + (py >> 1) * 8 + (px >> 1);
+        const int j = k * P2 + (py >> 1) * H + (px >> 1);
         const u32x4 v = *reinterpret_cast<const u32x4*>(dout + (b * rows + T + j) * (long)D + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]) * 0.25f; acc[2 * e + 1] += bf_hi(v[e]) * 0.25f; }
@@ -280,20 +284,22 @@ extern "C" int hvlm_clip_embed(const void* patch_out, const void* cls, const voi
 }
 
 extern "C" int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,
-                                              int drop_cls, void* stream) {
+                                              int drop_cls, int grid, void* stream) {
   HVLM_REQUIRE(tokens && out && B > 0 && T >= 1 && D % 8 == 0, "pool_fwd: bad args");
-  const long total = (long)B * (T + 256) * (D / 8);
+  HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_fwd: grid=%d must be even (16 = reference geometry)", grid);
+  const long total = (long)B * (T + grid * grid) * (D / 8);
   hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, drop_cls ? 257 : 256, drop_cls ? 1 : 0);
+                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0);
   return check_launch("temporal_spatial_pool_fwd");
 }
 
 extern "C" int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D,
-                                              void* stream) {
+                                              int grid, void* stream) {
   HVLM_REQUIRE(dout && dtokens && B > 0 && T >= 1 && D % 8 == 0, "pool_bwd: bad args");
-  const long total = (long)B * T * 256 * (D / 8);
+  HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_bwd: grid=%d must be even", grid);
+  const long total = (long)B * T * grid * grid * (D / 8);
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)dout, (bf16_t*)dtokens, B, T, D);
+                     (const bf16_t*)dout, (bf16_t*)dtokens, B, T, D, grid);
   return check_launch("temporal_spatial_pool_bwd");
 }
 

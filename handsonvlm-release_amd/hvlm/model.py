@@ -214,16 +214,17 @@ class HandsOnVLMForCausalLM:
         if inv is not None:
             tok = tok[inv]
         tok = tok.contiguous()
-        NV = T + 256
+        G = cfg.vision.image_size // cfg.vision.patch_size       # patches per side: 16 at the reference's 224 px
+        NV = T + G * G
         if cfg.project_after_pool:
-            pooled = ops.temporal_spatial_pool_fwd(tok, B, T, drop_cls=True).view(B * NV, d)
+            pooled = ops.temporal_spatial_pool_fwd(tok, B, T, drop_cls=True, grid=G).view(B * NV, d)
             vis = ops.gemm_nt(pooled, self.proj_w, bias=self.proj_b)
             if keep_for_backward:
                 self._vis_saved = dict(pooled=pooled)
         else:
-            feats = tok[:, 1:].contiguous().view(B * T * 256, d)
+            feats = tok[:, 1:].contiguous().view(B * T * G * G, d)
             ptok = ops.gemm_nt(feats, self.proj_w, bias=self.proj_b)
-            vis = ops.temporal_spatial_pool_fwd(ptok, B, T, drop_cls=False).view(B * NV, self.token_dim)
+            vis = ops.temporal_spatial_pool_fwd(ptok, B, T, drop_cls=False, grid=G).view(B * NV, self.token_dim)
             if keep_for_backward:
                 self._vis_saved = dict(feats=feats)
         return vis.view(B, NV, self.token_dim)
@@ -420,7 +421,8 @@ class HandsOnVLMForCausalLM:
             self.stack._dw(dvis, sv["pooled"], self.proj_w_g, _round_up(B * NV, 64))
             ops.cast_f32_to_bf16(ops.colsum(dvis), out=self.proj_b_g)
         else:
-            dtok = ops.temporal_spatial_pool_bwd(dvis.view(B, NV, -1), B, c["T"]).view(-1, self.token_dim)
+            G = cfg.vision.image_size // cfg.vision.patch_size
+            dtok = ops.temporal_spatial_pool_bwd(dvis.view(B, NV, -1), B, c["T"], grid=G).view(-1, self.token_dim)
             self.stack._dw(dtok, sv["feats"], self.proj_w_g, _round_up(dtok.shape[0], 64))
             ops.cast_f32_to_bf16(ops.colsum(dtok), out=self.proj_b_g)
         self._vis_saved = None

@@ -320,20 +320,21 @@ def clip_embed(patch_out, cls, pos, N: int, NP: int, D: int) -> torch.Tensor:
     return tokens
 
 
-def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool) -> torch.Tensor:
+def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool, grid: int = 16) -> torch.Tensor:
+    """grid = patches per side (16: the reference's 224-px geometry; 24: 336 px)."""
     _chk(tokens, BF16, "pool.tokens")
     assert tokens.is_contiguous()
     D = tokens.shape[-1]
-    out = torch.empty((B, T + 256, D), dtype=BF16, device=tokens.device)
-    check(_lib.load().hvlm_temporal_spatial_pool_fwd(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, _stream()),
+    out = torch.empty((B, T + grid * grid, D), dtype=BF16, device=tokens.device)
+    check(_lib.load().hvlm_temporal_spatial_pool_fwd(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _stream()),
           "pool_fwd")
     return out
 
 
-def temporal_spatial_pool_bwd(dout: torch.Tensor, B: int, T: int) -> torch.Tensor:
+def temporal_spatial_pool_bwd(dout: torch.Tensor, B: int, T: int, grid: int = 16) -> torch.Tensor:
     D = dout.shape[-1]
-    dtok = torch.empty((B, T, 256, D), dtype=BF16, device=dout.device)
-    check(_lib.load().hvlm_temporal_spatial_pool_bwd(_p(dout), _p(dtok), B, T, D, _stream()), "pool_bwd")
+    dtok = torch.empty((B, T, grid * grid, D), dtype=BF16, device=dout.device)
+    check(_lib.load().hvlm_temporal_spatial_pool_bwd(_p(dout), _p(dtok), B, T, D, grid, _stream()), "pool_bwd")
     return dtok
 
 

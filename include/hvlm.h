@@ -187,15 +187,16 @@ int hvlm_patch_im2col(const void* images, void* patches, int N, int HW, int P, i
 int hvlm_clip_embed(const void* patch_out, const void* cls, const void* pos, void* tokens, int N,
                     int NP, int D, void* stream);
 /* VisualToTokenHelper.compress_tokens('temporal_spatial_pool')
- * (hoi_forecast/model/visual_to_tokens.py:252-272): tokens [B,T,256,D] -> out [B,T+256,D];
- * rows [0,T): mean over the 256 patches of each frame; rows [T,T+256): frames
- * round(linspace(0,T-1,4)) on their 16x16 grid, 2x2 average-pooled to 8x8.
- * drop_cls != 0: the input has NP+1 tokens per frame and token 0 (CLS) is skipped
+ * (hoi_forecast/model/visual_to_tokens.py:252-272): tokens [B,T,G*G,D] -> out [B,T+G*G,D];
+ * rows [0,T): mean over the G*G patches of each frame; rows [T,T+G*G): frames
+ * round(linspace(0,T-1,4)) on their GxG grid, 2x2 average-pooled to (G/2)x(G/2).
+ * grid = G = 16 is the reference geometry (224 px: it asserts 256 patches); 24 = the 336-px generalisation.
+ * drop_cls != 0: the input has G*G+1 tokens per frame and token 0 (CLS) is skipped
  * (feature_select 'patch', clip_encoder.py:29-37). */
 int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,
-                                   int drop_cls, void* stream);
-/* backward of the above: dtokens [B,T,256,D] (fully written) from dout [B,T+256,D]. */
-int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D, void* stream);
+                                   int drop_cls, int grid, void* stream);
+/* backward of the above: dtokens [B,T,G*G,D] (fully written) from dout [B,T+G*G,D]. */
+int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D, int grid, void* stream);
 
 /* Multimodal splice (handsonvlm.py:212-451): builds inputs_embeds [B,S,D] where
  *   src[b*S+s] >= 0  : row = embed_tokens[src]            (text token id)

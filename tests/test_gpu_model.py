@@ -150,6 +150,43 @@ def test_dedup_frames_identical():
     assert torch.equal(a, b)
 
 
+
+
+def test_336px_generalisation_vs_oracle():
+    """24x24 patches per frame (336 px): CLIP on 577 tokens, 100 + 4*12*12 = 676 visual tokens.  The reference cannot
+    run this geometry (it asserts 224 px / 256 patches), so the checker is the oracle's restatement of the same
+    arithmetic on a 24x24 grid; the HIP path must agree with it like at 224 px."""
+    from hvlm.config import CLIPVisionConfig, HandsOnVLMConfig
+    from hvlm.model import HandsOnVLMForCausalLM
+    c = dict(synth.TINY, image=336)
+    cfg = HandsOnVLMConfig(hidden_size=c["D"], intermediate_size=c["FFN"], num_hidden_layers=c["L"],
+                           num_attention_heads=c["H"], mm_hidden_size=c["clip_d"],
+                           vision=CLIPVisionConfig(hidden_size=c["clip_d"], intermediate_size=c["clip_mlp"],
+                                                   num_hidden_layers=c["clip_layers"], num_attention_heads=c["clip_heads"],
+                                                   image_size=336))
+    m = HandsOnVLMForCausalLM(cfg, device="cuda:0", training=True)
+    p = synth.to_torch(synth.llama_params(c))
+    cp = synth.to_torch(synth.clip_params(c))
+    sd = dict(p)
+    sd.update({"model.vision_tower.vision_tower." + k: v for k, v in cp.items()})
+    m.load_state_dict(sd)
+    ids, labels, mask = synth.make_text_batch(1, 24, seed=3, n_hand=(4,))
+    images = synth.make_images(1, c["frames"], 2, 336, seed=11)
+    fh, fv = synth.make_hands(1, seed=5)
+    eps = torch.randn(8, 256, generator=torch.Generator().manual_seed(0))
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh.clone(),
+            contact_point=torch.zeros(1, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(1), cvae_eps=eps.cuda())
+    assert out.logits.shape[1] == 24 + 676 - 1
+    out.loss.backward()
+    vis = R.visual_tokens(images, cp, c["clip_layers"], c["clip_heads"], p["model.mm_projector.weight"],
+                          p["model.mm_projector.bias"])
+    assert vis.shape[1] == 676
+    ref = R.forward_loss(p, dict(n_layers=c["L"], n_heads=c["H"], cond_dtype=torch.bfloat16), ids, labels, mask, vis, fh, fv, eps)
+    got, want = float(out.loss.detach()), float(ref["loss"])
+    REPORT["336px_loss"] = dict(hip=got, oracle=want)
+    assert abs(got - want) / abs(want) < 1e-2, (got, want)
+
+
 def test_zz_write_report():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/gpu_model_report.json", "w") as f:

@@ -161,6 +161,15 @@ def test_pool_vs_reference_golden_and_oracle(ops, golden):
     dout = rnd(2, 356, 64, seed=22)
     R.temporal_spatial_pool(tf).backward(dout.float())
     assert rel(ops.temporal_spatial_pool_bwd(dout.cuda(), 2, 100), tf.grad.to(BF)) <= 1e-3
+    # 336-px generalisation: 24x24 patches -> 100 + 4*12*12 = 676 visual tokens (no reference geometry: oracle only)
+    tok24 = rnd(1, 100, 577, 64, seed=22)
+    out24 = ops.temporal_spatial_pool_fwd(tok24.cuda(), 1, 100, drop_cls=True, grid=24)
+    assert out24.shape == (1, 676, 64)
+    assert rel(out24, R.temporal_spatial_pool(tok24[:, :, 1:].float()).to(BF)) <= 1e-3
+    d24 = rnd(1, 676, 64, seed=23)
+    t24 = tok24[:, :, 1:].float().clone().requires_grad_(True)
+    R.temporal_spatial_pool(t24).backward(d24.float())
+    assert rel(ops.temporal_spatial_pool_bwd(d24.cuda(), 1, 100, grid=24), t24.grad.to(BF)) <= 1e-3
 
 
 def test_splice_and_hand_posenc_vs_oracle(ops):
