@@ -142,13 +142,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   const int nkt_all = (S + 63) / 64;
   const int nkt = CAUSAL ? min(nkt_all, min(q0 + QB - 1, S - 1) / 64 + 1) : nkt_all;
   const bf16_t* kbase = qkv + tok0 * ld + (long)H * DH + h * DH;
-  const bf16_t* vtbase = vt + ((long)b * H + h) * DH * (long)S_pad;
+  const bf16_t* vbase = kbase + (long)H * DH;
 
+  // a stage = the K and V tiles of 64 keys, both row-major; the V^T fragments of O^T = V^T P^T are gathered from the V
+  // tile with `ds_read_b64_tr_b16` (inline asm, see the backward kernels) — no V^T pre-pass, no workspace
   auto stage = [&](int buf, int kt) {
     const unsigned base = (unsigned)buf * STAGE;
     load_tile<64, DH, NW>(smem, base, kbase, ld, kt * 64, S, w, l);
-    load_tile<DH, 64, NW>(smem, base + KT, vtbase + kt * 64, S_pad, 0, DH, w, l);
+    load_tile<64, DH, NW>(smem, base + KT, vbase, ld, kt * 64, S, w, l);
   };
+  const int p16 = l & 15, g16 = l31 >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  unsigned v_off[DH / 32][2];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      v_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
 
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -215,13 +225,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
           for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
           const bf16x8 pf = pack8(pv);
-          const int c1 = kb * 4 + 2 * sp;
+          const unsigned kbytes = sV + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
+          s16x4_t lo[DH / 32], hi4[DH / 32];
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db)
+            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+                         : "=&v"(lo[db]), "=&v"(hi4[db]) : "v"(v_off[db][0] + kbytes), "v"(v_off[db][1] + kbytes) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
           for (int db = 0; db < DH / 32; ++db) {
-            const int r = db * 32 + l31;
-            const bf16x8 vf = lds_frag64x2(smem, sV + tile_addr<64>(r, c1) + 8u * hi,
-                                           sV + tile_addr<64>(r, c1 + 1) + 8u * hi);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            s16x8_t vv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
+            asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[db], 0, 0, 0);
           }
         }
     };
@@ -831,9 +846,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
       return check_launch("attn_fwd_resident");
     }
   }
-  rc = launch_head_transpose<DH>(qkv, ws, B, S, H, ld, 2 * H * DH, st);
-  if (rc) return rc;
-  constexpr int LDS = 2 * 2 * 64 * DH * 2;
+  constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // rows per workgroup: 128 (4 waves) or 96 (3 waves) — whichever wastes fewer query rows (S=257 -> 96)
   const int waste4 = (S + 127) / 128 * 128 - S, waste3 = (S + 95) / 96 * 96 - S;
   if (false && waste3 < waste4) {   // 96-row workgroups measured slower in situ (649 vs 593 us per CLIP layer): kept for A/B only
@@ -855,11 +868,8 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
 template <int DH, bool CAUSAL>
 static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse,
                     bf16_t* dqkv, char* ws, int B, int S, int H, int ld, float scale, hipStream_t st) {
-  const size_t tsz = (size_t)B * H * DH * spad(S) * 2;
-  bf16_t* qT = reinterpret_cast<bf16_t*>(ws);
-  bf16_t* kT = reinterpret_cast<bf16_t*>(ws + tsz);
-  bf16_t* doT = reinterpret_cast<bf16_t*>(ws + 2 * tsz);
-  float* delta = reinterpret_cast<float*>(ws + 3 * tsz);
+  bf16_t* qT = nullptr; bf16_t* kT = nullptr; bf16_t* doT = nullptr;     // (unused kernel arguments, kept for signature stability)
+  float* delta = reinterpret_cast<float*>(ws);
   int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
   {
     const long total = (long)B * S * H * (DH / 8);
@@ -891,11 +901,15 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
 
 using namespace hvlm;
 
+// The kernels gather every transposed operand with LDS transpose reads: the forward needs no workspace any more (a
+// token amount is returned so callers keep passing a valid pointer), the backward only delta[B,H,S] fp32.
 extern "C" size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh) {
-  return (size_t)B * H * dh * spad(S) * 2;
+  (void)B; (void)S; (void)H; (void)dh;
+  return 256;
 }
 extern "C" size_t hvlm_attn_bwd_ws_bytes(int B, int S, int H, int dh) {
-  return 3 * (size_t)B * H * dh * spad(S) * 2 + (size_t)B * H * S * 4 + 256;
+  (void)dh;
+  return (size_t)B * H * S * 4 + 256;
 }
 
 extern "C" int hvlm_attn_fwd(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh,

@@ -136,9 +136,9 @@ int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int3
  *   qkv: bf16 [B*S, ld]  q at col 0, k at col H*dh, v at col 2*H*dh (per head dh contiguous)
  *   out: bf16 [B*S, H*dh]; lse: f32 [B, H, S] (log-sum-exp of scaled scores; NULL to skip)
  *   dh in {64, 128}.
- *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): holds
- *       the k-contiguous transposed operand copies (V^T forward; Q^T, K^T, dO^T and the
- *       delta = rowsum(dO*O) vector backward) produced by an HBM-bound pre-pass.
+ *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): the backward keeps
+ *       delta = rowsum(dO*O) there; the forward needs none (the transposed operands V^T, K^T, Q^T, dO^T are
+ *       gathered inside the kernels with LDS transpose reads — the parameter stays for ABI stability).
  * bwd: dqkv (same layout as qkv, fully written for rows < S) from dout [B*S, H*dh].
  * ------------------------------------------------------------------------------------------ */
 size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh);
