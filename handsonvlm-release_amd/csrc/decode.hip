@@ -9,15 +9,52 @@
 namespace hvlm {
 namespace {
 
-// y[n] = sum_k W[n,k] x[k] (+ res[n]);  one wave per ROWS consecutive rows, x staged in LDS.
-template <int ROWS>
+// y[n] = sum_k W[n,k] x'[k] (+ res[n]);  one wave per ROWS consecutive rows, x' staged in LDS.
+// PRE selects what x' is (computed by every workgroup while it stages the 8-22 KB vector: cheaper than a kernel launch):
+//   0: x' = x;   1: x' = RMSNorm(x) * nw  (same arithmetic as rmsnorm_fwd_kernel: bf16(x*rstd) then * w, bf16);
+//   2: x' = SwiGLU(x) with x = [gate(K) | up(K)]  (same arithmetic as swiglu_fwd_kernel).
+template <int ROWS, int PRE>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                    bf16_t* __restrict__ y, const bf16_t* __restrict__ res, int N,
-                                                   int K, int ldw) {
+                                                   int K, int ldw, const bf16_t* __restrict__ nw, float eps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-  for (int i = threadIdx.x * 8; i < K; i += 256 * 8)
-    *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(x + i);
+  if constexpr (PRE == 0) {
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8)
+      *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(x + i);
+  } else if constexpr (PRE == 1) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float a = bf_lo(v[e]), b = bf_hi(v[e]); ss += a * a + b * b; }
+    }
+    ss = block_sum<4>(ss, red);
+    const float rstd = rsqrtf(ss / (float)K + eps);
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + i);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf2(bf2f(f2bf(bf_lo(v[e]) * rstd)) * bf_lo(wv[e]), bf2f(f2bf(bf_hi(v[e]) * rstd)) * bf_hi(wv[e]));
+      *reinterpret_cast<u32x4*>(xs + i) = o;
+    }
+  } else {
+    for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+      const u32x4 g = *reinterpret_cast<const u32x4*>(x + i);
+      const u32x4 u = *reinterpret_cast<const u32x4*>(x + K + i);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
+        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
+        o[e] = pack_bf2(s0 * bf_lo(u[e]), s1 * bf_hi(u[e]));
+      }
+      *reinterpret_cast<u32x4*>(xs + i) = o;
+    }
+  }
   __syncthreads();
   const int l = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -130,21 +167,116 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   }
 }
 
+// Flash-decoding split of the kernel above for the native decode step: grid (H, NS); workgroup (h, j) handles keys
+// [j*S/NS, (j+1)*S/NS) and writes {local max, local sum, unnormalised o[DH]} (DH + 2 floats); the combine kernel
+// (one workgroup per head) merges the NS partials.  One workgroup per head used 32 of 256 CUs: 32 us per layer at S = 870.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                                  const bf16_t* __restrict__ vc, float* __restrict__ part_out,
+                                                                  int S, int ld, float scale, int NS) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);          // [DH]
+  float* red = qs + DH;                                  // [8]
+  constexpr int CP = DH / 2;
+  constexpr int G = 256 / CP;
+  float* part = red + 8;                                 // [G][DH]
+  float* sc = part + G * DH;                             // [keys of this split]
+  const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
+  const int s_begin = (int)((long)S * j / NS), s_end = (int)((long)S * (j + 1) / NS);
+  const int n = s_end - s_begin;
+  if (t < DH) qs[t] = bf2f(q[h * DH + t]) * scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int i = t; i < n; i += 256) {
+    const bf16_t* kp = kc + (size_t)(s_begin + i) * ld + h * DH;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) {
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += bf_lo(kv[e]) * qs[c + 2 * e] + bf_hi(kv[e]) * qs[c + 2 * e + 1];
+    }
+    sc[i] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = block_max<4>(mx, red);
+  float sum = 0.f;
+  for (int i = t; i < n; i += 256) {
+    const float p = __expf(sc[i] - mx);
+    sc[i] = p;
+    sum += p;
+  }
+  sum = block_sum<4>(sum, red + 4);
+  __syncthreads();
+  const int cp = t % CP, g = t / CP;
+  float a0 = 0.f, a1 = 0.f;
+  const bf16_t* vbase = vc + (size_t)s_begin * ld + h * DH + 2 * cp;
+#pragma unroll 8
+  for (int i = g; i < n; i += G) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(vbase + (size_t)i * ld);
+    const float p = sc[i];
+    a0 += p * bf_lo(v);
+    a1 += p * bf_hi(v);
+  }
+  part[g * DH + 2 * cp] = a0;
+  part[g * DH + 2 * cp + 1] = a1;
+  __syncthreads();
+  float* po = part_out + ((size_t)h * NS + j) * (DH + 2);
+  if (t < DH) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc += part[i * DH + t];
+    po[2 + t] = acc;
+  }
+  if (t == 0) { po[0] = n > 0 ? mx : -INFINITY; po[1] = n > 0 ? sum : 0.f; }
+}
+
+template <int DH>
+__global__ __launch_bounds__(DH) void attn_decode_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int NS) {
+  const int h = blockIdx.x, t = threadIdx.x;
+  const float* p = part + (size_t)h * NS * (DH + 2);
+  float m = -INFINITY;
+  for (int j = 0; j < NS; ++j) m = fmaxf(m, p[j * (DH + 2)]);
+  float l = 0.f, o = 0.f;
+  for (int j = 0; j < NS; ++j) {
+    const float mj = p[j * (DH + 2)];
+    const float wj = (mj == -INFINITY) ? 0.f : __expf(mj - m);
+    l += p[j * (DH + 2) + 1] * wj;
+    o += p[j * (DH + 2) + 2 + t] * wj;
+  }
+  out[h * DH + t] = f2bf(o / l);
+}
+
 }  // namespace
 }  // namespace hvlm
 
 using namespace hvlm;
+
+// GEMV with a fused prologue on x (pre: 0 none, 1 RMSNorm with weights `nw`, 2 SwiGLU of x = [gate | up]); internal to the
+// native decode step (hvlm_gemv_bf16 is pre = 0).
+static int gemv_pre(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw, int pre,
+                    const void* nw, float eps, void* stream) {
+  constexpr int ROWS = 2;
+  const int waves = cdiv(N, ROWS);
+  dim3 grid(cdiv(waves, 4)), block(256);
+  if (pre == 1)
+    hipLaunchKernelGGL((gemv_kernel<ROWS, 1>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps);
+  else if (pre == 2)
+    hipLaunchKernelGGL((gemv_kernel<ROWS, 2>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f);
+  else
+    hipLaunchKernelGGL((gemv_kernel<ROWS, 0>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f);
+  return check_launch("gemv");
+}
 
 extern "C" int hvlm_gemv_bf16(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw,
                               void* stream) {
   HVLM_REQUIRE(W && x && y, "gemv: null pointer");
   HVLM_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw >= K && ldw % 8 == 0, "gemv: bad shape (K %% 8, ldw %% 8)");
   HVLM_REQUIRE(K * 2 <= 64 * 1024, "gemv: K too large for the LDS copy of x");
-  constexpr int ROWS = 2;
-  const int waves = cdiv(N, ROWS);
-  hipLaunchKernelGGL((gemv_kernel<ROWS>), dim3(cdiv(waves, 4)), dim3(256), K * 2, as_stream(stream), (const bf16_t*)W,
-                     (const bf16_t*)x, (bf16_t*)y, (const bf16_t*)residual, N, K, ldw);
-  return check_launch("gemv_bf16");
+  return gemv_pre(W, x, y, residual, N, K, ldw, 0, nullptr, 0.f, stream);
 }
 
 extern "C" int hvlm_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, int S, int H, int dh,
@@ -174,33 +306,48 @@ extern "C" int hvlm_llama_decode_step(const void* const* w_qkv, const void* cons
                "decode_step: null pointer");
   HVLM_REQUIRE(cache_ld >= 3 * D && D == H * dh, "decode_step: bad shape");
   bf16_t* w = reinterpret_cast<bf16_t*>(ws);
-  bf16_t* xn = w;            // [D]
-  bf16_t* ao = xn + D;       // [D]
+  bf16_t* ao = w;            // [D]
   bf16_t* h = ao + D;        // [D]
-  bf16_t* hn = h + D;        // [D]
-  bf16_t* xa = hn + D;       // [D]
+  bf16_t* xa = h + D;        // [D]
   bf16_t* xb = xa + D;       // [D]
   bf16_t* gu = xb + D;       // [2F]
-  bf16_t* act = gu + 2 * (size_t)F;  // [F]
+  float* apart = reinterpret_cast<float*>(gu + 2 * (size_t)F + 64);   // [H][NS][dh + 2] attention partials
+  HVLM_REQUIRE(dh == 64 || dh == 128, "decode_step: dh must be 64 or 128");
+  HVLM_REQUIRE(((size_t)F * 2) <= 64 * 1024 && (size_t)D * 2 <= 64 * 1024, "decode_step: D / F too large for the LDS copy of x");
   const float scale = 1.0f / sqrtf((float)dh);
   const bf16_t* x = reinterpret_cast<const bf16_t*>(x_in);
+  const int S = pos + 1;
+  const int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);      // key splits: H * NS workgroups
+  const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1) * 4;
+  HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
   int rc;
+  // 7 launches per layer: the two RMSNorms and the SwiGLU ride in the prologue of the GEMV that consumes them, attention is
+  // split over the keys (flash-decoding) + a combine pass
   for (int l = 0; l < L; ++l) {
     bf16_t* kv = reinterpret_cast<bf16_t*>(kv_cache[l]);
     bf16_t* row = kv + (size_t)pos * cache_ld;
-    if ((rc = hvlm_rmsnorm_fwd(x, ln1[l], xn, nullptr, 1, D, eps, stream))) return rc;
-    if ((rc = hvlm_gemv_bf16(w_qkv[l], xn, row, nullptr, 3 * D, D, D, stream))) return rc;
+    if ((rc = gemv_pre(w_qkv[l], x, row, nullptr, 3 * D, D, D, 1, ln1[l], eps, stream))) return rc;
     if ((rc = hvlm_rope_qk(row, cos_tab, sin_tab, pos_dev, 1, H, dh, cache_ld, 0, stream))) return rc;
-    if ((rc = hvlm_attn_decode(row, kv + D, kv + 2 * D, ao, pos + 1, H, dh, cache_ld, scale, stream))) return rc;
-    if ((rc = hvlm_gemv_bf16(w_o[l], ao, h, x, D, D, D, stream))) return rc;
-    if ((rc = hvlm_rmsnorm_fwd(h, ln2[l], hn, nullptr, 1, D, eps, stream))) return rc;
-    if ((rc = hvlm_gemv_bf16(w_gu[l], hn, gu, nullptr, 2 * F, D, D, stream))) return rc;
-    if ((rc = hvlm_swiglu_fwd(gu, act, 1, F, stream))) return rc;
+    if (dh == 128) {
+      hipLaunchKernelGGL((attn_decode_partial_kernel<128>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS);
+      hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
+    } else {
+      hipLaunchKernelGGL((attn_decode_partial_kernel<64>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS);
+      hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
+    }
+    if ((rc = check_launch("attn_decode_split"))) return rc;
+    if ((rc = gemv_pre(w_o[l], ao, h, x, D, D, D, 0, nullptr, 0.f, stream))) return rc;
+    if ((rc = gemv_pre(w_gu[l], h, gu, nullptr, 2 * F, D, D, 1, ln2[l], eps, stream))) return rc;
     bf16_t* xo = (l & 1) ? xb : xa;
-    if ((rc = hvlm_gemv_bf16(w_down[l], act, xo, h, D, F, F, stream))) return rc;
+    if ((rc = gemv_pre(w_down[l], gu, xo, h, D, F, F, 2, nullptr, 0.f, stream))) return rc;
     x = xo;
   }
   return hvlm_rmsnorm_fwd(x, norm_w, hidden_out, nullptr, 1, D, eps, stream);
 }
 
-extern "C" size_t hvlm_llama_decode_ws_bytes(int D, int F) { return (size_t)(6 * D + 3 * (size_t)F) * 2 + 256; }
+extern "C" size_t hvlm_llama_decode_ws_bytes(int D, int F) {
+  // activations (4 D + 2 F bf16) + attention partials (up to 128 heads x 8 splits x 130 floats)
+  return (size_t)(4 * D + 2 * (size_t)F + 64) * 2 + (size_t)128 * 8 * 130 * 4 + 256;
+}

@@ -136,7 +136,13 @@ class LlamaStack:
     def new_cache(self, max_len: Optional[int] = None) -> List[torch.Tensor]:
         """Per-layer [max_len, 3D] buffers in the fused qkv layout (k at column D, v at 2D)."""
         n = max_len or self.cfg.max_position_embeddings
-        return [torch.empty((n, 3 * self.D), dtype=BF16, device=self.device) for _ in range(self.L)]
+        # kept across samples (evaluation generates one sample after the other: 1.6 GB for 7B at n = 1100; allocating it
+        # per sample cost 7.8 ms of an 80 ms sample) — and the decode-step pointer tables keyed on it stay valid
+        kept = getattr(self, "_kv_cache", None)
+        if kept is None or kept[0].shape[0] < n:
+            kept = [torch.empty((n, 3 * self.D), dtype=BF16, device=self.device) for _ in range(self.L)]
+            self._kv_cache = kept
+        return kept
 
     def decode_step(self, x1: torch.Tensor, pos: int, cache: List[torch.Tensor]) -> torch.Tensor:
         """One new token (x1 [1, D]) at position `pos` against the KV cache -> final-normed hidden [1, D].
