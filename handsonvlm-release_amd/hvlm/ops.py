@@ -8,6 +8,7 @@ missing, `_lib.load()` raises (there is no fallback).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,10 @@ NORM_BWD_BLOCKS = 1024
 IGNORE_INDEX = -100
 BF16 = torch.bfloat16
 
+
+_GEMM_CUS = 256                      # persistent GEMM grid (MI355X: 256 CUs); only used to decide the tail split below
+_GEMM_TAIL = os.environ.get("HVLM_GEMM_TAIL", "1") == "1"
+_GEMM_TAIL_MIN_K = int(os.environ.get("HVLM_GEMM_TAIL_MIN_K", "8192"))
 
 # Optional instrumentation (bench.py): called as hook(M, N, K) -> context manager around each GEMM launch.
 _gemm_hook = None
@@ -95,9 +100,37 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
             if hook is not None:
                 hook(M, N, K, False)
             return out
-    check(_lib.load().hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
-                                        out.stride(0), _p(bias), _p(residual), ldr, act,
-                                        1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")
+    # Tail of the last partial round of 256x256 tiles (e.g. 880 tiles on 256 CUs = 3.44 rounds): when it fills at most half of
+    # the chip and K is long enough to pay for two extra launches, the bottom row panels that make up that partial round run
+    # as a split-K GEMM (its K-slices fill the idle CUs: 3 + 1/s tile-times instead of 4), the rest as exactly R full rounds.
+    lib = _lib.load()
+    tn = (N + 255) // 256
+    if tiles > _GEMM_CUS and K >= _GEMM_TAIL_MIN_K and out.dtype == BF16 and N % 4 == 0 and _GEMM_TAIL:
+        T = tiles % _GEMM_CUS
+        if 0 < T <= _GEMM_CUS // 2 and T % tn == 0:
+            rows_tail_tiles = T // tn
+            m_body = ((M + 255) // 256 - rows_tail_tiles) * 256
+            splits = 0
+            for cand in (4, 3, 2):
+                if T * cand <= _GEMM_CUS and K % (64 * cand) == 0:
+                    splits = cand
+                    break
+            if splits and 0 < m_body < M:
+                mt = M - m_body
+                res_b = None if residual is None else residual[:m_body]
+                res_t = None if residual is None else residual[m_body:]
+                check(lib.hvlm_gemm_bf16_nt(_p(a[:m_body]), _p(b), _p(out[:m_body]), m_body, N, K, a.stride(0), b.stride(0),
+                                            out.stride(0), _p(bias), _p(res_b), ldr, act, 0, _stream()), "gemm_bf16_nt")
+                ws = torch.empty((lib.hvlm_gemm_splitk_ws_bytes(mt, N, splits),), dtype=torch.uint8, device=a.device)
+                check(lib.hvlm_gemm_bf16_nt_splitk(_p(a[m_body:]), _p(b), _p(out[m_body:]), mt, N, K, a.stride(0), b.stride(0),
+                                                   out.stride(0), _p(bias), _p(res_t), ldr, act, _p(ws), splits, _stream()),
+                      "gemm_splitk(tail)")
+                if hook is not None:
+                    hook(M, N, K, False)
+                return out
+    check(lib.hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
+                                out.stride(0), _p(bias), _p(residual), ldr, act,
+                                1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")
     if hook is not None:
         hook(M, N, K, False)
     return out

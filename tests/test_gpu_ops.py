@@ -438,3 +438,26 @@ def test_gemm_dynamic_scheduling_under_contention(ops):
     assert torch.equal(static, quiet)
     ref = a.float() @ b.float().t() + bias.float()
     assert rel(quiet, ref.to(BF)) <= 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(13872, 4096, 8192), (8752, 4096, 8192), (4400, 12288, 8192)])
+def test_gemm_tail_rows_as_splitk(ops, M, N, K):
+    """When the last round of 256x256 tiles would fill at most half the chip and K >= 8192, gemm_nt runs the bottom row
+    panels (exactly that partial round) as a split-K GEMM and the rest as full rounds.  Same bound as the one-launch
+    path, bit-identical run to run, and within a bf16 ulp of the one-launch result (fp32 summation order only)."""
+    g = torch.Generator(device="cuda").manual_seed(90)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(BF); b = (torch.randn(N, K, device="cuda", generator=g) * 0.5).to(BF)
+    bias = torch.randn(N, device="cuda", generator=g).to(BF); res = torch.randn(M, N, device="cuda", generator=g).to(BF)
+    ref = a.float() @ b.float().t() + bias.float() + res.float()
+    old = ops._GEMM_TAIL
+    try:
+        ops._GEMM_TAIL = True
+        c1 = ops.gemm_nt(a, b, bias=bias, residual=res)
+        c2 = ops.gemm_nt(a, b, bias=bias, residual=res)
+        ops._GEMM_TAIL = False
+        c0 = ops.gemm_nt(a, b, bias=bias, residual=res)
+    finally:
+        ops._GEMM_TAIL = old
+    assert torch.equal(c1, c2)
+    assert rel(c1, ref.to(BF)) <= 1e-3 and rel(c0, ref.to(BF)) <= 1e-3
+    assert rel(c1, c0) <= 1e-4
