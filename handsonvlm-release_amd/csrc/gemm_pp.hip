@@ -18,7 +18,11 @@
 //     values, the tile base lives in the (scalar) descriptor, rows past M / N fall outside num_records;
 //   * persistent workgroups walk tiles in the XCD-aware grouped order of gemm.hip; the staging cursor runs across
 //     tile boundaries, so the epilogue of tile i overlaps the loads of tile i+1.  The two groups re-align at the
-//     epilogue (group 1 skips its last barrier, re-staggers after it) so both epilogues run concurrently.
+//     epilogue (group 1 skips its last barrier, re-staggers after it) so both epilogues run concurrently;
+//   * epilogue through a wave-private LDS transpose (16-B row-contiguous stores / residual loads), see `epilogue`;
+//   * tiles are assigned dynamically (per-XCD atomic counters + stealing) when there are >= 3 per workgroup, see PPSched;
+//   * the same body is instantiated for K-strided operands (TN: dW = dY^T X) and for fp8 e4m3 operands on the scaled
+//     MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), see gemm_pp_body.
 #include "common.h"
 #include "gemm_args.h"
 #include <type_traits>
