@@ -34,8 +34,9 @@ def test_header_symbols_all_exported(lib):
     assert lib.load().hvlm_abi_version() == 1
     # workspace queries are pure host functions
     l = lib.load()
-    assert l.hvlm_attn_fwd_ws_bytes(2, 100, 4, 128) == 2 * 4 * 128 * 128 * 2
-    assert l.hvlm_attn_bwd_ws_bytes(1, 64, 1, 64) >= 3 * 64 * 64 * 2 + 64 * 4
+    # (no head-transpose staging any more: forward needs a token workspace, backward the per-row delta in fp32)
+    assert 0 < l.hvlm_attn_fwd_ws_bytes(2, 100, 4, 128) <= 4096
+    assert l.hvlm_attn_bwd_ws_bytes(1, 64, 1, 64) >= 64 * 4
 
 
 def test_argument_validation_returns_error_not_crash(lib):
