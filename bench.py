@@ -11,7 +11,7 @@ HBM when the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  "roofline":     dominant kernel (gemm_pp_kernel, MFMA-bound): algorithmic FLOPs of all its launches
+  "roofline":     dominant kernel (gemm_pp4_kernel, MFMA-bound): algorithmic FLOPs of all its launches
                   in the timed region / their summed duration (HIP events on the launch stream), vs the
                   dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
   "cpu_baseline": the CPU oracle (oracle/ref_cpu.py, a port of the reference's eager fp32 path) timed on
@@ -329,7 +329,7 @@ def main():
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)
         if gs is not None:
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp_kernel", "achieved": gs["tflops"],
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4_kernel", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                                "launches": gs["launches"], "avg_launch_us": gs["avg_us"],

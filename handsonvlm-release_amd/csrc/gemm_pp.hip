@@ -84,8 +84,9 @@ __device__ PPSched g_pp_all[PP_NSCHED];
 // LDS image, the DMA pieces, the swizzle and the whole 8-phase schedule are unchanged; a fragment is two ds_read_b128
 // (32 k-bytes per lane), 4 MFMAs of 64 cycles per phase instead of 8 of 32.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-template <bool TN, bool FP8>
+template <bool TN, bool FP8, bool SEG4 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
+  static_assert(!(TN && SEG4), "the 4-segment schedule is for K-contiguous operands");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
   constexpr int ES = FP8 ? 1 : 2;          // operand element size in bytes
   constexpr int NKS = FP8 ? 2 : 4;         // MFMA k-steps per K-tile
@@ -515,6 +516,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   stage_a(0, 0, c1); stage_b(0, 0, c1); stage_b(0, 1, c1); stage_a(0, 1, c1);
   advance(c1);                            // c1 = K-tile 1 (its B1, A1 are staged in phases 0, 1 below)
   stage_a(1, 0, c1); stage_b(1, 0, c1);
+  if constexpr (SEG4) stage_b(1, 1, c1);  // the 4-segment schedule stages A0, B0, B1 two K-tiles ahead, A1 one ahead
   c2 = c1;
   advance(c2);                            // c2 = K-tile 2
   HVLM_VMCNT(8);                          // A0, B0 of K-tile 0 landed (this wave's pieces)
@@ -551,6 +553,35 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     asm volatile("" : "+v"(acc[J][I0]), "+v"(acc[J][I0 + 1]));                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
   } while (0)
+#define HVLM_MFMA_OCT_STEP(I0, AF0, AF1, KS)                                                              \
+  do {                                                                                                    \
+    if constexpr (KS < NKS) {                                                                             \
+      if constexpr (FP8) {                                                                                \
+        acc[0][I0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb0[KS], AF0[KS], acc[0][I0], 0, 0, 0, SCALE1, 0, SCALE1); \
+        acc[0][I0 + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb0[KS], AF1[KS], acc[0][I0 + 1], 0, 0, 0, SCALE1, 0, SCALE1); \
+        acc[1][I0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb1[KS], AF0[KS], acc[1][I0], 0, 0, 0, SCALE1, 0, SCALE1); \
+        acc[1][I0 + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb1[KS], AF1[KS], acc[1][I0 + 1], 0, 0, 0, SCALE1, 0, SCALE1); \
+      } else {                                                                                            \
+        acc[0][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[KS], AF0[KS], acc[0][I0], 0, 0, 0);      \
+        acc[0][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[KS], AF1[KS], acc[0][I0 + 1], 0, 0, 0); \
+        acc[1][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[KS], AF0[KS], acc[1][I0], 0, 0, 0);      \
+        acc[1][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[KS], AF1[KS], acc[1][I0 + 1], 0, 0, 0); \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+#define HVLM_MFMA_OCT(I0, AF0, AF1)                                                                       \
+  do {                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    HVLM_MFMA_OCT_STEP(I0, AF0, AF1, 0);                                                                  \
+    HVLM_MFMA_OCT_STEP(I0, AF0, AF1, 1);                                                                  \
+    HVLM_MFMA_OCT_STEP(I0, AF0, AF1, 2);                                                                  \
+    HVLM_MFMA_OCT_STEP(I0, AF0, AF1, 3);                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+    asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
 #define HVLM_PHASE_SYNC()                 \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -571,6 +602,28 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       const unsigned sb = cb * STAGE_BYTES;
       frag_t fb0[NKS], fb1[NKS], fa0[NKS], fa1[NKS];
       constexpr int SCALE1 = 0x7f7f7f7f;        // e8m0 block scales = 2^0
+      if constexpr (SEG4) {
+        // 4-segment schedule: two 16-MFMA segments per K-tile (4 barriers instead of 8).  Load segment A reads B0, B1
+        // and this group's A rows of half 0 (16 reads) and stages A1 of K-tile g+1; load segment B reads the rows of
+        // half 1 (8 reads) and stages A0, B0, B1 of K-tile g+2 into the slots segment A just read.  Every DMA piece
+        // has four segments to land; the counted wait stays vmcnt(8) at both syncs.
+        read_b(sb, T0{}, fb0);
+        read_a(sb, T0{}, fa0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(sb, T1{}, fb1);
+        read_a(sb, T1{}, fa1);
+        stage_a(ob, 1, c1);
+        HVLM_PHASE_SYNC();
+        HVLM_MFMA_OCT(0, fa0, fa1);
+        __builtin_amdgcn_s_barrier();
+        read_a(sb, T2{}, fa0);
+        read_a(sb, T3{}, fa1);
+        stage_a(cb, 0, c2);
+        stage_b(cb, 0, c2);
+        stage_b(cb, 1, c2);
+        HVLM_PHASE_SYNC();
+        HVLM_MFMA_OCT(2, fa0, fa1);
+      } else {
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
       const unsigned adb = lds0 + sb + tb_off, ada0 = lds0 + sb + ta_off[0], ada1 = lds0 + sb + ta_off[1];   // TN
       if constexpr (!TN) {
@@ -612,6 +665,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       stage_b(cb, 0, c2);
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1, 15, 15, 15, 15);
+      }
       c1 = c2;
       advance(c2);
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
@@ -635,6 +689,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     }
     epilogue(m0, n0, (size_t)ksl * p.slab);
     int t_aft = -1;
+    asm volatile("" : "+v"(t_aft_v));       // retire the slot load here: left pending, it puts a vmcnt(0) into the K loop
     if (dyn) {
       if (w == 0 && l == 0) {
         int* sp = &g_pp.slots[blockIdx.x][(it + 3) & 3];
@@ -663,6 +718,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   }
   HVLM_VMCNT(0);
 #undef HVLM_MFMA_QUAD
+#undef HVLM_MFMA_OCT
+#undef HVLM_MFMA_OCT_STEP
 #undef HVLM_MFMA_STEP
 #undef HVLM_TR2
 #undef HVLM_PHASE_SYNC
@@ -671,11 +728,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false, false>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true, false>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_body<false, false, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true>(p); }
 
-template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8
+template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4 = NT bf16, NT fp8 on the 4-segment schedule
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -685,6 +744,8 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
     attr_done = true;
   }
   if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 4) hipLaunchKernelGGL(gemm_pp4_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 3) hipLaunchKernelGGL(gemm_pp4_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 2) hipLaunchKernelGGL(gemm_pp_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   return HVLM_OK;
@@ -702,8 +763,17 @@ int pp_sched_slot(hipStream_t stream) {
   return n++;
 }
 
-int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<0>(p, grid, stream); }
+// HVLM_GEMM_SEG4=0 selects the 8-phase schedule for the K-contiguous kernels (A/B switch; default = 4-segment)
+static bool use_seg4() {
+  static const bool v = !(getenv("HVLM_GEMM_SEG4") && atoi(getenv("HVLM_GEMM_SEG4")) == 0);
+  return v;
+}
+int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
+  return use_seg4() ? launch_pp<3>(p, grid, stream) : launch_pp<0>(p, grid, stream);
+}
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<1>(p, grid, stream); }
-int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<2>(p, grid, stream); }
+int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
+  return use_seg4() ? launch_pp<4>(p, grid, stream) : launch_pp<2>(p, grid, stream);
+}
 
 }  // namespace hvlm
