@@ -501,7 +501,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 9;
@@ -603,7 +603,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0; p.dbg = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -674,7 +674,7 @@ extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, in
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0; p.dbg = 0;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;

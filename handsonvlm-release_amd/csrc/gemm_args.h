@@ -14,6 +14,7 @@ struct GemmArgs {
   int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
   size_t slab;                  // elements between fp32 slabs
   int dyn;                      // gemm_pp: 0 = static tile assignment, s+1 = dynamic scheduling on state slot s (pp_sched_slot)
+  int dbg;                      // development ablations (HVLM_GEMM_DBG), 0 in production
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
 };
 

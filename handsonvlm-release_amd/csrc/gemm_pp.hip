@@ -612,15 +612,17 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         __builtin_amdgcn_sched_barrier(0);
         read_b(sb, T1{}, fb1);
         read_a(sb, T1{}, fa1);
-        stage_a(ob, 1, c1);
+        if (!(p.dbg & 2)) stage_a(ob, 1, c1);
         HVLM_PHASE_SYNC();
         HVLM_MFMA_OCT(0, fa0, fa1);
         __builtin_amdgcn_s_barrier();
         read_a(sb, T2{}, fa0);
         read_a(sb, T3{}, fa1);
-        stage_a(cb, 0, c2);
-        stage_b(cb, 0, c2);
-        stage_b(cb, 1, c2);
+        if (!(p.dbg & 1)) {
+          stage_a(cb, 0, c2);
+          stage_b(cb, 0, c2);
+          stage_b(cb, 1, c2);
+        }
         HVLM_PHASE_SYNC();
         HVLM_MFMA_OCT(2, fa0, fa1);
       } else {
@@ -666,8 +668,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1, 15, 15, 15, 15);
       }
-      c1 = c2;
-      advance(c2);
+      if (!(p.dbg & 4)) {
+        c1 = c2;
+        advance(c2);
+      }
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
     }
     int m0, n0, ksl;
