@@ -481,6 +481,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
 
 using namespace hvlm;
 
+// development ablations of the ping-pong kernel's K loop (wrong results by construction; timing / PMC only):
+// 1 = no LDS-DMA in load segment B, 2 = none in load segment A, 4 = staging cursors never advance (cache-hot source)
+static int gemm_dbg() {
+  static const int v = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
+  return v;
+}
+
 extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda,
                                  int ldb, int ldc, const void* bias, const void* residual, int ldr,
                                  int act, int out_f32, void* stream) {
@@ -501,7 +508,7 @@ extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, i
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg();
   { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
   const char* ve = getenv("HVLM_GEMM_VARIANT");   // development switch; default = tuned variant
   const int variant = ve ? atoi(ve) : 9;
@@ -603,7 +610,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0; p.dbg = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg();
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
