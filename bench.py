@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
+    ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
     return ap.parse_args()
 
@@ -92,10 +93,11 @@ class GemmEvents:
 
     def __init__(self):
         self.pairs = []
+        self.kernels = 0          # launches of the GEMM kernel (a tail-split call is two)
         self.enabled = False
         self._cur = None
 
-    def __call__(self, M, N, K, begin):
+    def __call__(self, M, N, K, begin, n_kernels=1):
         if not self.enabled:
             return
         if begin:
@@ -106,6 +108,7 @@ class GemmEvents:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.pairs.append((self._cur, e, 2.0 * M * N * K, (M, N, K)))
+            self.kernels += n_kernels
 
     def summary(self):
         if not self.pairs:
@@ -123,8 +126,8 @@ class GemmEvents:
                 cur_e = max(cur_e, e0)
         ms += cur_e - cur_s
         fl = sum(f for _, _, f, _ in self.pairs)
-        return dict(launches=len(self.pairs), total_ms=ms, total_flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
-                    avg_us=ms * 1e3 / len(self.pairs))
+        return dict(launches=self.kernels, calls=len(self.pairs), total_ms=ms, total_flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+                    avg_us=ms * 1e3 / self.kernels)
 
 
     def by_shape(self):
@@ -152,7 +155,7 @@ def pmc_traffic(ev, args):
         if shp not in table:
             return None, f"GEMM shape {shp} of this run is not in profiles/r01k_gemm_traffic.json"
         tot += table[shp]
-    return tot / len(ev.pairs), ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, collected per GEMM shape in isolation "
+    return tot / ev.kernels, ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch, collected per GEMM shape in isolation "
                                  "(tools/gemm_traffic.py -> profiles/r01k_gemm_traffic.json), weighted by this run's launches; "
                                  "algorithmic operand+output bytes per launch: 0.70 GB")
 
@@ -254,8 +257,8 @@ def main():
     cfg = make_config(args)
     B, T = args.batch, args.text_len
     model = HandsOnVLMForCausalLM(cfg, device=device, training=True).init_random(seed=0)
-    opt = AdamW(model, lr=2e-5, weight_decay=0.0)
-    buckets = hdp.attach(model, hdp.GradBuckets())
+    opt = AdamW(model, lr=2e-5, weight_decay=0.0, overlap=not args.no_opt_overlap)
+    buckets = hdp.attach(model, hdp.GradBuckets(), opt)
     batch = make_batch(cfg, B, T, args.unique_frames, seed=100 + rank, device=device)
     ev = GemmEvents()
     if not args.no_gemm_events:
@@ -263,9 +266,10 @@ def main():
 
     def step():
         out = model(**batch)
+        opt.begin_step(grad_scale=1.0 / world)     # per-bucket updates start as the buckets become final in backward
         model.backward()
         buckets.wait()
-        opt.step(grad_scale=1.0 / world)
+        opt.step()
         return out
 
     def barrier():
@@ -332,7 +336,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4_kernel", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
-                               "launches": gs["launches"], "avg_launch_us": gs["avg_us"],
+                               "launches": gs["launches"], "gemm_calls": gs["calls"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}
         if world == 1 and not args.no_eval:

@@ -43,11 +43,13 @@ class GradBuckets:
         self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("HVLM_FORCE_DIST", "0") == "1")
         self.handles: List = []
 
-    def reduce_async(self, *tensors: torch.Tensor):
+    def reduce_async(self, *tensors: torch.Tensor) -> List:
+        """Starts the all-reduces; returns their work handles (empty when not distributed)."""
         if not self.active:
-            return
-        for t in tensors:
-            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return []
+        hs = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
+        self.handles.extend(hs)
+        return hs
 
     def wait(self):
         for h in self.handles:
@@ -55,24 +57,27 @@ class GradBuckets:
         self.handles = []
 
 
-def attach(model, buckets: GradBuckets):
+def attach(model, buckets: GradBuckets, opt=None):
     """Wires the model's backward hooks to the buckets: layer i -> its flat bucket; 'tail' -> embed, lm_head,
-    projector, final norm and the CVAE head's PyTorch gradients."""
+    projector, final norm and the CVAE head's PyTorch gradients.  With an overlapped optimizer (`opt`, optim.AdamW
+    with overlap=True) every bucket is also handed to it the moment it is final, ordered after its all-reduce."""
     stack = model.stack
+    ready = opt.bucket_ready if opt is not None else (lambda key, after=(): None)
 
     def on_layer(i: int):
-        buckets.reduce_async(stack.layers[i].flat_g)
+        ready(f"layers.{i}", buckets.reduce_async(stack.layers[i].flat_g))
 
     def on_named(which: str):
         if which == "head":
             # lm_head's gradient (263 MB for 7B) is final before the decoder backward starts: reducing it here hides it
             # under the whole backward instead of leaving it exposed at the end of the step.
-            buckets.reduce_async(model.lm_head_g)
+            ready("head", buckets.reduce_async(model.lm_head_g))
         if which == "tail":
-            buckets.reduce_async(stack.norm_g, model.embed_g, model.proj_w_g, model.proj_b_g)
+            hs = buckets.reduce_async(stack.norm_g, model.embed_g, model.proj_w_g, model.proj_b_g)
             for p in model.hand_traj_decoder.parameters():
                 if p.grad is not None:
                     buckets.reduce_async(p.grad)
+            ready("tail", hs)
 
     stack.on_layer_grad_ready = on_layer
     model.on_grads_ready = on_named

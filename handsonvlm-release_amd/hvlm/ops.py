@@ -27,7 +27,7 @@ _GEMM_CUS = 256                      # persistent GEMM grid (MI355X: 256 CUs); o
 _GEMM_TAIL = os.environ.get("HVLM_GEMM_TAIL", "1") == "1"
 _GEMM_TAIL_MIN_K = int(os.environ.get("HVLM_GEMM_TAIL_MIN_K", "8192"))
 
-# Optional instrumentation (bench.py): called as hook(M, N, K) -> context manager around each GEMM launch.
+# Optional instrumentation (bench.py): hook(M, N, K, True) before / hook(M, N, K, False[, n_kernels]) after each GEMM call.
 _gemm_hook = None
 
 
@@ -126,7 +126,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
                                                    out.stride(0), _p(bias), _p(res_t), ldr, act, _p(ws), splits, _stream()),
                       "gemm_splitk(tail)")
                 if hook is not None:
-                    hook(M, N, K, False)
+                    hook(M, N, K, False, 2)             # two launches of the GEMM kernel inside this interval
                 return out
     check(lib.hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
                                 out.stride(0), _p(bias), _p(residual), ldr, act,

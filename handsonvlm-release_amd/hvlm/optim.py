@@ -4,7 +4,15 @@ weight decay 0, betas (0.9, 0.999), eps 1e-8 (HF Trainer defaults).
 
 One fused HIP kernel per tensor (hvlm_adamw_step) updates master/m/v, writes the bf16 working copy
 and — for GEMM weights — its transposed copy used by the dX GEMMs, so no separate transpose pass
-runs after the step."""
+runs after the step.
+
+Overlapped mode (`overlap=True`, GPU only): the update of a gradient bucket (one decoder layer; lm_head; the
+embed / norm / projector tail) is enqueued on the optimizer's own HIP stream the moment that bucket is final —
+after its all-reduce under DP, after its backward kernels otherwise — so the HBM-bound update (≈190 GB of state
+traffic per 7B step) runs beside the MFMA-bound backward of the earlier layers instead of after it.  The reference
+does not clip gradients (scripts/zero3.json has no `gradient_clipping`, so DeepSpeed's default 0 applies): no
+global-norm dependency forces the update to wait for the whole backward, and the result is bit-identical to the
+end-of-step update."""
 from __future__ import annotations
 
 import math
@@ -25,7 +33,8 @@ def cosine_lr(step: int, total_steps: int, base_lr: float, warmup_ratio: float =
 
 
 class AdamW:
-    def __init__(self, model, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+    def __init__(self, model, lr: float = 2e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 overlap: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -36,15 +45,60 @@ class AdamW:
                                    v=torch.zeros_like(master)))
         self.head = torch.optim.AdamW(model.hand_traj_decoder.parameters(), lr=lr, betas=betas, eps=eps,
                                       weight_decay=weight_decay)
-
-    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
-        """grad_scale multiplies every gradient (1/world_size after a SUM all-reduce)."""
-        self.step_count += 1
-        lr = self.lr if lr is None else lr
-        b1, b2 = self.betas
+        # gradient-bucket key -> its tensors (the keys dp.attach's hooks report: "layers.<i>", "head", "tail")
+        self.groups = {}
         for st in self.state:
+            n = st["name"]
+            key = n.rsplit(".", 1)[0] if n.startswith("layers.") else ("head" if n == "lm_head" else "tail")
+            self.groups.setdefault(key, []).append(st)
+        self.overlap = bool(overlap) and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream() if self.overlap else None
+        self._open = None                  # (lr, grad_scale) between begin_step() and step()
+        self._done = set()
+
+    def _update(self, sts, lr, grad_scale):
+        b1, b2 = self.betas
+        for st in sts:
             ops.adamw_step_(st["master"], st["m"], st["v"], st["g"], st["w"], st["wt"], lr, b1, b2, self.eps, self.wd,
                             grad_scale, self.step_count)
+
+    def begin_step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
+        """Overlapped mode: call before backward; fixes this step's lr / grad_scale for the per-bucket updates."""
+        self.step_count += 1
+        self._open = (self.lr if lr is None else lr, grad_scale)
+        self._done = set()
+
+    def bucket_ready(self, key: str, after=()):
+        """The gradients of bucket `key` are final once the work handles in `after` (its all-reduces) complete, or —
+        without handles — once the kernels enqueued so far on the current stream have run: update it on the optimizer
+        stream.  No-op outside overlapped mode / outside begin_step()..step()."""
+        if not self.overlap or self._open is None or key not in self.groups or key in self._done:
+            return
+        lr, grad_scale = self._open
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            if after:
+                for h in after:
+                    h.wait()               # NCCL/RCCL work: orders THIS stream after the collective, the host does not block
+            else:
+                self.stream.wait_stream(cur)
+            self._update(self.groups[key], lr, grad_scale)
+        self._done.add(key)
+
+    def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
+        """grad_scale multiplies every gradient (1/world_size after a SUM all-reduce).  After begin_step(): finishes
+        the step (buckets not yet updated + the CVAE head) and joins the optimizer stream."""
+        if self._open is None:
+            self.step_count += 1
+            lr = self.lr if lr is None else lr
+            rest = self.state
+        else:
+            lr, grad_scale = self._open
+            rest = [st for k, sts in self.groups.items() if k not in self._done for st in sts]
+            self._open = None
+        self._update(rest, lr, grad_scale)
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.stream)   # next forward reads the weights written there
         for grp in self.head.param_groups:
             grp["lr"] = lr
         if grad_scale != 1.0:

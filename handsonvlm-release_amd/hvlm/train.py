@@ -23,8 +23,8 @@ from .optim import AdamW, cosine_lr
 def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_steps=None, lr=2e-5, warmup_ratio=0.03,
           weight_decay=0.0, save_every_epoch=True, log_every=10, seed=0, num_workers=0):
     rank, local, world = dp.init_from_env()
-    buckets = dp.attach(model, dp.GradBuckets())
-    opt = AdamW(model, lr=lr, weight_decay=weight_decay)
+    opt = AdamW(model, lr=lr, weight_decay=weight_decay, overlap=True)
+    buckets = dp.attach(model, dp.GradBuckets(), opt)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed) \
         if world > 1 else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=per_device_batch, sampler=sampler, shuffle=sampler is None,
@@ -46,10 +46,11 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
             if step >= total:
                 break
             out = model(**batch)
+            step += 1
+            opt.begin_step(lr=cosine_lr(step, total, lr, warmup_ratio), grad_scale=1.0 / world)
             model.backward()
             buckets.wait()
-            step += 1
-            opt.step(lr=cosine_lr(step, total, lr, warmup_ratio), grad_scale=1.0 / world)
+            opt.step()
             if step % log_every == 0 or step == total:
                 rec = dict(step=step, loss=float(out.loss.detach()), **{k: float(v) for k, v in out.loss_components.items()},
                            samples_per_s=world * per_device_batch * log_every / (time.perf_counter() - t0))

@@ -115,3 +115,36 @@ def test_fp8_forward_close_to_bf16_forward():
     r = float((got - ref).norm() / ref.norm())
     print("fp8 vs bf16 forward rel", r)
     assert float(ref.norm()) > 1.0 and 1e-4 < r < 8e-2 and torch.isfinite(got).all()
+
+
+def test_overlapped_optimizer_bit_identical_to_end_of_step_update():
+    """AdamW per gradient bucket on the optimizer stream, started from the backward hooks (optim.AdamW overlap=True),
+    against the same update done after the whole backward: every weight, transposed copy and moment bit-identical after
+    two steps (the reference does not clip gradients, so no update depends on the other buckets)."""
+    from test_gpu_model import tiny_model, tiny_batch
+    from hvlm import dp
+    from hvlm.optim import AdamW
+    ids, labels, mask, images, fh, fv = tiny_batch()
+    eps = torch.randn(2 * 8, 256, generator=torch.Generator().manual_seed(1)).cuda()
+    snaps = []
+    for overlap in (False, True):
+        m, cfg = tiny_model(training=True)
+        opt = AdamW(m, lr=1e-3, weight_decay=0.01, overlap=overlap)
+        buckets = dp.attach(m, dp.GradBuckets(), opt)
+        assert opt.overlap == overlap and set(opt.groups) == {f"layers.{i}" for i in range(cfg.num_hidden_layers)} | {"head", "tail"}
+        for _ in range(2):
+            out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(BF), future_hands=fh.clone(),
+                    future_valid=fv.clone(), cvae_eps=eps)
+            opt.begin_step(grad_scale=0.5)
+            out.loss.backward()
+            if overlap:
+                assert opt._done == set(opt.groups)                 # every bucket was handed over from a hook
+            buckets.wait()
+            opt.step()
+        torch.cuda.synchronize()
+        snaps.append([(st["name"], st["w"].clone(), None if st["wt"] is None else st["wt"].clone(), st["m"].clone(),
+                       st["v"].clone(), st["master"].clone()) for st in opt.state])
+    for a, b in zip(*snaps):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert (x is None and y is None) or torch.equal(x, y), a[0]
