@@ -245,6 +245,11 @@ def eval_leg(model, cfg, T, device):
 
 def main():
     args = parse()
+    # exactly ONE line on stdout (the JSON): libraries that print to stdout (RCCL's "Librccl path : ..." banner, the CPU
+    # oracle's progress) are sent to stderr by swapping file descriptor 1 for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from hvlm import dp as hdp
     rank, local, world = hdp.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -349,7 +354,8 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(cfg, T)
             except Exception as ex:  # noqa
                 res["cpu_baseline"] = {"error": str(ex)[:200]}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
