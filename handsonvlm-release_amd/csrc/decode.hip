@@ -10,15 +10,18 @@ namespace hvlm {
 namespace {
 
 // y[n] = sum_k W[n,k] x'[k] (+ res[n]);  one wave per ROWS consecutive rows, x' staged in LDS.
+// yrow != null: y is advanced by *yrow * ystride elements first (read on the device).
 // PRE selects what x' is (computed by every workgroup while it stages the 8-22 KB vector: cheaper than a kernel launch):
 //   0: x' = x;   1: x' = RMSNorm(x) * nw  (same arithmetic as rmsnorm_fwd_kernel: bf16(x*rstd) then * w, bf16);
 //   2: x' = SwiGLU(x) with x = [gate(K) | up(K)]  (same arithmetic as swiglu_fwd_kernel).
 template <int ROWS, int PRE>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                    bf16_t* __restrict__ y, const bf16_t* __restrict__ res, int N,
-                                                   int K, int ldw, const bf16_t* __restrict__ nw, float eps) {
+                                                   int K, int ldw, const bf16_t* __restrict__ nw, float eps,
+                                                   const int32_t* __restrict__ yrow, long ystride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+  if (yrow) y += (long)(*yrow) * ystride;      // graph-replayed decode: the output row (KV-cache position) lives on the device
   if constexpr (PRE == 0) {
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8)
       *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(x + i);
@@ -173,7 +176,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 template <int DH>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                                   const bf16_t* __restrict__ vc, float* __restrict__ part_out,
-                                                                  int S, int ld, float scale, int NS) {
+                                                                  int S, int ld, float scale, int NS,
+                                                                  const int32_t* __restrict__ pos_dev) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = reinterpret_cast<float*>(smem);          // [DH]
   float* red = qs + DH;                                  // [8]
@@ -182,6 +186,11 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
   float* part = red + 8;                                 // [G][DH]
   float* sc = part + G * DH;                             // [keys of this split]
   const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
+  if (pos_dev) {                                         // graph-replayed decode: q is the cache base, the position is on the device
+    const int p = *pos_dev;
+    S = p + 1;
+    q += (size_t)p * ld;
+  }
   const int s_begin = (int)((long)S * j / NS), s_end = (int)((long)S * (j + 1) / NS);
   const int n = s_end - s_begin;
   if (t < DH) qs[t] = bf2f(q[h * DH + t]) * scale;
@@ -247,6 +256,41 @@ __global__ __launch_bounds__(DH) void attn_decode_combine_kernel(const float* __
   out[h * DH + t] = f2bf(o / l);
 }
 
+// RoPE of the one new q / k row of the graph-replayed decode step: row = kv + *pos * ld, tables indexed by *pos.  Same
+// arithmetic as rope_kernel (elementwise.hip): o1 = bf16(bf16(x1*c) + bf16(-x2*s)), o2 = bf16(bf16(x2*c) + bf16(x1*s)).
+__global__ __launch_bounds__(256) void rope_decode_kernel(bf16_t* __restrict__ kv, const bf16_t* __restrict__ cos_tab,
+                                                          const bf16_t* __restrict__ sin_tab,
+                                                          const int32_t* __restrict__ pos_dev, int H, int dh, int ld) {
+  const int half = dh / 2, pv = half / 8;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * H * pv) return;
+  const int p = *pos_dev;
+  const int hh = i / pv, c = (i - hh * pv) * 8;
+  bf16_t* base = kv + (size_t)p * ld + (size_t)hh * dh + c;
+  const u32x4 cv = *reinterpret_cast<const u32x4*>(cos_tab + (long)p * half + c);
+  const u32x4 sv = *reinterpret_cast<const u32x4*>(sin_tab + (long)p * half + c);
+  const u32x4 x1 = *reinterpret_cast<const u32x4*>(base);
+  const u32x4 x2 = *reinterpret_cast<const u32x4*>(base + half);
+  u32x4 o1, o2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a[2] = {bf_lo(x1[e]), bf_hi(x1[e])}, b[2] = {bf_lo(x2[e]), bf_hi(x2[e])};
+    const float cc[2] = {bf_lo(cv[e]), bf_hi(cv[e])}, ss[2] = {bf_lo(sv[e]), bf_hi(sv[e])};
+    float r1[2], r2[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      r1[k] = bf2f(f2bf(a[k] * cc[k])) + bf2f(f2bf(-b[k] * ss[k]));
+      r2[k] = bf2f(f2bf(b[k] * cc[k])) + bf2f(f2bf(a[k] * ss[k]));
+    }
+    o1[e] = pack_bf2(r1[0], r1[1]);
+    o2[e] = pack_bf2(r2[0], r2[1]);
+  }
+  *reinterpret_cast<u32x4*>(base) = o1;
+  *reinterpret_cast<u32x4*>(base + half) = o2;
+}
+
+__global__ void pos_advance_kernel(int32_t* pos_dev) { pos_dev[0] += 1; }
+
 }  // namespace
 }  // namespace hvlm
 
@@ -255,19 +299,19 @@ using namespace hvlm;
 // GEMV with a fused prologue on x (pre: 0 none, 1 RMSNorm with weights `nw`, 2 SwiGLU of x = [gate | up]); internal to the
 // native decode step (hvlm_gemv_bf16 is pre = 0).
 static int gemv_pre(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw, int pre,
-                    const void* nw, float eps, void* stream) {
+                    const void* nw, float eps, void* stream, const int32_t* yrow = nullptr, long ystride = 0) {
   constexpr int ROWS = 2;
   const int waves = cdiv(N, ROWS);
   dim3 grid(cdiv(waves, 4)), block(256);
   if (pre == 1)
     hipLaunchKernelGGL((gemv_kernel<ROWS, 1>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps, yrow, ystride);
   else if (pre == 2)
     hipLaunchKernelGGL((gemv_kernel<ROWS, 2>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride);
   else
     hipLaunchKernelGGL((gemv_kernel<ROWS, 0>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride);
   return check_launch("gemv");
 }
 
@@ -296,13 +340,17 @@ extern "C" int hvlm_attn_decode(const void* q, const void* k_cache, const void* 
 }
 
 // One whole decode step of the decoder stack, launched from native code (no per-kernel host round trip):
-// 9 launches per layer on the caller's stream.  Pointer tables are HOST arrays of device pointers.
-extern "C" int hvlm_llama_decode_step(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
-                                      const void* const* w_down, const void* const* ln1, const void* const* ln2,
-                                      void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
-                                      const int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D,
-                                      int F, int H, int dh, int pos, int cache_ld, float eps, void* stream) {
-  HVLM_REQUIRE(w_qkv && w_o && w_gu && w_down && ln1 && ln2 && kv_cache && norm_w && x_in && hidden_out && ws,
+// 7 launches per layer on the caller's stream.  Pointer tables are HOST arrays of device pointers.
+// pos >= 0: the position is a host value (eager mode).  pos < 0: the position is read on the device from pos_dev[0] by every
+// kernel that needs it (the qkv GEMV's output row, RoPE, the attention length) and advanced by one at the end, so the
+// launch sequence is identical for every token and can be captured once in a hipGraph and replayed (max_S bounds the
+// attention's LDS score buffer and fixes the key split).
+static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
+                            const void* const* w_down, const void* const* ln1, const void* const* ln2,
+                            void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
+                            const int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D,
+                            int F, int H, int dh, int pos, int max_S, int cache_ld, float eps, void* stream) {
+  HVLM_REQUIRE(w_qkv && w_o && w_gu && w_down && ln1 && ln2 && kv_cache && norm_w && x_in && hidden_out && ws && pos_dev,
                "decode_step: null pointer");
   HVLM_REQUIRE(cache_ld >= 3 * D && D == H * dh, "decode_step: bad shape");
   bf16_t* w = reinterpret_cast<bf16_t*>(ws);
@@ -316,25 +364,33 @@ extern "C" int hvlm_llama_decode_step(const void* const* w_qkv, const void* cons
   HVLM_REQUIRE(((size_t)F * 2) <= 64 * 1024 && (size_t)D * 2 <= 64 * 1024, "decode_step: D / F too large for the LDS copy of x");
   const float scale = 1.0f / sqrtf((float)dh);
   const bf16_t* x = reinterpret_cast<const bf16_t*>(x_in);
-  const int S = pos + 1;
+  const bool dev = pos < 0;
+  const int S = dev ? max_S : pos + 1;
+  HVLM_REQUIRE(S > 0, "decode_step: bad position / max_S");
   const int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);      // key splits: H * NS workgroups
   const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1) * 4;
   HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
+  const int32_t* pd = dev ? pos_dev : nullptr;
   int rc;
   // 7 launches per layer: the two RMSNorms and the SwiGLU ride in the prologue of the GEMV that consumes them, attention is
   // split over the keys (flash-decoding) + a combine pass
   for (int l = 0; l < L; ++l) {
     bf16_t* kv = reinterpret_cast<bf16_t*>(kv_cache[l]);
-    bf16_t* row = kv + (size_t)pos * cache_ld;
-    if ((rc = gemv_pre(w_qkv[l], x, row, nullptr, 3 * D, D, D, 1, ln1[l], eps, stream))) return rc;
-    if ((rc = hvlm_rope_qk(row, cos_tab, sin_tab, pos_dev, 1, H, dh, cache_ld, 0, stream))) return rc;
+    bf16_t* row = dev ? kv : kv + (size_t)pos * cache_ld;
+    if ((rc = gemv_pre(w_qkv[l], x, row, nullptr, 3 * D, D, D, 1, ln1[l], eps, stream, pd, cache_ld))) return rc;
+    if (dev) {
+      hipLaunchKernelGGL(rope_decode_kernel, dim3(cdiv(2 * H * (dh / 16), 256)), dim3(256), 0, as_stream(stream), kv,
+                         (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, pos_dev, H, dh, cache_ld);
+    } else if ((rc = hvlm_rope_qk(row, cos_tab, sin_tab, pos_dev, 1, H, dh, cache_ld, 0, stream))) {
+      return rc;
+    }
     if (dh == 128) {
       hipLaunchKernelGGL((attn_decode_partial_kernel<128>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
-                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS);
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd);
       hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
     } else {
       hipLaunchKernelGGL((attn_decode_partial_kernel<64>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
-                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS);
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd);
       hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
     }
     if ((rc = check_launch("attn_decode_split"))) return rc;
@@ -344,7 +400,32 @@ extern "C" int hvlm_llama_decode_step(const void* const* w_qkv, const void* cons
     if ((rc = gemv_pre(w_down[l], gu, xo, h, D, F, F, 2, nullptr, 0.f, stream))) return rc;
     x = xo;
   }
-  return hvlm_rmsnorm_fwd(x, norm_w, hidden_out, nullptr, 1, D, eps, stream);
+  if ((rc = hvlm_rmsnorm_fwd(x, norm_w, hidden_out, nullptr, 1, D, eps, stream))) return rc;
+  if (dev) {
+    hipLaunchKernelGGL(pos_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), const_cast<int32_t*>(pos_dev));
+    return check_launch("pos_advance");
+  }
+  return HVLM_OK;
+}
+
+extern "C" int hvlm_llama_decode_step(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
+                                      const void* const* w_down, const void* const* ln1, const void* const* ln2,
+                                      void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
+                                      const int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D,
+                                      int F, int H, int dh, int pos, int cache_ld, float eps, void* stream) {
+  HVLM_REQUIRE(pos >= 0, "decode_step: negative position");
+  return decode_step_impl(w_qkv, w_o, w_gu, w_down, ln1, ln2, kv_cache, norm_w, cos_tab, sin_tab, pos_dev, x_in, hidden_out, ws,
+                          L, D, F, H, dh, pos, 0, cache_ld, eps, stream);
+}
+
+extern "C" int hvlm_llama_decode_step_dev(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
+                                          const void* const* w_down, const void* const* ln1, const void* const* ln2,
+                                          void* const* kv_cache, const void* norm_w, const void* cos_tab,
+                                          const void* sin_tab, int32_t* pos_dev, const void* x_in, void* hidden_out,
+                                          void* ws, int L, int D, int F, int H, int dh, int max_S, int cache_ld, float eps,
+                                          void* stream) {
+  return decode_step_impl(w_qkv, w_o, w_gu, w_down, ln1, ln2, kv_cache, norm_w, cos_tab, sin_tab, pos_dev, x_in, hidden_out, ws,
+                          L, D, F, H, dh, -1, max_S, cache_ld, eps, stream);
 }
 
 extern "C" size_t hvlm_llama_decode_ws_bytes(int D, int F) {

@@ -84,6 +84,7 @@ class LlamaStack:
         self.saved: List[dict] = []
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
         self._dec_tables = None
+        self._dec_graph = None
         self.on_layer_grad_ready: Optional[Callable[[int], None]] = None   # DP hook: bucket i is final
 
     # -- parameters -----------------------------------------------------------------------------
@@ -144,10 +145,7 @@ class LlamaStack:
             self._kv_cache = kept
         return kept
 
-    def decode_step(self, x1: torch.Tensor, pos: int, cache: List[torch.Tensor]) -> torch.Tensor:
-        """One new token (x1 [1, D]) at position `pos` against the KV cache -> final-normed hidden [1, D].
-        HBM-bound (every weight is streamed once by the GEMV kernel); the 9 launches per layer are issued by one
-        native call (hvlm_llama_decode_step), not from Python."""
+    def _decode_tables(self, cache):
         import ctypes
         from . import _lib
         lib = _lib.load()
@@ -158,7 +156,56 @@ class LlamaStack:
             ws = torch.empty((lib.hvlm_llama_decode_ws_bytes(self.D, self.F),), dtype=torch.uint8, device=self.device)
             self._dec_tables = (cache, lw("qkv"), lw("o"), lw("gu"), lw("down"), lw("ln1"), lw("ln2"), arr(cache), ws,
                                 self._positions(1, self.cfg.max_position_embeddings))
-        _, tq, to, tg, td, t1, t2, tc, ws, posv = self._dec_tables
+            self._dec_graph = None
+        return self._dec_tables
+
+    def decode_step(self, x1: torch.Tensor, pos: int, cache: List[torch.Tensor]) -> torch.Tensor:
+        """One new token (x1 [1, D]) at position `pos` against the KV cache -> final-normed hidden [1, D].
+        HBM-bound (every weight is streamed once by the GEMV kernel).  The 7 launches per layer are issued by one native
+        call (hvlm_llama_decode_step), asynchronously and far ahead of the GPU.  HVLM_DECODE_GRAPH=1 captures that call ONCE
+        in a hipGraph (hvlm_llama_decode_step_dev: the position lives on the device, so the launch sequence is the same for
+        every token) and replays it per token — 226 kernel nodes, one graph launch, bit-identical results.  Measured on
+        MI355X (tools/decode_bench.py, 7B, cache length 870): 3.11 ms/token either way — the step is bound by the GPU, not by
+        launch issue — so the eager loop stays the default and the graph is for hosts whose CPU is the bottleneck."""
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        _, tq, to, tg, td, t1, t2, tc, ws, posv = self._decode_tables(cache)
+        L = self.L
+        if os.environ.get("HVLM_DECODE_GRAPH", "0") == "1":
+            st = self._dec_graph
+            if st is None:
+                st = dict(x=torch.empty((1, self.D), dtype=BF16, device=self.device),
+                          hidden=torch.empty((1, self.D), dtype=BF16, device=self.device),
+                          pos=torch.zeros(1, dtype=torch.int32, device=self.device), next_pos=-1)
+
+                def issue():
+                    rc = lib.hvlm_llama_decode_step_dev(tq, to, tg, td, t1, t2, tc, ops._p(self.norm_w), ops._p(self.cos),
+                                                        ops._p(self.sin), ops._p(st["pos"]), ops._p(st["x"]), ops._p(st["hidden"]),
+                                                        ops._p(ws), L, self.D, self.F, self.H, self.dh, cache[0].shape[0],
+                                                        cache[0].stride(0), self.cfg.rms_norm_eps, ops._stream())
+                    _lib.check(rc, "llama_decode_step_dev")
+
+                # eager once (code objects loaded before the capture), on the last cache row, which is put back afterwards
+                last = cache[0].shape[0] - 1
+                keep = [c[last].clone() for c in cache]
+                st["x"].zero_()
+                st["pos"].fill_(last)
+                issue()
+                for c, r in zip(cache, keep):
+                    c[last].copy_(r)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    issue()
+                st["g"] = g
+                self._dec_graph = st
+            st["x"].copy_(x1)
+            if st["next_pos"] != pos:                       # new sample (or first use): reset the device-side position
+                st["pos"].fill_(pos)
+            st["g"].replay()
+            st["next_pos"] = pos + 1
+            return st["hidden"].clone()
         hidden = torch.empty((1, self.D), dtype=BF16, device=self.device)
         rc = lib.hvlm_llama_decode_step(tq, to, tg, td, t1, t2, tc, ops._p(self.norm_w), ops._p(self.cos), ops._p(self.sin),
                                         ctypes.c_void_p(posv.data_ptr() + 4 * pos), ops._p(x1), ops._p(hidden), ops._p(ws), L,

@@ -168,6 +168,16 @@ int hvlm_llama_decode_step(const void* const* w_qkv, const void* const* w_o, con
                            void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
                            const int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D,
                            int F, int H, int dh, int pos, int cache_ld, float eps, void* stream);
+/* The same step with the position kept ON THE DEVICE: every kernel that needs it (the qkv GEMV's output row, RoPE, the
+ * attention length) reads pos_dev[0], and the last kernel advances it by one — the launch sequence does not depend on the
+ * token, so the caller captures it ONCE in a hipGraph and replays it per generated token (hvlm/llama.py::decode_step;
+ * the reference's sample() loop, handsonvlm.py:478-672, re-runs the whole model per token instead).  max_S = capacity of
+ * the caches (bounds the attention's LDS score buffer, fixes the key split).  No host synchronisation, no allocation. */
+int hvlm_llama_decode_step_dev(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
+                               const void* const* w_down, const void* const* ln1, const void* const* ln2,
+                               void* const* kv_cache, const void* norm_w, const void* cos_tab, const void* sin_tab,
+                               int32_t* pos_dev, const void* x_in, void* hidden_out, void* ws, int L, int D, int F,
+                               int H, int dh, int max_S, int cache_ld, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
  * SwiGLU — transformers LlamaMLP: down(silu(gate(x)) * up(x)).  gu is the fused [M, 2F] output of

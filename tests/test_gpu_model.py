@@ -191,3 +191,36 @@ def test_zz_write_report():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/gpu_model_report.json", "w") as f:
         json.dump(REPORT, f, indent=1)
+
+
+def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
+    """The decode step replayed from ONE captured hipGraph (position on the device, hvlm_llama_decode_step_dev) against the
+    eagerly launched step (hvlm_llama_decode_step): hidden states and the KV rows it writes bit-identical over several
+    tokens, across a restart at an earlier position (next sample), with the cache's last row untouched by the capture."""
+    m, cfg = tiny_model(training=False)
+    st, D = m.stack, cfg.hidden_size
+    cache = st.new_cache(64)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(20, D, device="cuda", generator=gen).to(torch.bfloat16)
+    for c in cache:
+        c.copy_(torch.randn(c.shape, device="cuda", generator=gen).to(torch.bfloat16))
+    st.forward(x, 1, 20, save=False, cache=cache)
+    snap = [c.clone() for c in cache]
+    xs = [torch.randn(1, D, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(4)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("HVLM_DECODE_GRAPH", mode)
+        for c, s0 in zip(cache, snap):
+            c.copy_(s0)
+        hs = [st.decode_step(x1, 20 + i, cache).clone() for i, x1 in enumerate(xs)]
+        rows = [c[20:24].clone() for c in cache]
+        hs.append(st.decode_step(xs[1], 20, cache).clone())          # a new sample restarts at an earlier position
+        hs.append(st.decode_step(xs[2], 21, cache).clone())
+        res[mode] = (hs, rows, [c[63].clone() for c in cache])
+    assert st._dec_graph is not None
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert torch.equal(a, b) and torch.isfinite(a.float()).all()
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert torch.equal(a, b)
+    for a, s0 in zip(res["1"][2], snap):
+        assert torch.equal(a, s0[63])
