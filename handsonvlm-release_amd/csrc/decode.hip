@@ -171,18 +171,28 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 // Flash-decoding split of the kernel above for the native decode step: grid (H, NS); workgroup (h, j) handles keys
-// [j*S/NS, (j+1)*S/NS) and writes {local max, local sum, unnormalised o[DH]} (DH + 2 floats); the combine kernel
-// (one workgroup per head) merges the NS partials.  One workgroup per head used 32 of 256 CUs: 32 us per layer at S = 870.
+// [j*S/NS, (j+1)*S/NS) and writes {local max, local sum, unnormalised o[DH]} (DH + 2 floats).  One workgroup per head
+// used 32 of 256 CUs: 32 us per layer at S = 870.
+// Fused into it (each was a 5-8 us kernel boundary per layer of an HBM-bound step that has 70 us of GEMV per layer):
+//   * RoPE of the new token (cos_tab != null): q is rotated while it is staged in LDS; the new K row (key S-1, raw in the
+//     cache) is rotated by the one thread that scores it, which also writes it back for the tokens to come.  Same arithmetic
+//     as rope_kernel: o1 = bf16(bf16(x1*c) + bf16(-x2*s)), o2 = bf16(bf16(x2*c) + bf16(x1*s));
+//   * the combine of the NS partials (cnt != null): the LAST workgroup of a head to finish (per-head ticket counter in the
+//     workspace, zero before first use, reset by that workgroup) merges them and writes the head's output.
 template <int DH>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                                   const bf16_t* __restrict__ vc, float* __restrict__ part_out,
                                                                   int S, int ld, float scale, int NS,
-                                                                  const int32_t* __restrict__ pos_dev) {
+                                                                  const int32_t* __restrict__ pos_dev,
+                                                                  const bf16_t* __restrict__ cos_tab,
+                                                                  const bf16_t* __restrict__ sin_tab, int* __restrict__ cnt,
+                                                                  bf16_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = reinterpret_cast<float*>(smem);          // [DH]
   float* red = qs + DH;                                  // [8]
   constexpr int CP = DH / 2;
   constexpr int G = 256 / CP;
+  constexpr int HALF = DH / 2;
   float* part = red + 8;                                 // [G][DH]
   float* sc = part + G * DH;                             // [keys of this split]
   const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x;
@@ -193,11 +203,52 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
   }
   const int s_begin = (int)((long)S * j / NS), s_end = (int)((long)S * (j + 1) / NS);
   const int n = s_end - s_begin;
-  if (t < DH) qs[t] = bf2f(q[h * DH + t]) * scale;
+  const bool rope = cos_tab != nullptr;
+  const bf16_t* ct = rope ? cos_tab + (size_t)(S - 1) * HALF : nullptr;
+  const bf16_t* st = rope ? sin_tab + (size_t)(S - 1) * HALF : nullptr;
+  if (t < DH) {
+    if (rope) {
+      const int c = t < HALF ? t : t - HALF;
+      const float x1 = bf2f(q[h * DH + c]), x2 = bf2f(q[h * DH + c + HALF]);
+      const float cc = bf2f(ct[c]), ss = bf2f(st[c]);
+      const float r = t < HALF ? bf2f(f2bf(x1 * cc)) + bf2f(f2bf(-x2 * ss)) : bf2f(f2bf(x2 * cc)) + bf2f(f2bf(x1 * ss));
+      qs[t] = bf2f(f2bf(r)) * scale;
+    } else {
+      qs[t] = bf2f(q[h * DH + t]) * scale;
+    }
+  }
+  // the new token's key (rope mode, last split): raw in the cache.  8 threads rotate it (one 8-pair chunk each), write it
+  // back for the tokens to come and park it in LDS; it is then scored like any other key, from LDS.
+  const bool has_new = rope && j == NS - 1;
+  const int n_old = has_new ? n - 1 : n;
+  bf16_t* knew = reinterpret_cast<bf16_t*>(sc + ((n + 3) & ~3));            // [DH] bf16, 16-byte aligned
+  if (has_new && t < HALF / 8) {
+    const int c = 8 * t;
+    bf16_t* kp = const_cast<bf16_t*>(kc) + (size_t)(S - 1) * ld + h * DH;
+    const u32x4 x1 = *reinterpret_cast<const u32x4*>(kp + c), x2 = *reinterpret_cast<const u32x4*>(kp + c + HALF);
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(ct + c), sv = *reinterpret_cast<const u32x4*>(st + c);
+    u32x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a[2] = {bf_lo(x1[e]), bf_hi(x1[e])}, b[2] = {bf_lo(x2[e]), bf_hi(x2[e])};
+      const float cc[2] = {bf_lo(cv[e]), bf_hi(cv[e])}, ss[2] = {bf_lo(sv[e]), bf_hi(sv[e])};
+      float r1[2], r2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        r1[k] = bf2f(f2bf(a[k] * cc[k])) + bf2f(f2bf(-b[k] * ss[k]));
+        r2[k] = bf2f(f2bf(b[k] * cc[k])) + bf2f(f2bf(a[k] * ss[k]));
+      }
+      o1[e] = pack_bf2(r1[0], r1[1]);
+      o2[e] = pack_bf2(r2[0], r2[1]);
+    }
+    *reinterpret_cast<u32x4*>(kp + c) = o1;
+    *reinterpret_cast<u32x4*>(kp + c + HALF) = o2;
+    *reinterpret_cast<u32x4*>(knew + c) = o1;
+    *reinterpret_cast<u32x4*>(knew + c + HALF) = o2;
+  }
   __syncthreads();
   float mx = -INFINITY;
-  for (int i = t; i < n; i += 256) {
-    const bf16_t* kp = kc + (size_t)(s_begin + i) * ld + h * DH;
+  auto score = [&](auto kp) {                  // kp: global or LDS pointer to one key row of this head
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < DH; c += 8) {
@@ -205,7 +256,16 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
 #pragma unroll
       for (int e = 0; e < 4; ++e) dot += bf_lo(kv[e]) * qs[c + 2 * e] + bf_hi(kv[e]) * qs[c + 2 * e + 1];
     }
+    return dot;
+  };
+  for (int i = t; i < n_old; i += 256) {
+    const float dot = score(kc + (size_t)(s_begin + i) * ld + h * DH);
     sc[i] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  if (has_new && t == (n_old & 255)) {
+    const float dot = score(static_cast<const bf16_t*>(knew));
+    sc[n_old] = dot;
     mx = fmaxf(mx, dot);
   }
   mx = block_max<4>(mx, red);
@@ -231,13 +291,43 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
   part[g * DH + 2 * cp + 1] = a1;
   __syncthreads();
   float* po = part_out + ((size_t)h * NS + j) * (DH + 2);
+  // (agent-scope relaxed atomic stores / loads = write-through, L1-bypassing accesses: the partials cross XCDs without the
+  // L2 write-back + invalidate of a release / acquire fence, which cost ~20 us per layer here)
+  auto st_f = [](float* ptr, float v) {
+    __hip_atomic_store(reinterpret_cast<int*>(ptr), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (t < DH) {
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < G; ++i) acc += part[i * DH + t];
-    po[2 + t] = acc;
+    st_f(po + 2 + t, acc);
   }
-  if (t == 0) { po[0] = n > 0 ? mx : -INFINITY; po[1] = n > 0 ? sum : 0.f; }
+  if (t == 0) { st_f(po, n > 0 ? mx : -INFINITY); st_f(po + 1, n > 0 ? sum : 0.f); }
+  if (cnt == nullptr) return;
+  // fused combine: the last of the head's NS workgroups merges the partials
+  __shared__ int is_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's partial stores have reached the coherence point
+  __syncthreads();
+  if (t == 0) is_last = (__hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1);
+  __syncthreads();
+  if (!is_last) return;
+  if (t < DH) {
+    auto ld_f = [](const float* ptr) {
+      return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    const float* p = part_out + (size_t)h * NS * (DH + 2);
+    float m = -INFINITY;
+    for (int jj = 0; jj < NS; ++jj) m = fmaxf(m, ld_f(p + jj * (DH + 2)));
+    float l = 0.f, o = 0.f;
+    for (int jj = 0; jj < NS; ++jj) {
+      const float mj = ld_f(p + jj * (DH + 2));
+      const float wj = (mj == -INFINITY) ? 0.f : __expf(mj - m);
+      l += ld_f(p + jj * (DH + 2) + 1) * wj;
+      o += ld_f(p + jj * (DH + 2) + 2 + t) * wj;
+    }
+    out[h * DH + t] = f2bf(o / l);
+  }
+  if (t == 0) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DH>
@@ -340,7 +430,8 @@ extern "C" int hvlm_attn_decode(const void* q, const void* k_cache, const void* 
 }
 
 // One whole decode step of the decoder stack, launched from native code (no per-kernel host round trip):
-// 7 launches per layer on the caller's stream.  Pointer tables are HOST arrays of device pointers.
+// 5 launches per layer on the caller's stream.  Pointer tables are HOST arrays of device pointers.  The workspace must be
+// zero-filled once before its first use (combine tickets).
 // pos >= 0: the position is a host value (eager mode).  pos < 0: the position is read on the device from pos_dev[0] by every
 // kernel that needs it (the qkv GEMV's output row, RoPE, the attention length) and advanced by one at the end, so the
 // launch sequence is identical for every token and can be captured once in a hipGraph and replayed (max_S bounds the
@@ -360,6 +451,9 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   bf16_t* xb = xa + D;       // [D]
   bf16_t* gu = xb + D;       // [2F]
   float* apart = reinterpret_cast<float*>(gu + 2 * (size_t)F + 64);   // [H][NS][dh + 2] attention partials
+  int* cnt = reinterpret_cast<int*>(apart + (size_t)128 * 8 * 130);    // [H] tickets of the fused combine (zero at rest)
+  const bool fused = !(getenv("HVLM_DECODE_UNFUSED") && atoi(getenv("HVLM_DECODE_UNFUSED")));   // read per call: the tests toggle it
+  HVLM_REQUIRE(H <= 128, "decode_step: more than 128 heads");
   HVLM_REQUIRE(dh == 64 || dh == 128, "decode_step: dh must be 64 or 128");
   HVLM_REQUIRE(((size_t)F * 2) <= 64 * 1024 && (size_t)D * 2 <= 64 * 1024, "decode_step: D / F too large for the LDS copy of x");
   const float scale = 1.0f / sqrtf((float)dh);
@@ -368,30 +462,39 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   const int S = dev ? max_S : pos + 1;
   HVLM_REQUIRE(S > 0, "decode_step: bad position / max_S");
   const int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);      // key splits: H * NS workgroups
-  const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1) * 4;
+  const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1 + 4) * 4 + (size_t)dh * 2;   // + the new key row
   HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
   const int32_t* pd = dev ? pos_dev : nullptr;
   int rc;
-  // 7 launches per layer: the two RMSNorms and the SwiGLU ride in the prologue of the GEMV that consumes them, attention is
-  // split over the keys (flash-decoding) + a combine pass
+  // 5 launches per layer: the two RMSNorms and the SwiGLU ride in the prologue of the GEMV that consumes them; attention is
+  // split over the keys (flash-decoding) with the new token's RoPE and the combine of the splits fused in
   for (int l = 0; l < L; ++l) {
     bf16_t* kv = reinterpret_cast<bf16_t*>(kv_cache[l]);
     bf16_t* row = dev ? kv : kv + (size_t)pos * cache_ld;
     if ((rc = gemv_pre(w_qkv[l], x, row, nullptr, 3 * D, D, D, 1, ln1[l], eps, stream, pd, cache_ld))) return rc;
-    if (dev) {
-      hipLaunchKernelGGL(rope_decode_kernel, dim3(cdiv(2 * H * (dh / 16), 256)), dim3(256), 0, as_stream(stream), kv,
-                         (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, pos_dev, H, dh, cache_ld);
-    } else if ((rc = hvlm_rope_qk(row, cos_tab, sin_tab, pos_dev, 1, H, dh, cache_ld, 0, stream))) {
-      return rc;
+    // RoPE of the new q / k row and the combine of the key splits are fused into the attention kernel (HVLM_DECODE_UNFUSED=1
+    // keeps them as separate launches: A/B and the parity test)
+    if (!fused) {
+      if (dev) {
+        hipLaunchKernelGGL(rope_decode_kernel, dim3(cdiv(2 * H * (dh / 16), 256)), dim3(256), 0, as_stream(stream), kv,
+                           (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, pos_dev, H, dh, cache_ld);
+      } else if ((rc = hvlm_rope_qk(row, cos_tab, sin_tab, pos_dev, 1, H, dh, cache_ld, 0, stream))) {
+        return rc;
+      }
     }
+    const bf16_t* fc = fused ? (const bf16_t*)cos_tab : nullptr;
+    const bf16_t* fs = fused ? (const bf16_t*)sin_tab : nullptr;
+    int* fcnt = fused ? cnt : nullptr;
     if (dh == 128) {
       hipLaunchKernelGGL((attn_decode_partial_kernel<128>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
-                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd);
-      hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
+      if (!fused)
+        hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
     } else {
       hipLaunchKernelGGL((attn_decode_partial_kernel<64>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
-                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd);
-      hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
+                         (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
+      if (!fused)
+        hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
     }
     if ((rc = check_launch("attn_decode_split"))) return rc;
     if ((rc = gemv_pre(w_o[l], ao, h, x, D, D, D, 0, nullptr, 0.f, stream))) return rc;
@@ -429,6 +532,6 @@ extern "C" int hvlm_llama_decode_step_dev(const void* const* w_qkv, const void* 
 }
 
 extern "C" size_t hvlm_llama_decode_ws_bytes(int D, int F) {
-  // activations (4 D + 2 F bf16) + attention partials (up to 128 heads x 8 splits x 130 floats)
-  return (size_t)(4 * D + 2 * (size_t)F + 64) * 2 + (size_t)128 * 8 * 130 * 4 + 256;
+  // activations (4 D + 2 F bf16) + attention partials (up to 128 heads x 8 splits x 130 floats) + 128 combine tickets
+  return (size_t)(4 * D + 2 * (size_t)F + 64) * 2 + (size_t)128 * 8 * 130 * 4 + 128 * 4 + 256;
 }

@@ -153,7 +153,7 @@ class LlamaStack:
         if self._dec_tables is None or self._dec_tables[0] is not cache:
             arr = lambda ts: (ctypes.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
             lw = lambda k: arr([lp.w[k] for lp in self.layers])  # noqa: E731
-            ws = torch.empty((lib.hvlm_llama_decode_ws_bytes(self.D, self.F),), dtype=torch.uint8, device=self.device)
+            ws = torch.zeros((lib.hvlm_llama_decode_ws_bytes(self.D, self.F),), dtype=torch.uint8, device=self.device)
             self._dec_tables = (cache, lw("qkv"), lw("o"), lw("gu"), lw("down"), lw("ln1"), lw("ln2"), arr(cache), ws,
                                 self._positions(1, self.cfg.max_position_embeddings))
             self._dec_graph = None

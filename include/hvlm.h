@@ -161,7 +161,8 @@ int hvlm_attn_decode(const void* q, const void* k_cache, const void* v_cache, vo
 /* One decode step of the whole decoder stack from native code (replaces LlamaModel.forward for one new token at
  * position `pos`): pointer tables are HOST arrays [L] of DEVICE pointers (fused weights as in hvlm/llama.py;
  * kv_cache[l] is [max_len, cache_ld] in the fused qkv layout, row `pos` is written).  pos_dev points at a device
- * int32 equal to pos.  ws: hvlm_llama_decode_ws_bytes(D, F) bytes.  hidden_out: final-normed hidden [D]. */
+ * int32 equal to pos.  ws: hvlm_llama_decode_ws_bytes(D, F) bytes, ZERO-FILLED once before its first use (it holds the
+ * tickets of the fused attention combine; every step leaves them at zero).  hidden_out: final-normed hidden [D]. */
 size_t hvlm_llama_decode_ws_bytes(int D, int F);
 int hvlm_llama_decode_step(const void* const* w_qkv, const void* const* w_o, const void* const* w_gu,
                            const void* const* w_down, const void* const* ln1, const void* const* ln2,

@@ -208,8 +208,10 @@ def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
     snap = [c.clone() for c in cache]
     xs = [torch.randn(1, D, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(4)]
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("HVLM_DECODE_GRAPH", mode)
+    for mode in ("0", "1", "unfused"):
+        # "unfused": RoPE and the combine of the key splits as separate launches (the fused attention kernel is the default)
+        monkeypatch.setenv("HVLM_DECODE_GRAPH", "0" if mode == "unfused" else mode)
+        monkeypatch.setenv("HVLM_DECODE_UNFUSED", "1" if mode == "unfused" else "0")
         for c, s0 in zip(cache, snap):
             c.copy_(s0)
         hs = [st.decode_step(x1, 20 + i, cache).clone() for i, x1 in enumerate(xs)]
@@ -218,9 +220,11 @@ def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
         hs.append(st.decode_step(xs[2], 21, cache).clone())
         res[mode] = (hs, rows, [c[63].clone() for c in cache])
     assert st._dec_graph is not None
-    for a, b in zip(res["0"][0], res["1"][0]):
-        assert torch.equal(a, b) and torch.isfinite(a.float()).all()
-    for a, b in zip(res["0"][1], res["1"][1]):
-        assert torch.equal(a, b)
+    D3 = 2 * D                                                       # compare the K and V parts of the rows (q is scratch)
+    for other in ("1", "unfused"):
+        for a, b in zip(res["0"][0], res[other][0]):
+            assert torch.equal(a, b) and torch.isfinite(a.float()).all(), other
+        for a, b in zip(res["0"][1], res[other][1]):
+            assert torch.equal(a[:, D:D + D3], b[:, D:D + D3]), other
     for a, s0 in zip(res["1"][2], snap):
         assert torch.equal(a, s0[63])
