@@ -1,4 +1,6 @@
-// bf16 NT GEMM, 8-phase "ping-pong" schedule for gfx950:  C[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.
+// bf16 NT GEMM, "ping-pong" schedule for gfx950:  C[M,N] = act(A[M,K] @ B[N,K]^T + bias) + residual.
+// Two schedules of the same structure: 8 phases per K-tile (described first; used by the K-strided TN instantiation) and
+// 4 segments per K-tile (SEG4, the default for K-contiguous operands: see the comment at `if constexpr (SEG4)`).
 //
 // Same tile geometry and LDS image as gemm.hip (256x256 output tile, BK = 64, 8 waves, 128-B LDS rows with
 // the 16-B chunk permutation c ^ ((row>>1)&7), swapped-operand v_mfma_f32_32x32x16_bf16 so a lane owns one
@@ -22,7 +24,10 @@
 //   * epilogue through a wave-private LDS transpose (16-B row-contiguous stores / residual loads), see `epilogue`;
 //   * tiles are assigned dynamically (per-XCD atomic counters + stealing) when there are >= 3 per workgroup, see PPSched;
 //   * the same body is instantiated for K-strided operands (TN: dW = dY^T X) and for fp8 e4m3 operands on the scaled
-//     MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), see gemm_pp_body.
+//     MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), see gemm_pp_body;
+//   * SEG4: the four 8-MFMA phases become two 16-MFMA segments (output rows of half 0, then half 1, each x both column
+//     fragments), 4 barriers per K-tile instead of 8: MFMA busy 70.5 % -> 78.3 %, cycles -10 %, time -3..4 % (the kernel is
+//     clock/power-limited: profiles/r01p_gemm_pp4_pmc.txt).
 #include "common.h"
 #include "gemm_args.h"
 #include <type_traits>

@@ -161,10 +161,10 @@ class LlamaStack:
 
     def decode_step(self, x1: torch.Tensor, pos: int, cache: List[torch.Tensor]) -> torch.Tensor:
         """One new token (x1 [1, D]) at position `pos` against the KV cache -> final-normed hidden [1, D].
-        HBM-bound (every weight is streamed once by the GEMV kernel).  The 7 launches per layer are issued by one native
+        HBM-bound (every weight is streamed once by the GEMV kernel).  The 5 launches per layer are issued by one native
         call (hvlm_llama_decode_step), asynchronously and far ahead of the GPU.  HVLM_DECODE_GRAPH=1 captures that call ONCE
         in a hipGraph (hvlm_llama_decode_step_dev: the position lives on the device, so the launch sequence is the same for
-        every token) and replays it per token — 226 kernel nodes, one graph launch, bit-identical results.  Measured on
+        every token) and replays it per token — 162 kernel nodes, one graph launch, bit-identical results.  Measured on
         MI355X (tools/decode_bench.py, 7B, cache length 870): 3.11 ms/token either way — the step is bound by the GPU, not by
         launch issue — so the eager loop stays the default and the graph is for hosts whose CPU is the bottleneck."""
         import ctypes
