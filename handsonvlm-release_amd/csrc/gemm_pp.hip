@@ -89,7 +89,7 @@ __device__ PPSched g_pp_all[PP_NSCHED];
 // LDS image, the DMA pieces, the swizzle and the whole 8-phase schedule are unchanged; a fragment is two ds_read_b128
 // (32 k-bytes per lane), 4 MFMAs of 64 cycles per phase instead of 8 of 32.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-template <bool TN, bool FP8, bool SEG4 = false>
+template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   static_assert(!(TN && SEG4), "the 4-segment schedule is for K-contiguous operands");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
@@ -617,13 +617,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         __builtin_amdgcn_sched_barrier(0);
         read_b(sb, T1{}, fb1);
         read_a(sb, T1{}, fa1);
-        if (!(p.dbg & 2)) stage_a(ob, 1, c1);
+        if (!(DBG && (p.dbg & 2))) stage_a(ob, 1, c1);
         HVLM_PHASE_SYNC();
         HVLM_MFMA_OCT(0, fa0, fa1);
         __builtin_amdgcn_s_barrier();
         read_a(sb, T2{}, fa0);
         read_a(sb, T3{}, fa1);
-        if (!(p.dbg & 1)) {
+        if (!(DBG && (p.dbg & 1))) {
           stage_a(cb, 0, c2);
           stage_b(cb, 0, c2);
           stage_b(cb, 1, c2);
@@ -673,7 +673,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       HVLM_PHASE_SYNC();
       HVLM_MFMA_QUAD(0, 2, fb0, fa0, fa1, 15, 15, 15, 15);
       }
-      if (!(p.dbg & 4)) {
+      if (!(DBG && (p.dbg & 4))) {
         c1 = c2;
         advance(c2);
       }
@@ -738,12 +738,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_b
 __global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true, false>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_body<false, false, true>(p); }
+// the same kernel with the K-loop ablation switches of GemmArgs::dbg compiled in (HVLM_GEMM_DBG != 0 only)
+__global__ __launch_bounds__(512, 2) void gemm_pp4_dbg_kernel(GemmArgs p) { gemm_pp_body<false, false, true, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true>(p); }
 
-template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4 = NT bf16, NT fp8 on the 4-segment schedule
+template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4 = NT bf16, NT fp8 on the 4-segment schedule; 5 = 3 + ablation switches
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -754,6 +756,7 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   }
   if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 4) hipLaunchKernelGGL(gemm_pp4_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 5) hipLaunchKernelGGL(gemm_pp4_dbg_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 3) hipLaunchKernelGGL(gemm_pp4_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 2) hipLaunchKernelGGL(gemm_pp_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
@@ -778,6 +781,7 @@ static bool use_seg4() {
   return v;
 }
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
+  if (p.dbg) return launch_pp<5>(p, grid, stream);
   return use_seg4() ? launch_pp<3>(p, grid, stream) : launch_pp<0>(p, grid, stream);
 }
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<1>(p, grid, stream); }
