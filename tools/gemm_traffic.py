@@ -26,20 +26,24 @@ for r in shapes:
             for row in csv.DictReader(open(f)):
                 if "gemm_pp" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                     v.append(float(row["Counter_Value"]))
-        vals[ctr] = sum(v) / len(v) if v else None
+        # per CALL of ops.gemm_nt (3 calls): a tail-split call is two launches of the GEMM kernel, both are summed
+        vals[ctr] = sum(v) / 3.0 if v else None
+        vals["kernels_per_call"] = len(v) / 3.0
         subprocess.run(["rm", "-rf", d])
     if vals["FETCH_SIZE"] is None or vals["WRITE_SIZE"] is None:
         continue
     fetch_b = vals["FETCH_SIZE"] * 1024 * 2      # KB -> B, gfx950: 128-B requests counted as 64 B
     write_b = vals["WRITE_SIZE"] * 1024
     algo = 2.0 * (M * K + N * K + M * N)
-    out.append(dict(M=M, N=N, K=K, launches=r["launches"], fetch_bytes=fetch_b, write_bytes=write_b, algorithmic_bytes=algo))
+    out.append(dict(M=M, N=N, K=K, launches=r["launches"], kernels_per_call=vals["kernels_per_call"], fetch_bytes=fetch_b, write_bytes=write_b,
+                    algorithmic_bytes=algo))
     print(out[-1], flush=True)
 n = sum(o["launches"] for o in out)
 res = dict(per_shape=out,
            mean_traffic_bytes_per_launch=sum(o["launches"] * (o["fetch_bytes"] + o["write_bytes"]) for o in out) / n,
            mean_algorithmic_bytes_per_launch=sum(o["launches"] * o["algorithmic_bytes"] for o in out) / n,
            launches_covered=n, launches_total=sum(r["launches"] for r in shapes),
-           method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/gemm_one.py per shape, FETCH_SIZE x2 (gfx950), launch-weighted")
+           method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on tools/gemm_one.py per shape, per ops.gemm_nt call "
+                  "(all launches of the GEMM kernel in the call summed), FETCH_SIZE x2 (gfx950), call-weighted")
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_traffic.json"), "w"), indent=1)
 print({k: v for k, v in res.items() if k != "per_shape"})
