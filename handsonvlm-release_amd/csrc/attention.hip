@@ -698,6 +698,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
 
   const int nqt = (S + 63) / 64;
   const int qt_begin = CAUSAL ? (k0 / 64) : 0;
+  const int mk_base = CAUSAL ? ki : 0;                                             // see the mask in the loop
+  const unsigned mk_lim = ki < S ? (unsigned)(S - mk_base) : 0u;
   const bf16_t* qbase = qkv + tok0 * ld + h * DH;
   const bf16_t* dobase = dout + tok0 * (long)(H * DH) + h * DH;
   const float* lse_row = lse + ((long)b * H + h) * S;
@@ -753,41 +755,67 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
         const bf16x8 dofr = lds_frag128(smem, sDO + a);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], dp, 0, 0, 0);
       }
-      // dS = P o (dP - delta); the softmax scale is applied once to dK at the end.  The kernel sits at the 256-VGPR
-      // limit: 8 elements in flight at a time, and no second (unmasked) code variant — it spilled.
+      // dS = P o (dP - delta); the softmax scale is applied once to dK at the end.
+      // The Q^T / dO^T fragments (4 transpose reads per d block) are software-pipelined one set ahead of the two MFMAs that
+      // consume them, and the first set of a query half is in flight while its P / dS values are computed: with one wave
+      // per SIMD (dh = 128) nothing else hides the LDS latency.  lse / delta of the 16 query rows are read BEFORE the first
+      // set is issued (a tracked LDS read behind untracked ones would make the compiler drain them).  A second, mask-free
+      // variant of this section for interior tiles (as in the dQ kernel) was tried twice — as a branch and as a second copy
+      // of the tile body: both spill (344 / 560 B of scratch: the accumulators meet at the join) and run 1.8x slower.
+      float lse_r[16], dlt_r[16];
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        float pvals[8], dsvals[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = 8 * sp + j;
-          const int ql = qb * 32 + crow(r, hi);
-          float pj = fast_exp2(__builtin_fmaf(s[r], scale_log2, -s_lse[ql]));
-          {
-            const int q = qq0 + ql;
-            if (q >= S || ki >= S || (CAUSAL && ki > q)) pj = 0.f;
-          }
-          pvals[j] = pj;
-          dsvals[j] = pj * (dp[r] - s_dlt[ql]);
-        }
-        const bf16x8 pf = pack8(pvals);
-        const bf16x8 dsf = pack8(dsvals);
-        // queries (qb*32 + 16*sp) + {4hi + 0..3, 8 + 4hi + 0..3}: the k-slot order of the P / dS registers
-        const unsigned qbytes = (unsigned)(qb * 32 + 16 * sp) * (DH * 2);
-#pragma unroll
-        for (int db = 0; db < DH / 32; ++db) {
-          s16x4_t d0, d1, q0r, q1r;
-          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                       : "=&v"(d0), "=&v"(d1), "=&v"(q0r), "=&v"(q1r)
-                       : "v"(tr_off[db][0] + sDO + qbytes), "v"(tr_off[db][1] + sDO + qbytes), "v"(tr_off[db][0] + sQ + qbytes),
-                         "v"(tr_off[db][1] + sQ + qbytes)
-                       : "memory");
-          const s16x8_t dotv = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-          const s16x8_t qtv = {q0r[0], q0r[1], q0r[2], q0r[3], q1r[0], q1r[1], q1r[2], q1r[3]};
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dotv), pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qtv), dsf, dk[db], 0, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int ql = qb * 32 + crow(r, hi);
+        lse_r[r] = s_lse[ql];
+        dlt_r[r] = s_dlt[ql];
       }
+      asm volatile("" : "+v"(lse_r[0]), "+v"(lse_r[1]), "+v"(lse_r[2]), "+v"(lse_r[3]), "+v"(lse_r[4]), "+v"(lse_r[5]), "+v"(lse_r[6]), "+v"(lse_r[7]), "+v"(lse_r[8]), "+v"(lse_r[9]), "+v"(lse_r[10]), "+v"(lse_r[11]), "+v"(lse_r[12]), "+v"(lse_r[13]), "+v"(lse_r[14]), "+v"(lse_r[15]));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(dlt_r[0]), "+v"(dlt_r[1]), "+v"(dlt_r[2]), "+v"(dlt_r[3]), "+v"(dlt_r[4]), "+v"(dlt_r[5]), "+v"(dlt_r[6]), "+v"(dlt_r[7]), "+v"(dlt_r[8]), "+v"(dlt_r[9]), "+v"(dlt_r[10]), "+v"(dlt_r[11]), "+v"(dlt_r[12]), "+v"(dlt_r[13]), "+v"(dlt_r[14]), "+v"(dlt_r[15]));
+      s16x4_t d0[2], d1[2], q0r[2], q1r[2];
+#define HVLM_DKV_ISSUE(SET, SP, DB)                                                                                    \
+      do {                                                                                                              \
+        const unsigned qbytes_ = (unsigned)(qb * 32 + 16 * (SP)) * (DH * 2);                                           \
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7" \
+                     : "=&v"(d0[SET]), "=&v"(d1[SET]), "=&v"(q0r[SET]), "=&v"(q1r[SET])                                 \
+                     : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_),                         \
+                       "v"(tr_off[DB][0] + sQ + qbytes_), "v"(tr_off[DB][1] + sQ + qbytes_)                            \
+                     : "memory");                                                                                       \
+      } while (0)
+      HVLM_DKV_ISSUE(0, 0, 0);
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int idx = 0; idx < 2 * (DH / 32); ++idx) {
+        const int sp = idx / (DH / 32), db = idx % (DH / 32);
+        if (db == 0) {
+          float pvals[8], dsvals[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int r = 8 * sp + j;
+            const int ql = qb * 32 + crow(r, hi);
+            float pj = fast_exp2(__builtin_fmaf(s[r], scale_log2, -lse_r[r]));
+            // valid iff (causal: ki <= q) && q < S && ki < S  ==  (unsigned)(q - mk_base) < mk_lim : one add + one compare
+            if ((unsigned)(qq0 + ql - mk_base) >= mk_lim) pj = 0.f;
+            pvals[j] = pj;
+            dsvals[j] = pj * (dp[r] - dlt_r[r]);
+          }
+          // queries (qb*32 + 16*sp) + {4hi + 0..3, 8 + 4hi + 0..3}: the k-slot order of the P / dS registers
+          pf = pack8(pvals);
+          dsf = pack8(dsvals);
+        }
+        const int cur = idx & 1;
+        if (idx + 1 < 2 * (DH / 32)) {
+          if (cur == 0) HVLM_DKV_ISSUE(1, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
+          else HVLM_DKV_ISSUE(0, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+        }
+        const s16x8_t dotv = {d0[cur][0], d0[cur][1], d0[cur][2], d0[cur][3], d1[cur][0], d1[cur][1], d1[cur][2], d1[cur][3]};
+        const s16x8_t qtv = {q0r[cur][0], q0r[cur][1], q0r[cur][2], q0r[cur][3], q1r[cur][0], q1r[cur][1], q1r[cur][2], q1r[cur][3]};
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dotv), pf, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qtv), dsf, dk[db], 0, 0, 0);
+      }
+#undef HVLM_DKV_ISSUE
     }
   }
   if (ki < S) {
