@@ -16,7 +16,7 @@ for (M, N, K) in [(13872, 12288, 4096), (13872, 4096, 11008), (4096, 4096, 13888
     for _ in range(3): ops.gemm_nt(a, b, out=out)
     torch.cuda.synchronize()
     row = {}
-    for occ in (0, 8, 16, 32):
+    for occ in (0, 8, 16, 32, 64):
         ts = []
         for rep in range(5):
             torch.cuda.synchronize()
