@@ -482,7 +482,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) >= 8 ? (WM * WN) / 4 : 1) v
 using namespace hvlm;
 
 // development ablations of the ping-pong kernel's K loop (wrong results by construction; timing / PMC only):
-// 1 = no LDS-DMA in load segment B, 2 = none in load segment A, 4 = staging cursors never advance (cache-hot source)
+// 1 = no LDS-DMA in load segment B, 2 = none in load segment A, 4 = staging cursors never advance (cache-hot source),
+// 8 = no fragment reads in load segment B (8 of the 24 ds_read_b128 per K-tile and wave)
 static int gemm_dbg() {
   static const int v = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
   return v;

@@ -621,8 +621,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         HVLM_PHASE_SYNC();
         HVLM_MFMA_OCT(0, fa0, fa1);
         __builtin_amdgcn_s_barrier();
-        read_a(sb, T2{}, fa0);
-        read_a(sb, T3{}, fa1);
+        if (!(DBG && (p.dbg & 8))) {           // dbg 8: a third of the fragment reads gone (stale A fragments of half 0)
+          read_a(sb, T2{}, fa0);
+          read_a(sb, T3{}, fa1);
+        }
         if (!(DBG && (p.dbg & 1))) {
           stage_a(cb, 0, c2);
           stage_b(cb, 0, c2);
