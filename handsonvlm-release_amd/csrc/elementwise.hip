@@ -218,15 +218,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
-// ---- column sums: out[c] += sum_r in[r][c]; grid (cdiv(C,256), slabs), out pre-zeroed -----------
+// ---- column sums: out[c] = sum_r in[r][c].  One workgroup per 64 columns: 32 row groups x 8 lanes x 8 columns (16-byte
+// loads), the row groups combined through LDS in a fixed order -> deterministic (no atomics, no pre-zeroed output). ----
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in,
                                                      float* __restrict__ out, int R, int C,
                                                      int ld_in) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int r = blockIdx.y; r < R; r += gridDim.y) s += bf2f(in[(size_t)r * ld_in + c]);
-  atomicAdd(out + c, s);
+  __shared__ float part[32][65];
+  const int lane8 = threadIdx.x & 7, rg = threadIdx.x >> 3;
+  const int c = blockIdx.x * 64 + lane8 * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c + 7 < C) {
+    for (int r = rg; r < R; r += 32) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(in + (size_t)r * ld_in + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+    }
+  } else {
+    for (int r = rg; r < R; r += 32)
+      for (int e = 0; e < 8; ++e)
+        if (c + e < C) acc[e] += bf2f(in[(size_t)r * ld_in + c + e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[rg][lane8 * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += part[g][threadIdx.x];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+  }
 }
 
 }  // namespace
@@ -297,10 +317,7 @@ extern "C" int hvlm_transpose_bf16(const void* in, void* out, int R, int C, int 
 
 extern "C" int hvlm_colsum_bf16(const void* in, float* out, int R, int C, int ld_in, void* stream) {
   HVLM_REQUIRE(in && out && R > 0 && C > 0 && ld_in >= C, "colsum: bad args");
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * C, as_stream(stream));
-  if (e != hipSuccess) { set_error("colsum: memset: %s", hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
-  int slabs = R < 64 ? R : 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 256), slabs), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)in, out, R, C, ld_in);
+  HVLM_REQUIRE(ld_in % 8 == 0, "colsum: ld_in %% 8");
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64)), dim3(256), 0, as_stream(stream), (const bf16_t*)in, out, R, C, ld_in);
   return check_launch("colsum_bf16");
 }

@@ -63,10 +63,30 @@ __global__ __launch_bounds__(CE_T) void ce_fwd_kernel(const bf16_t* __restrict__
     float mm = red_m[0], ss = red_s[0];
     for (int i = 1; i < CE_T / 64; ++i) ms_merge(mm, ss, red_m[i], red_s[i]);
     const float lse = mm + logf(ss);
-    if (row_lse) row_lse[row] = lse;
-    atomicAdd(loss_sum, lse - bf2f(lr[tgt]));
-    atomicAdd(loss_sum + 1, 1.f);
+    if (row_lse) {
+      row_lse[row] = lse;          // the loss is summed from these in a fixed order by ce_loss_sum_kernel (deterministic)
+    } else {
+      atomicAdd(loss_sum, lse - bf2f(lr[tgt]));
+      atomicAdd(loss_sum + 1, 1.f);
+    }
   }
+}
+
+// loss_sum[0] += sum over valid rows of (lse - logit[target]), loss_sum[1] += their count — ONE workgroup, fixed order:
+// the reported loss is run-to-run bit-identical (fp32 atomics from 13 872 row workgroups are not).
+__global__ __launch_bounds__(1024) void ce_loss_sum_kernel(const bf16_t* __restrict__ logits,
+                                                           const int32_t* __restrict__ targets,
+                                                           const float* __restrict__ row_lse,
+                                                           float* __restrict__ loss_sum, int M, int ldl) {
+  __shared__ float red[16];
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < M; r += 1024) {
+    const int tgt = targets[r];
+    if (tgt >= 0) { s += row_lse[r] - bf2f(logits[(size_t)r * ldl + tgt]); n += 1.f; }
+  }
+  s = block_sum<16>(s, red);
+  n = block_sum<16>(n, red);
+  if (threadIdx.x == 0) { loss_sum[0] += s; loss_sum[1] += n; }
 }
 
 __global__ __launch_bounds__(CE_T) void ce_bwd_kernel(const bf16_t* __restrict__ logits,
@@ -204,6 +224,9 @@ extern "C" int hvlm_ce_fwd(const void* logits, const int32_t* targets, float* lo
   HVLM_REQUIRE(M > 0 && V > 0 && ldl >= V && ldl % 8 == 0, "ce_fwd: bad shape (ldl %% 8)");
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(CE_T), 0, as_stream(stream), (const bf16_t*)logits,
                      targets, loss_sum, row_lse, M, V, ldl);
+  if (row_lse)
+    hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const bf16_t*)logits, targets,
+                       (const float*)row_lse, loss_sum, M, ldl);
   return check_launch("ce_fwd");
 }
 

@@ -325,6 +325,47 @@ extern "C" int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* 
   return check_launch("embed_splice_bwd");
 }
 
+namespace hvlm {
+namespace {
+// Deterministic embedding gradient: one (token, 8-channel chunk) per thread, rows of the segment summed in the fixed,
+// host-sorted order (fp32), written once as bf16.  No atomics: run-to-run bit-identical.
+__global__ __launch_bounds__(256) void embed_grad_segments_kernel(const bf16_t* __restrict__ dx,
+                                                                  const int32_t* __restrict__ seg_rows,
+                                                                  const int32_t* __restrict__ seg_start,
+                                                                  const int32_t* __restrict__ seg_token,
+                                                                  bf16_t* __restrict__ dembed, int n_seg, int D) {
+  const int dv = D / 8;
+  const long total = (long)n_seg * dv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % dv) * 8;
+    const int sg = (int)(i / dv);
+    const int r0 = seg_start[sg], r1 = seg_start[sg + 1];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dx + (long)seg_rows[r] * D + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e], acc[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(dembed + (long)seg_token[sg] * D + c) = o;
+  }
+}
+
+}  // namespace
+}  // namespace hvlm
+
+extern "C" int hvlm_embed_grad_segments(const void* dx, const int32_t* seg_rows, const int32_t* seg_start,
+                                        const int32_t* seg_token, void* dembed, int n_seg, int D, void* stream) {
+  HVLM_REQUIRE(dx && seg_rows && seg_start && seg_token && dembed && n_seg >= 0 && D % 8 == 0, "embed_grad_segments: bad args");
+  if (n_seg == 0) return HVLM_OK;
+  const long total = (long)n_seg * (D / 8);
+  hipLaunchKernelGGL(embed_grad_segments_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)dx, seg_rows, seg_start, seg_token, (bf16_t*)dembed, n_seg, D);
+  return check_launch("embed_grad_segments");
+}
+
 extern "C" int hvlm_hand_gather_fwd(const void* hidden, const int32_t* rows, void* out, int B, int D,
                                     int out_f32, void* stream) {
   HVLM_REQUIRE(hidden && rows && out && B > 0 && D % 2 == 0, "hand_gather_fwd: bad args");

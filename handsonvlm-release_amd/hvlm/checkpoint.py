@@ -102,3 +102,46 @@ def save_pretrained(model, path: str, max_shard_bytes: int = 10 * 2 ** 30):
     sd.update(getattr(model, "_extra_state", {}))
     config_to_json(model.config, path)
     save_state(sd, path, max_shard_bytes)
+
+
+# -- training state (optimizer, schedule position, RNG): what `trainer.train(resume_from_checkpoint=True)` restores in the
+#    reference (handsonvlm/train/train.py:399-402; HF Trainer: optimizer.pt, scheduler.pt, trainer_state.json,
+#    rng_state_{rank}.pth).  The cosine schedule is a pure function of the step, so the step count is its state. ---------
+TRAINER_STATE = "trainer_state.json"
+
+
+def save_training_state(opt, path: str, global_step: int, epoch: int, rank: int = 0, extra: Optional[dict] = None):
+    """Rank 0 writes the optimizer (fp32 master weights, both moments, step count, the CVAE head's torch optimizer) as
+    one file per gradient bucket under `path`/optimizer/ plus trainer_state.json; EVERY rank writes its RNG state."""
+    os.makedirs(os.path.join(path, "optimizer"), exist_ok=True)
+    rng = {"cpu": torch.get_rng_state()}
+    if torch.cuda.is_available():
+        rng["cuda"] = torch.cuda.get_rng_state()
+    torch.save(rng, os.path.join(path, f"rng_state_{rank}.pth"))
+    if rank != 0:
+        return
+    for key, tensors in opt.state_groups():
+        torch.save({n: {k: v.detach().cpu() for k, v in d.items()} for n, d in tensors.items()},
+                   os.path.join(path, "optimizer", key + ".pt"))
+    torch.save(opt.meta_state(), os.path.join(path, "optimizer", "meta.pt"))
+    st = {"global_step": int(global_step), "epoch": int(epoch)}
+    st.update(extra or {})
+    json.dump(st, open(os.path.join(path, TRAINER_STATE), "w"), indent=1)
+
+
+def load_training_state(opt, path: str, rank: int = 0) -> dict:
+    """Restores what save_training_state wrote; returns trainer_state.json's dict.  Raises when the checkpoint has
+    weights but no optimizer state (resuming from it would silently restart Adam) — use opt.reload_from_model() then."""
+    odir = os.path.join(path, "optimizer")
+    if not os.path.isdir(odir) or not os.path.exists(os.path.join(path, TRAINER_STATE)):
+        raise FileNotFoundError(f"{path} holds no optimizer state (weights-only checkpoint): cannot resume training from it")
+    for key in opt.groups:
+        opt.load_group(key, torch.load(os.path.join(odir, key + ".pt"), map_location="cpu", weights_only=True))
+    opt.load_meta_state(torch.load(os.path.join(odir, "meta.pt"), map_location="cpu", weights_only=True))
+    rp = os.path.join(path, f"rng_state_{rank}.pth")
+    if os.path.exists(rp):
+        rng = torch.load(rp, map_location="cpu", weights_only=True)
+        torch.set_rng_state(rng["cpu"])
+        if "cuda" in rng and torch.cuda.is_available():
+            torch.cuda.set_rng_state(rng["cuda"])
+    return json.load(open(os.path.join(path, TRAINER_STATE)))

@@ -27,7 +27,8 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HVLM_DIST_BACKEND=gloo: ranks that share one device (functional checks on a 1-GPU box; RCCL refuses that)
+            backend = os.environ.get("HVLM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -67,6 +67,7 @@ class SplicePlan:
     hand_rows: Optional[torch.Tensor]  # int32 [B*4] rows preceding each <hand_traj> label, -1 if none
     has_hand: Optional[np.ndarray]    # bool [B]
     lengths: np.ndarray
+    seg: Optional[tuple] = None       # (seg_rows, seg_start, seg_token) int32 device tensors: text rows sorted by token id
 
 
 class _EngineLoss(torch.autograd.Function):
@@ -101,7 +102,6 @@ class HandsOnVLMForCausalLM:
         if training:
             self.lm_head_t = torch.zeros(D, Vp, dtype=BF16, device=dev)
             self.embed_g = torch.zeros(V, D, dtype=BF16, device=dev)
-            self.embed_g32 = torch.zeros(V, D, dtype=torch.float32, device=dev)
             self.lm_head_g = torch.zeros(Vp, D, dtype=BF16, device=dev)
             self.proj_w_g = torch.zeros_like(self.proj_w)
             self.proj_b_g = torch.zeros_like(self.proj_b)
@@ -296,7 +296,19 @@ class HandsOnVLMForCausalLM:
                     hr[b] = b * S + pos
                     has_hand[b] = True
             hand_rows = torch.from_numpy(hr.reshape(-1)).to(dev)
-        return SplicePlan(B=B, S=S, src=torch.from_numpy(src.reshape(-1)).to(dev),
+        seg = None
+        if nl is not None and getattr(self, "training", False):
+            # text rows grouped by token id in a FIXED order (stable sort): the embedding gradient is summed segment by
+            # segment without atomics (hvlm_embed_grad_segments), so the step is run-to-run bit-identical
+            flat = src.reshape(-1)
+            rows = np.nonzero(flat >= 0)[0].astype(np.int32)
+            order = np.argsort(flat[rows], kind="stable")
+            rows = rows[order]
+            toks = flat[rows]
+            starts = np.concatenate([[0], np.nonzero(np.diff(toks))[0] + 1, [rows.size]]).astype(np.int32)
+            seg = (torch.from_numpy(rows).to(dev), torch.from_numpy(starts).to(dev),
+                   torch.from_numpy(toks[starts[:-1]].astype(np.int32)).to(dev))
+        return SplicePlan(seg=seg, B=B, S=S, src=torch.from_numpy(src.reshape(-1)).to(dev),
                           hand_slot=torch.from_numpy(slot.reshape(-1)).to(dev),
                           hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets,
@@ -308,6 +320,9 @@ class HandsOnVLMForCausalLM:
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None,
                 image=None, future_hands=None, contact_point=None, future_valid=None, gt_label_valid=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, **kwargs):
+        """handsonvlm.py:70-210.  NOTE on `out.logits` in a training pass: it is a view of the engine's logits buffer,
+        which backward() overwrites IN PLACE with d(loss)/d(logits) (no second [M, 32128] buffer: 0.9 GB at B = 16);
+        read or clone the logits before calling backward, or pass keep_logits=True to get a detached copy."""
         cfg = self.config
         dev = self.device
         B = image.shape[0]
@@ -373,6 +388,8 @@ class HandsOnVLMForCausalLM:
                 loss = _EngineLoss.apply(self._anchor, self, value)
             else:
                 loss = value
+        if training_pass and kwargs.get("keep_logits", False):
+            logits = logits.clone()
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None,
                                      loss_components=comps)
         if return_dict is False:
@@ -412,10 +429,12 @@ class HandsOnVLMForCausalLM:
             self.stack._join_side()              # lm_head's gradient was computed on the side stream
             self.on_grads_ready("head")
         dx = self.stack.backward(dhidden)
-        self.embed_g32.zero_()
-        dvis = torch.empty((B * NV, self.token_dim), dtype=BF16, device=dev)
-        ops.embed_splice_bwd(dx, plan.src, self.embed_g32, dvis, B, S, self.token_dim, NV)
-        ops.cast_f32_to_bf16(self.embed_g32, out=self.embed_g)
+        self.embed_g.zero_()
+        # zeros, not empty: the splice backward only writes the rows of samples that contain an <image> token; a text-only
+        # sample (forward supports it, like handsonvlm.py:234-244) must contribute ZERO projector gradient
+        dvis = torch.zeros((B * NV, self.token_dim), dtype=BF16, device=dev)
+        ops.embed_splice_bwd(dx, plan.src, None, dvis, B, S, self.token_dim, NV)          # visual rows only
+        ops.embed_grad_segments(dx, *plan.seg, self.embed_g)
         sv = self._vis_saved
         if cfg.project_after_pool:
             self.stack._dw(dvis, sv["pooled"], self.proj_w_g, _round_up(B * NV, 64))
@@ -496,7 +515,10 @@ class HandsOnVLMForCausalLM:
         scores = []
         n_new = 0
         use_kv = model_kwargs.get("use_kv_cache", True)
-        cache = self.stack.new_cache(min(cfg.max_position_embeddings, input_ids.shape[1] + vis.shape[1] + 160)) if use_kv else None
+        # cache rows: the spliced prompt (T - 1 + NV) plus every token that can still be generated (max_length counts
+        # ids, like the reference's stopping criterion), capped by the position table like the reference (2048)
+        n_gen = 160 if max_length is None else max(1, max_length - input_ids.shape[1])
+        cache = self.stack.new_cache(min(cfg.max_position_embeddings, input_ids.shape[1] + vis.shape[1] + n_gen)) if use_kv else None
         cur_len = 0
         while True:
             fh = torch.stack(pred_hands, dim=2) if pred_hands else None
@@ -510,7 +532,8 @@ class HandsOnVLMForCausalLM:
                 tok_in = int(input_ids[0, -1])
                 hand_in = pred_hands[-1] if tok_in == HAND_TOKEN_ID and pred_hands else None
                 if cur_len + 1 > cache[0].shape[0]:
-                    raise RuntimeError("KV cache exhausted")
+                    raise RuntimeError(f"sequence exceeds the KV cache ({cache[0].shape[0]} rows = min(max_position_embeddings, "
+                                       "prompt + visual tokens + max_new_tokens)); the reference fails at the same length")
                 logits_last = self._decode(tok_in, hand_in, cur_len, cache)
                 cur_len += 1
             next_scores = logits_last.float()

@@ -384,6 +384,14 @@ def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV):
           "embed_splice_bwd")
 
 
+def embed_grad_segments(dx, seg_rows, seg_start, seg_token, dembed):
+    """Deterministic text-embedding gradient: dembed[seg_token[i]] = sum of dx rows seg_rows[seg_start[i]:seg_start[i+1]]."""
+    _chk(dx, BF16, "embed_grad.dx"); _chk(dembed, BF16, "embed_grad.dembed")
+    assert dx.is_contiguous() and dembed.is_contiguous() and dx.shape[1] == dembed.shape[1]
+    check(_lib.load().hvlm_embed_grad_segments(_p(dx), _p(seg_rows), _p(seg_start), _p(seg_token), _p(dembed),
+                                               seg_token.numel(), dx.shape[1], _stream()), "embed_grad_segments")
+
+
 # ------------------------------------------------------------------------------------------------
 # heads / optimizer
 # ------------------------------------------------------------------------------------------------

@@ -24,7 +24,10 @@ from . import ops
 
 
 def cosine_lr(step: int, total_steps: int, base_lr: float, warmup_ratio: float = 0.03) -> float:
-    """HF `cosine` schedule with linear warm-up (get_cosine_schedule_with_warmup)."""
+    """HF `cosine` schedule with linear warm-up: lr_lambda(step) of transformers.get_cosine_schedule_with_warmup with
+    num_warmup_steps = ceil(total * warmup_ratio) (HF Trainer).  `step` is the number of optimizer steps ALREADY taken
+    (0 for the first update): the HF scheduler is stepped after optimizer.step(), so the first update runs at lr_lambda(0)
+    (= 0 when there is a warm-up) and the last at lr_lambda(total - 1) > 0."""
     warm = math.ceil(total_steps * warmup_ratio)
     if step < warm:
         return base_lr * step / max(1, warm)
@@ -109,3 +112,36 @@ class AdamW:
 
     def memory_bytes(self) -> int:
         return sum(st["master"].numel() * 12 for st in self.state)
+
+    # -- checkpoint / resume (the reference resumes the HF Trainer's optimizer + scheduler state,
+    #    handsonvlm/train/train.py:399-402) ------------------------------------------------------
+    def reload_from_model(self):
+        """Re-derive the fp32 master weights from the model's bf16 tensors (after loading WEIGHTS ONLY into a model this
+        optimizer was already built for; moments and the step count are reset)."""
+        for st in self.state:
+            st["master"].copy_(st["w"].to(torch.float32))
+            st["m"].zero_(); st["v"].zero_()
+        self.step_count = 0
+
+    def state_groups(self):
+        """Yields (bucket key, {tensor name: {"master","m","v"}}) — one checkpoint shard per gradient bucket."""
+        for key, sts in self.groups.items():
+            yield key, {st["name"]: {"master": st["master"], "m": st["m"], "v": st["v"]} for st in sts}
+
+    def meta_state(self) -> dict:
+        return {"step_count": self.step_count, "head": self.head.state_dict()}
+
+    def load_group(self, key: str, tensors: dict):
+        for st in self.groups[key]:
+            src = tensors[st["name"]]
+            for k in ("master", "m", "v"):
+                st[k].copy_(src[k].to(st[k].device))
+            # the bf16 working copy (and its transposed copy) always follow the fp32 master
+            st["w"].copy_(st["master"].to(st["w"].dtype).view_as(st["w"]))
+            if st["wt"] is not None:
+                ops.transpose(st["w"], out=st["wt"])
+
+    def load_meta_state(self, meta: dict):
+        self.step_count = int(meta["step_count"])
+        self.head.load_state_dict(meta["head"])
+        self._open, self._done = None, set()

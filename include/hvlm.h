@@ -225,6 +225,15 @@ int hvlm_embed_splice_fwd(const void* embed, const void* visual, const int32_t* 
 int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* dembed, void* dvisual, int B,
                           int S, int D, int NV, void* stream);
 
+/* Deterministic form of the text-embedding gradient (the `embed_tokens` rows of the splice backward): the host sorts
+ * the text rows of the batch by token id (stable) into segments — seg_token[n_seg] the distinct ids, seg_start[n_seg+1]
+ * offsets into seg_rows[], seg_rows[] the row indices into dx [B*S, D] — and every segment is summed in that fixed order in
+ * fp32 and written ONCE as bf16 into dembed [V, D] (rows of tokens that do not occur are left untouched: the caller zeroes
+ * dembed).  No atomics: the SFT step is run-to-run bit-identical (hvlm_embed_splice_bwd with dembed = NULL then only
+ * scatters the visual rows).  Reference: autograd of nn.Embedding at handsonvlm.py:245-300. */
+int hvlm_embed_grad_segments(const void* dx, const int32_t* seg_rows, const int32_t* seg_start,
+                             const int32_t* seg_token, void* dembed, int n_seg, int D, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Heads
  * ------------------------------------------------------------------------------------------ */

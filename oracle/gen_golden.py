@@ -275,3 +275,45 @@ if __name__ == "__main__":
     if "g5" in which: g5_cvae()
     if "g4" in which: g4_ops()
     if "g23" in which: g2_g3(synth.TINY)
+
+
+def g3_bf16(cfg):
+    """The bf16-EAGER envelope of G3: the same reference model and batch as g2_g3, but run the way the reference trains
+    (`--bf16 True`, scripts/finetune.sh:15): every LLM / projector / head module in bfloat16, the CLIP tower in float16
+    (handsonvlm/train/train.py:316), PyTorch eager kernels with their own fp32 accumulation.  Its distance from the fp32
+    golden (g3_forward.npz) is the rounding noise a bf16 implementation of this path is EXPECTED to have; the GPU tests
+    bound the HIP path's distance from the fp32 golden by a small multiple of it (tests/test_gpu_model.py)."""
+    model = build_reference_model(cfg)
+    model.train()
+    model.to(torch.bfloat16)
+    model.model.vision_tower[0].to(torch.float16)
+    B, T = 2, 24
+    ids, labels, mask = synth.make_text_batch(B, T, seed=3, n_hand=(4, 0), pad_tail=(0, 5))
+    images = synth.make_images(B, cfg["frames"], 10, cfg["image"], seed=11).to(torch.bfloat16)
+    fh, fv = synth.make_hands(B, seed=5)
+    # the SAME CVAE noise as G3 (randn_like on a bf16 tensor would draw a different stream): the fp32 draw, cast
+    torch.manual_seed(123)
+    eps_noise = torch.randn(B * 8, 256)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **k: eps_noise.to(t.dtype) if tuple(t.shape) == tuple(eps_noise.shape) else real(t, **k)
+    try:
+        out = model(input_ids=ids, attention_mask=mask, labels=labels, image=images, future_hands=fh.clone().to(torch.bfloat16),
+                    contact_point=torch.zeros(B, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(B),
+                    output_hidden_states=True, return_dict=True)
+    finally:
+        torch.randn_like = real
+    out.loss.backward()
+    sd = dict(model.named_parameters())
+    f = lambda t: t.detach().float()  # noqa: E731
+    save("g3_bf16.npz", loss=f(out.loss), logits_slice=f(out.logits[:, ::7, ::251]), hidden=f(out.hidden_states[-1]),
+         g_proj_w=f(sd["model.mm_projector.weight"].grad), g_proj_b=f(sd["model.mm_projector.bias"].grad),
+         g_q0=f(sd["model.layers.0.self_attn.q_proj.weight"].grad),
+         g_down1=f(sd["model.layers.1.mlp.down_proj.weight"].grad),
+         g_ln0=f(sd["model.layers.0.input_layernorm.weight"].grad), g_norm=f(sd["model.norm.weight"].grad),
+         g_embed_hand=f(sd["model.embed_tokens.weight"].grad[32100]),
+         g_embed_rows=f(sd["model.embed_tokens.weight"].grad[ids[0, :5].clamp(min=0)]),
+         g_lm_head_rows=f(sd["lm_head.weight"].grad[::1601]))
+
+
+if __name__ == "__main__" and "g3bf16" in sys.argv[1:]:
+    g3_bf16(synth.TINY)

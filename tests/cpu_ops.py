@@ -1,0 +1,346 @@
+"""TEST INFRASTRUCTURE ONLY — a CPU stand-in for `hvlm.ops` so that the HOST logic of the engine (LlamaStack forward /
+backward order, activation recompute, the splice plan, hvlm.dp hooks, hvlm.optim buckets, checkpoint / resume) can be
+driven without a GPU, including at world size 2 over gloo.
+
+`install(monkeypatch)` replaces the attributes of the `hvlm.ops` module with the functions below for the duration of one
+test.  Each function restates the documented semantics of the entry point of include/hvlm.h it stands in for (same
+argument meaning, same output layout, bf16 rounding at the same places) in plain PyTorch; the product package never
+imports this file and has no CPU path of its own (tests/test_abi_and_host.py checks that the real ops raise without a GPU).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_QUICK_GELU = 0, 1
+
+
+def _act(y, act):
+    return y * torch.sigmoid(1.702 * y) if act == ACT_QUICK_GELU else y
+
+
+def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=BF16):
+    y = a.float() @ b.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    y = _act(y, act)
+    if residual is not None:
+        y = y + residual.float()
+    y = y.to(out_dtype if out is None else out.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=BF16):
+    return gemm_nt(a.t() if trans_a else a, b.t() if trans_b else b, bias, residual, act, out, out_dtype)
+
+
+def transpose(x, r_pad=None, out=None):
+    R, C = x.shape
+    r_pad = R if r_pad is None else r_pad
+    if out is None:
+        out = torch.zeros((C, r_pad), dtype=BF16)
+    out.zero_()
+    out[:, :R] = x.t()
+    return out
+
+
+def colsum(x):
+    return x.float().sum(0)
+
+
+def rmsnorm_fwd(x, w, eps, save_rstd=True, out=None):
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1) + eps)
+    y = ((xf * rstd[..., None]).to(BF16).float() * w.float()).to(BF16)
+    if out is not None:
+        out.copy_(y)
+        y = out
+    return y, (rstd.reshape(-1) if save_rstd else None)
+
+
+def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None):
+    D = x.shape[-1]
+    xf, dyf = x.float().reshape(-1, D), dy.float().reshape(-1, D)
+    xhat = xf * rstd[:, None]
+    g = dyf * w.float()
+    dx = rstd[:, None] * (g - xhat * (g * xhat).mean(-1, keepdim=True))
+    if add is not None:
+        dx = dx + add.float().reshape(-1, D)
+    dw = (dyf * xhat).sum(0).to(BF16)
+    dx = dx.to(BF16).view_as(x)
+    if out is not None:
+        out.copy_(dx)
+        dx = out
+    return dx, dw
+
+
+def layernorm_fwd(x, w, b, eps, out=None):
+    y = F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(BF16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def _rope(t, cos, sin, pos, H, dh, inverse):
+    M = t.shape[0]
+    x = t.float().view(M, H, dh)
+    c = cos.float()[pos.long()][:, None, :]
+    s = sin.float()[pos.long()][:, None, :]
+    if inverse:
+        s = -s
+    x1, x2 = x[..., : dh // 2], x[..., dh // 2:]
+    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1).reshape(M, H * dh).to(BF16)
+
+
+def rope_qk_(qkv, cos, sin, pos, H, dh, inverse=False):
+    D = H * dh
+    qkv[:, :D] = _rope(qkv[:, :D], cos, sin, pos, H, dh, inverse)
+    qkv[:, D:2 * D] = _rope(qkv[:, D:2 * D], cos, sin, pos, H, dh, inverse)
+    return qkv
+
+
+def _split(qkv, B, S, H, dh):
+    D = H * dh
+    f = lambda t: t.float().reshape(B, S, H, dh).permute(0, 2, 1, 3)  # noqa: E731
+    return f(qkv[:, :D]), f(qkv[:, D:2 * D]), f(qkv[:, 2 * D:3 * D])
+
+
+def _scores(q, k, causal, scale, seqlens=None):
+    s = (q @ k.transpose(-1, -2)) * scale
+    S = q.shape[-2]
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    return s
+
+
+def attn_fwd(qkv, B, S, H, dh, causal, scale, need_lse=True, out=None):
+    q, k, v = _split(qkv, B, S, H, dh)
+    s = _scores(q, k, causal, scale)
+    lse = torch.logsumexp(s, -1)
+    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * dh).to(BF16)
+    if out is not None:
+        out.copy_(o)
+        o = out
+    return o, (lse.contiguous() if need_lse else None)
+
+
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None):
+    with torch.enable_grad():
+        x = qkv.float().detach().requires_grad_(True)
+        q, k, v = _split(x, B, S, H, dh)
+        o = (torch.softmax(_scores(q, k, causal, scale), -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * dh)
+        (g,) = torch.autograd.grad(o, x, dout.float())
+    g = g.to(BF16)
+    if dqkv is not None:
+        dqkv.copy_(g)
+        return dqkv
+    return g
+
+
+def swiglu_fwd(gu, out=None):
+    Fh = gu.shape[1] // 2
+    y = (F.silu(gu[:, :Fh].float()) * gu[:, Fh:].float()).to(BF16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def swiglu_bwd(gu, dact, out=None):
+    Fh = gu.shape[1] // 2
+    g, u, d = gu[:, :Fh].float(), gu[:, Fh:].float(), dact.float()
+    sg = torch.sigmoid(g)
+    dg = d * u * (sg * (1 + g * (1 - sg)))
+    du = d * g * sg
+    y = torch.cat([dg, du], 1).to(BF16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def patch_im2col(images, P, kpad):
+    N, _, HW, _ = images.shape
+    G = HW // P
+    x = images.reshape(N, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(N * G * G, 3 * P * P)
+    out = torch.zeros((N * G * G, kpad), dtype=BF16)
+    out[:, : 3 * P * P] = x
+    return out
+
+
+def clip_embed(patch_out, cls, pos, N, NP, D):
+    tok = torch.empty((N, NP + 1, D), dtype=torch.float32)
+    tok[:, 0] = cls.float() + pos[0].float()
+    tok[:, 1:] = patch_out.float().view(N, NP, D) + pos[1:].float()
+    return tok.to(BF16)
+
+
+def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16):
+    D = tokens.shape[-1]
+    G = grid
+    t = tokens.float().reshape(B, T, -1, D)
+    if drop_cls:
+        t = t[:, :, 1:]
+    sel = np.round(np.linspace(0, T - 1, 4)).astype(int)
+    s = t[:, sel].reshape(B * 4, G, G, D).permute(0, 3, 1, 2)
+    s = F.avg_pool2d(s, 2).permute(0, 2, 3, 1).reshape(B, G * G, D)
+    return torch.cat([t.mean(2), s], 1).to(BF16)
+
+
+def temporal_spatial_pool_bwd(dout, B, T, grid=16):
+    D = dout.shape[-1]
+    with torch.enable_grad():
+        x = torch.zeros(B, T, grid * grid, D, requires_grad=True)
+        t = x
+        sel = np.round(np.linspace(0, T - 1, 4)).astype(int)
+        s = t[:, sel].reshape(B * 4, grid, grid, D).permute(0, 3, 1, 2)
+        s = F.avg_pool2d(s, 2).permute(0, 2, 3, 1).reshape(B, grid * grid, D)
+        y = torch.cat([t.mean(2), s], 1)
+        (g,) = torch.autograd.grad(y, x, dout.float().reshape(B, T + grid * grid, D))
+    return g.to(BF16)
+
+
+def _hand_posenc(hands_b, slot, D):
+    """hands_b f32 [2, NH, 2] -> encoding [D] of slot (even channel = hand 0), handsonvlm.py:310-338."""
+    ch = D // 4
+    inv = torch.exp(torch.arange(0, ch, 2, dtype=torch.float32) * (-math.log(10000.0) / ch))
+    enc = []
+    for hand in range(2):
+        x, y = hands_b[hand, slot, 0], hands_b[hand, slot, 1]
+        enc.append(torch.cat([(x * inv).sin(), (y * inv).cos(), (x * inv).sin(), (y * inv).cos()]))
+    return torch.stack(enc, 1).reshape(D)
+
+
+def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None):
+    x = torch.zeros((B * S, D), dtype=torch.float32)
+    srcl = src.long()
+    for r in range(B * S):
+        b, s = divmod(r, S)
+        i = int(srcl[r])
+        if i >= 0:
+            x[r] = embed[i].float()
+        elif i <= -2:
+            x[r] = visual.reshape(B, NV, D)[b, -2 - i].float()
+        if hand_slot is not None and int(hand_slot[r]) >= 0:
+            x[r] += float(hand_scale[b]) * _hand_posenc(hands[b], int(hand_slot[r]), D)
+    x = x.to(BF16)
+    if out is not None:
+        out.copy_(x)
+        return out
+    return x
+
+
+def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV):
+    srcl = src.long()
+    for r in range(B * S):
+        b = r // S
+        i = int(srcl[r])
+        if i >= 0 and dembed is not None:
+            dembed[i] += dx[r].float()
+        elif i <= -2 and dvisual is not None:
+            dvisual.view(B, NV, D)[b, -2 - i] = dx[r]
+
+
+def embed_grad_segments(dx, seg_rows, seg_start, seg_token, dembed):
+    for i in range(seg_token.numel()):
+        acc = torch.zeros(dx.shape[1])
+        for r in seg_rows[int(seg_start[i]):int(seg_start[i + 1])].tolist():
+            acc += dx[r].float()
+        dembed[int(seg_token[i])] = acc.to(BF16)
+
+
+def ce_fwd(logits, targets, V):
+    M = logits.shape[0]
+    lg = logits[:, :V].float()
+    row_lse = torch.logsumexp(lg, -1)
+    valid = targets >= 0
+    t = targets.long().clamp(min=0)
+    nll = (row_lse - lg.gather(1, t[:, None]).squeeze(1)) * valid
+    return torch.stack([nll.sum(), valid.sum().float()]), row_lse
+
+
+def ce_bwd_(logits, targets, row_lse, grad_scale, V):
+    lg = logits[:, :V].float()
+    p = torch.exp(lg - row_lse[:, None])
+    valid = targets >= 0
+    p[torch.arange(lg.shape[0])[valid], targets.long()[valid]] -= 1.0
+    p = p * valid[:, None] * grad_scale.reshape(())
+    logits.zero_()
+    logits[:, :V] = p.to(BF16)
+    return logits
+
+
+def hand_gather_fwd(hidden, rows, B, D, out_dtype=torch.float32):
+    out = torch.zeros((B, 2, 4, D // 2), dtype=out_dtype)
+    for b in range(B):
+        for j in range(4):
+            r = int(rows[b * 4 + j])
+            if r >= 0:
+                out[b, :, j] = hidden[r].to(out_dtype).reshape(D // 2, 2).t()
+    return out
+
+
+def hand_gather_bwd_(dout, rows, dhidden, B, D):
+    for b in range(B):
+        for j in range(4):
+            r = int(rows[b * 4 + j])
+            if r >= 0:
+                dhidden[r] = (dhidden[r].float() + dout[b, :, j].float().t().reshape(D)).to(BF16)
+    return dhidden
+
+
+def adamw_step_(master, m, v, grad, w, wt, lr, beta1, beta2, eps, wd, grad_scale, step):
+    g = grad.float().reshape(master.shape) * grad_scale
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    mh = m / (1 - beta1 ** step)
+    vh = v / (1 - beta2 ** step)
+    master.mul_(1 - lr * wd).sub_(lr * mh / (vh.sqrt() + eps))
+    w.copy_(master.to(BF16).view_as(w))
+    if wt is not None:
+        wt.copy_(w.t())
+
+
+def add(a, b, out=None):
+    y = (a.float() + b.float()).to(BF16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def cast_f32_to_bf16(x, out=None):
+    if out is not None:
+        out.copy_(x.to(BF16))
+        return out
+    return x.to(BF16)
+
+
+def set_gemm_hook(hook):
+    pass
+
+
+_NAMES = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("install",)
+          and getattr(f, "__module__", None) == __name__]
+
+
+def install(monkeypatch):
+    """Replace hvlm.ops's kernel wrappers by the stand-ins above (undone by pytest at the end of the test)."""
+    from hvlm import ops
+    for n in _NAMES:
+        monkeypatch.setattr(ops, n, globals()[n], raising=False)
+
+
+def install_permanent():
+    """For spawned worker processes (no monkeypatch fixture there)."""
+    from hvlm import ops
+    for n in _NAMES:
+        setattr(ops, n, globals()[n])

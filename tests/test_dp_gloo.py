@@ -79,3 +79,114 @@ def test_single_process_is_a_noop():
     b.reduce_async(t)
     b.wait()
     assert b.world == 1 and torch.equal(t, torch.ones(4))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL engine at world size 2: hvlm.model.HandsOnVLMForCausalLM.forward/backward (LlamaStack.backward's
+# on_layer_grad_ready order, the 'head' / 'tail' hooks), hvlm.dp.attach and hvlm.optim.AdamW, with the HIP kernels replaced
+# by the CPU stand-in of tests/cpu_ops.py (test infrastructure; the product has no CPU path).  Reference recipe:
+# scripts/finetune.sh:6,20 (one process per GPU, per-device batch) + DeepSpeed's gradient averaging:
+# N-rank all-reduced gradients x 1/N == mean of the N single-rank gradients, and the weights after AdamW follow.
+# ---------------------------------------------------------------------------------------------------------------------
+def _tiny_model_and_batch(rank):
+    import cpu_ops
+    cpu_ops.install_permanent()
+    from oracle import synth
+    from hvlm.config import CLIPVisionConfig, HandsOnVLMConfig
+    from hvlm.model import HandsOnVLMForCausalLM
+    c = synth.TINY
+    cfg = HandsOnVLMConfig(hidden_size=c["D"], intermediate_size=c["FFN"], num_hidden_layers=c["L"], num_attention_heads=c["H"],
+                           mm_hidden_size=c["clip_d"],
+                           vision=CLIPVisionConfig(hidden_size=c["clip_d"], intermediate_size=c["clip_mlp"],
+                                                   num_hidden_layers=c["clip_layers"], num_attention_heads=c["clip_heads"]))
+    model = HandsOnVLMForCausalLM(cfg, device="cpu", training=True)
+    sd = dict(synth.to_torch(synth.llama_params(c)))
+    sd.update({"model.vision_tower.vision_tower." + k: v for k, v in synth.to_torch(synth.clip_params(c)).items()})
+    model.load_state_dict(sd)
+    ids, labels, mask = synth.make_text_batch(2, 20 + 4 * rank, seed=3 + rank, n_hand=(4, 4))
+    images = synth.make_images(2, c["frames"], 2, c["image"], seed=11 + rank)
+    fh, fv = synth.make_hands(2, seed=5 + rank)
+    eps = torch.randn(16, 256, generator=torch.Generator().manual_seed(rank))
+    batch = dict(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh,
+                 contact_point=torch.zeros(2, 2), future_valid=fv, gt_label_valid=torch.ones(2), cvae_eps=eps)
+    return model, batch
+
+
+def _grads(model):
+    g = {n: gr.clone() for n, _, gr, _ in model.trainable_tensors()}
+    g.update({"head." + n: p.grad.clone() for n, p in model.hand_traj_decoder.named_parameters()})
+    return g
+
+
+def _weights(model):
+    w = {n: wt.clone() for n, wt, _, _ in model.trainable_tensors()}
+    w.update({"head." + n: p.detach().clone() for n, p in model.hand_traj_decoder.named_parameters()})
+    return w
+
+
+def _engine_worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "handsonvlm-release_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from hvlm import dp
+    from hvlm.optim import AdamW
+    dp.init_from_env(backend="gloo")
+    model, batch = _tiny_model_and_batch(rank)
+    opt = AdamW(model, lr=1e-2)
+    buckets = dp.attach(model, dp.GradBuckets(), opt)
+    order = []
+    inner_layer, inner_named = model.stack.on_layer_grad_ready, model.on_grads_ready
+    model.stack.on_layer_grad_ready = lambda i: (order.append(f"layers.{i}"), inner_layer(i))
+    model.on_grads_ready = lambda w: (order.append(w), inner_named(w))
+    out = model(**batch)
+    opt.begin_step(grad_scale=1.0 / world)
+    model.backward()
+    buckets.wait()
+    summed = _grads(model)
+    opt.step()
+    ret[rank] = dict(order=order, grads={k: v.float().numpy() for k, v in summed.items()},
+                     weights={k: v.float().numpy() for k, v in _weights(model).items()}, loss=float(out.loss.detach()))
+    dist.destroy_process_group()
+
+
+def test_dp_world2_real_engine_equals_mean_of_single_rank_grads():
+    import numpy as np
+    for p in (ROOT, os.path.join(ROOT, "handsonvlm-release_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 30100 + (os.getpid() % 500)
+    mp.spawn(_engine_worker, args=(2, port, ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    L = 2
+    want_order = ["head"] + [f"layers.{i}" for i in range(L - 1, -1, -1)] + ["tail"]
+    assert r0["order"] == want_order and r1["order"] == want_order
+    # single-rank gradients of the two minibatches, in this process
+    from hvlm.optim import AdamW
+    single = []
+    for rank in (0, 1):
+        model, batch = _tiny_model_and_batch(rank)
+        out = model(**batch)
+        model.backward()
+        single.append(_grads(model))
+        assert abs(float(out.loss.detach()) - ret[rank]["loss"]) < 1e-6
+    for k in single[0]:
+        want = single[0][k].float() + single[1][k].float()
+        got0, got1 = torch.from_numpy(r0["grads"][k]), torch.from_numpy(r1["grads"][k])
+        assert torch.equal(got0, got1), k                                    # both ranks hold the same reduced bucket
+        tol = 2.0 ** -7 * want.abs().max().clamp(min=1e-30)                   # one bf16 rounding of the sum
+        assert (got0 - want).abs().max() <= tol, (k, float((got0 - want).abs().max()), float(tol))
+    # weights: AdamW(grad_scale = 1/2) on the reduced buckets == the same update applied in one process
+    model, _ = _tiny_model_and_batch(0)
+    opt = AdamW(model, lr=1e-2)
+    for n, _, g, _ in model.trainable_tensors():
+        g.copy_(torch.from_numpy(r0["grads"][n]).view_as(g))
+    for n, p in model.hand_traj_decoder.named_parameters():
+        p.grad = torch.from_numpy(np.array(r0["grads"]["head." + n])).clone()
+    opt.step(grad_scale=0.5)
+    for k, w in _weights(model).items():
+        assert torch.equal(w.float(), torch.from_numpy(r0["weights"][k])), k
+        assert np.array_equal(r0["weights"][k], r1["weights"][k]), k

@@ -79,13 +79,52 @@ def test_forward_backward_vs_reference_golden(golden, project_after_pool):
     r["g_cvae_dec2"] = rel(hp["hand_traj_decoder.cvae.dec_MLP.2.weight"].grad, g3["g_cvae_dec2"])
     REPORT[f"g3_pap{int(project_after_pool)}"] = r
     print(json.dumps(r, indent=1))
-    # bf16 end-to-end bounds (fp32 reference): loss within 1e-2 relative; activations / gradients within
-    # 3e-2 relative L2 (bf16 has 8 mantissa bits; 3 CLIP + 2 decoder layers of bf16 rounding).
-    assert abs(r["loss"] - r["loss_ref"]) / r["loss_ref"] < 1e-2
-    assert r["hidden_rel"] < 3e-2 and r["logits_rel"] < 3e-2
+    # Parity statement (north_star: <= 1e-3 rel in bf16 — reachable per op, tests/test_gpu_ops.py; end to end the yardstick is
+    # what bf16 itself costs on this path): g3_bf16.npz is the REFERENCE run bf16-eager (LLM bf16, tower fp16, as it trains;
+    # oracle/gen_golden.py::g3_bf16) on the same inputs; its distance from the fp32 golden is the envelope.  The HIP path
+    # must sit within 1.25x of that envelope per tensor, and under absolute caps at 1.5x the round-1 measurements.
+    env = golden("g3_bf16.npz")
+    envelope = {"hidden_rel": rel(T(env["hidden"])[valid], g3["hidden"][valid.numpy()]),
+                "logits_rel": rel(T(env["logits_slice"])[valid[:, ::7]], g3["logits_slice"][valid[:, ::7].numpy()])}
+    for k in ("g_proj_w", "g_proj_b", "g_q0", "g_down1", "g_ln0", "g_norm", "g_embed_hand", "g_embed_rows", "g_lm_head_rows"):
+        envelope[k] = rel(T(env[k]), g3[k])
+    r["bf16_eager_reference_envelope"] = envelope
+    REPORT[f"g3_pap{int(project_after_pool)}"] = r
+    assert abs(r["loss"] - r["loss_ref"]) / r["loss_ref"] < 2e-3           # bf16-eager reference: 6.3e-3
+    for k, e in envelope.items():
+        assert r[k] <= 1.25 * e, (k, r[k], e)
+    assert r["hidden_rel"] < 1.3e-2 and r["logits_rel"] < 1.5e-2
     for k in ("g_proj_w", "g_proj_b", "g_q0", "g_down1", "g_ln0", "g_norm", "g_embed_hand", "g_embed_rows",
               "g_lm_head_rows", "g_cvae_enc", "g_cvae_dec2"):
-        assert r[k] < 5e-2, (k, r[k])
+        assert r[k] < 3e-2, (k, r[k])
+
+
+def test_mixed_text_only_batch_backward_vs_oracle():
+    """A text-only sample (no <image> token; handsonvlm.py:234-244) next to an image sample: its visual-token gradient
+    rows are zero, so the projector gradient is that of the image sample alone — checked against the oracle's autograd on
+    the same batch, with the allocator's free memory poisoned with NaNs first."""
+    m, cfg = tiny_model()
+    c = synth.TINY
+    ids, labels, mask = synth.make_text_batch(2, 24, seed=3, n_hand=(4, 4))
+    ids[1][ids[1] == -200] = 7
+    images = synth.make_images(2, c["frames"], 10, c["image"], seed=11)
+    fh, fv = synth.make_hands(2, seed=5)
+    eps = torch.randn(16, 256, generator=torch.Generator().manual_seed(2))
+    poison = torch.full((64 << 20,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    del poison                                                         # back to the caching allocator, bits intact
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh.clone(),
+            contact_point=torch.zeros(2, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(2), cvae_eps=eps.cuda())
+    out.loss.backward()
+    named = {n: g for n, w, g, wt in m.trainable_tensors()}
+    p = {k: v.clone().requires_grad_(True) for k, v in synth.to_torch(synth.llama_params(c)).items()}
+    cp = synth.to_torch(synth.clip_params(c))
+    vis = R.visual_tokens(images, cp, c["clip_layers"], c["clip_heads"], p["model.mm_projector.weight"], p["model.mm_projector.bias"])
+    ref = R.forward_loss(p, dict(n_layers=c["L"], n_heads=c["H"], cond_dtype=torch.bfloat16), ids, labels, mask, vis, fh, fv, eps)
+    ref["loss"].backward()
+    assert abs(float(out.loss) - float(ref["loss"])) / float(ref["loss"]) < 1e-2
+    for ours, theirs in (("proj_w", "model.mm_projector.weight"), ("proj_b", "model.mm_projector.bias")):
+        assert torch.isfinite(named[ours].float()).all()
+        assert rel(named[ours], p[theirs].grad) < 3e-2, (ours, rel(named[ours], p[theirs].grad))
 
 
 @pytest.mark.parametrize("use_kv_cache", [True, False])

@@ -49,21 +49,60 @@ def test_dedup_exact_on_epic_tiling():
 
 
 def test_train_loop_and_resume(tmp_path):
+    """hvlm.train.train on the real kernels: (1) a fixed batch is learnt; (2) auto-resume (handsonvlm/train/train.py:399-402)
+    restores weights, fp32 masters / moments / step count, the CVAE head's optimizer, the schedule position, the data
+    order and the RNG: an interrupted-and-resumed run ends with BIT-identical weights and optimizer state (the step has no
+    atomics: embedding gradient by sorted segments, column sums and the CE loss in fixed order)."""
+    import os
     from hvlm.data import SyntheticEpicDataset
     from hvlm.train import train
     torch.manual_seed(0); torch.cuda.manual_seed_all(0)                          # the CVAE noise of every step
     m, cfg = tiny(training=True)
     m.config.dedup_frames = True
     ds = SyntheticEpicDataset(2, min_len=50, max_len=60)                        # the same two samples every step
-    log = train(m, ds, output_dir=str(tmp_path), per_device_batch=2, epochs=1, max_steps=8, lr=3e-4, log_every=1,
-                warmup_ratio=0.0)
+    log = train(m, ds, output_dir=str(tmp_path / "fixed"), per_device_batch=2, epochs=1, max_steps=8, lr=3e-4, log_every=1,
+                warmup_ratio=0.0, save_every_epoch=False)
     assert len(log) == 8 and all(np.isfinite(r["loss"]) for r in log)
     tl = [r["text loss"] for r in log]
     # fixed batch: CE falls; the trunk also receives the CVAE head's gradient (fresh noise every step), so one of the
     # seven transitions may go the other way (seen once in ten unseeded runs)
     assert sum(b < a for a, b in zip(tl, tl[1:])) >= 6 and tl[-1] < tl[0] - 0.1
-    import os
-    assert any(d.startswith("checkpoint-") for d in os.listdir(tmp_path))
+    assert os.path.isdir(tmp_path / "fixed" / "checkpoint-8" / "optimizer")
+
+    ds6 = SyntheticEpicDataset(6, min_len=50, max_len=60)                       # 3 batches per epoch: mid-epoch interruption
+    kw = dict(per_device_batch=2, epochs=1, max_steps=8, lr=3e-3, log_every=1, warmup_ratio=0.25, save_every_epoch=False,
+              save_steps=4, seed=5)
+
+    def snapshot(model, d):
+        w = {n: t.clone() for n, t, _, _ in model.trainable_tensors()}
+        w.update({"wt." + n: t.clone() for n, _, _, t in model.trainable_tensors() if t is not None})
+        o = {f: torch.load(os.path.join(d, f), map_location="cpu", weights_only=True) for f in sorted(os.listdir(d))}
+        return w, o
+
+    torch.manual_seed(1); torch.cuda.manual_seed_all(1)
+    ma, _ = tiny(training=True); ma.config.dedup_frames = True
+    full = train(ma, ds6, output_dir=str(tmp_path / "a"), **kw)
+    wa, oa = snapshot(ma, str(tmp_path / "a" / "checkpoint-8" / "optimizer"))
+    torch.manual_seed(1); torch.cuda.manual_seed_all(1)
+    mb, _ = tiny(training=True); mb.config.dedup_frames = True
+    part = train(mb, ds6, output_dir=str(tmp_path / "b"), stop_after=6, **kw)    # "killed" after step 6, last save at 4
+    assert [r["step"] for r in part] == [1, 2, 3, 4, 5, 6]
+    torch.manual_seed(999); torch.cuda.manual_seed_all(999)                      # a new process has unrelated RNG state
+    mc, _ = tiny(training=True); mc.config.dedup_frames = True                   # ... and pre-training weights
+    rest = train(mc, ds6, output_dir=str(tmp_path / "b"), **kw)
+    assert [r["step"] for r in rest] == [5, 6, 7, 8]
+    assert [r["loss"] for r in rest] == [r["loss"] for r in full[4:]]            # continues, bit for bit
+    assert rest[0]["loss"] != full[0]["loss"]                                    # ... and did not jump back to step 1
+    wc, oc = snapshot(mc, str(tmp_path / "b" / "checkpoint-8" / "optimizer"))
+    for k in wa:
+        assert torch.equal(wa[k], wc[k]), k
+    for f in oa:
+        if f == "meta.pt":
+            assert oa[f]["step_count"] == oc[f]["step_count"] == 8
+            continue
+        for n in oa[f]:
+            for kk in ("master", "m", "v"):
+                assert torch.equal(oa[f][n][kk], oc[f][n][kk]), (f, n, kk)
 
 
 def test_evaluation_harness_metrics_and_failed_generations():
