@@ -29,6 +29,10 @@ _CFG_MAP = {"hidden_size": "hidden_size", "intermediate_size": "intermediate_siz
 def config_from_json(path: str) -> HandsOnVLMConfig:
     raw = json.load(open(os.path.join(path, "config.json")))
     kw = {dst: raw[src] for src, dst in _CFG_MAP.items() if raw.get(src) is not None}
+    if raw.get("rope_theta") is not None:                                  # transformers 4.31 (the reference's pin)
+        kw["rope_theta"] = float(raw["rope_theta"])
+    elif isinstance(raw.get("rope_parameters"), dict) and "rope_theta" in raw["rope_parameters"]:   # transformers 5.x
+        kw["rope_theta"] = float(raw["rope_parameters"]["rope_theta"])
     cfg = HandsOnVLMConfig(**kw)
     if "vision_config" in raw:
         cfg.vision = CLIPVisionConfig(**{k: v for k, v in raw["vision_config"].items() if k in CLIPVisionConfig.__dataclass_fields__})
@@ -43,15 +47,28 @@ def config_to_json(cfg: HandsOnVLMConfig, path: str):
 
 
 def load_state(path: str) -> Dict[str, torch.Tensor]:
-    """Loads a (possibly sharded) HF .bin checkpoint directory into one CPU state dict."""
-    idx = os.path.join(path, INDEX)
-    if os.path.exists(idx):
-        files = sorted(set(json.load(open(idx))["weight_map"].values()))
-    else:
-        files = ["pytorch_model.bin"]
+    """Loads a (possibly sharded) HF checkpoint directory into one CPU state dict: the transformers-4.31 layout the reference
+    writes and reads (`pytorch_model.bin`, or `pytorch_model-0000i-of-0000N.bin` + `pytorch_model.bin.index.json`;
+    handsonvlm/model/builder.py:93,158) and the safetensors layout newer transformers versions write for the same model
+    (`model.safetensors`, or shards + `model.safetensors.index.json`)."""
+    def shard_files(index_name, single):
+        idx = os.path.join(path, index_name)
+        if os.path.exists(idx):
+            return sorted(set(json.load(open(idx))["weight_map"].values()))
+        return [single] if os.path.exists(os.path.join(path, single)) else None
+
     sd: Dict[str, torch.Tensor] = {}
+    files = shard_files(INDEX, "pytorch_model.bin")
+    if files is not None:
+        for f in files:
+            sd.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
+        return sd
+    files = shard_files("model.safetensors.index.json", "model.safetensors")
+    if files is None:
+        raise FileNotFoundError(f"{path}: neither pytorch_model*.bin nor model*.safetensors found")
+    from safetensors.torch import load_file
     for f in files:
-        sd.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
+        sd.update(load_file(os.path.join(path, f), device="cpu"))
     return sd
 
 
@@ -77,14 +94,36 @@ def save_state(sd: Dict[str, torch.Tensor], path: str, max_shard_bytes: int = 10
               open(os.path.join(path, INDEX), "w"), indent=1)
 
 
+def infer_vision_config(sd: Dict[str, torch.Tensor], prefix: str = "model.vision_tower.vision_tower.vision_model.") -> Optional[CLIPVisionConfig]:
+    """The reference's config.json names the tower (`mm_vision_tower`: openai/clip-vit-large-patch14) instead of describing
+    it; when the checkpoint carries the tower's tensors (LLaVA-style full checkpoints do) its geometry is read off them."""
+    k = prefix + "embeddings.class_embedding"
+    if k not in sd:
+        prefix = prefix[: -len("vision_model.")]          # key naming of transformers >= 5
+        k = prefix + "embeddings.class_embedding"
+        if k not in sd:
+            return None
+    d = sd[k].numel()
+    patch = sd[prefix + "embeddings.patch_embedding.weight"].shape[-1]
+    npos = sd[prefix + "embeddings.position_embedding.weight"].shape[0]
+    layers = 1 + max(int(key[len(prefix + "encoder.layers."):].split(".")[0]) for key in sd if key.startswith(prefix + "encoder.layers."))
+    return CLIPVisionConfig(hidden_size=d, intermediate_size=sd[prefix + "encoder.layers.0.mlp.fc1.weight"].shape[0],
+                            num_hidden_layers=layers, num_attention_heads=max(1, d // 64), patch_size=patch,
+                            image_size=int(round((npos - 1) ** 0.5)) * patch)
+
+
 def from_pretrained(path: str, device="cuda:0", training: bool = False, mm_projector_bin: Optional[str] = None, **cfg_overrides):
     """load_pretrained_model (handsonvlm/model/builder.py:18) for the HIP model."""
     from .model import HandsOnVLMForCausalLM
     cfg = config_from_json(path)
     for k, v in cfg_overrides.items():
         setattr(cfg, k, v)
-    model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
     sd = load_state(path)
+    if "vision" not in cfg_overrides and "vision_config" not in json.load(open(os.path.join(path, "config.json"))):
+        vis = infer_vision_config(sd)
+        if vis is not None:
+            cfg.vision = vis
+    model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
     if mm_projector_bin is not None:                           # initialize_vision_modules(pretrain_mm_mlp_adapter=...)
         adapter = torch.load(mm_projector_bin, map_location="cpu", weights_only=True)
         for k, v in adapter.items():

@@ -57,6 +57,8 @@ class CLIPVisionTower:
         """Takes CLIPVisionModel keys (transformers 4.31 naming, `vision_model.*`)."""
         cfg, dev = self.cfg, self.device
         d = cfg.hidden_size
+        if prefix + "embeddings.class_embedding" not in sd and "embeddings.class_embedding" in sd:
+            prefix = ""                  # transformers >= 5 writes CLIPVisionModel keys without the `vision_model.` level
         g = lambda k: sd[prefix + k].to(device=dev, dtype=BF16).contiguous()  # noqa: E731
         p = {}
         w = sd[prefix + "embeddings.patch_embedding.weight"].reshape(d, -1)

@@ -178,3 +178,31 @@ PROMPT_SOURCES = [
     ([[{"from": "human", "value": "Describe a kitchen."}, {"from": "gpt", "value": "It has a sink."}],
       [{"from": "human", "value": "Hi"}, {"from": "gpt", "value": "Hello there, how can I help you today?"}]], False),
 ]
+
+
+def collator_instances():
+    """Seeded inputs for the batch-contract fixture (oracle/gen_golden_collator.py <-> tests/test_next_rows_cpu.py): a list
+    of cases, each a list of per-sample dicts as the reference's datasets produce them."""
+    r = _rs(901)
+
+    def sample(T, full, single_image=False, bool_flag=False, dtype_hands=torch.float32):
+        ids = torch.from_numpy(r.randint(3, 32000, size=T).astype(np.int64))
+        labels = ids.clone()
+        labels[: T // 3] = -100
+        img = torch.from_numpy(r.standard_normal((3, 224, 224) if single_image else (100, 3, 224, 224)).astype(np.float32)).to(torch.bfloat16)
+        d = dict(input_ids=ids, labels=labels, image=img)
+        if full:
+            d.update(feat=torch.from_numpy(r.standard_normal((5, 10, 1024)).astype(np.float32)).to(torch.bfloat16),
+                     bbox_feat=torch.from_numpy(r.standard_normal((4, 10, 4)).astype(np.float32)).to(torch.bfloat16),
+                     valid_mask=torch.from_numpy(r.rand(5, 10) > 0.5),
+                     future_hands=torch.from_numpy(r.rand(2, 5, 2).astype(np.float32)).to(dtype_hands),
+                     contact_point=torch.from_numpy(r.rand(2).astype(np.float32)).to(dtype_hands),
+                     future_valid=torch.from_numpy(r.rand(2) > 0.3),
+                     gt_label_valid=True if bool_flag else torch.tensor(True), prompt="what will the hands do?")
+        return d
+
+    return [
+        [sample(12, full=False, single_image=True), sample(31, full=True, bool_flag=True)],          # zero-fill + tiling + ragged
+        [sample(55, full=True, dtype_hands=torch.bfloat16), sample(20, full=True, dtype_hands=torch.bfloat16),
+         sample(47, full=False)],                                                                     # truncation at 40
+    ]

@@ -187,3 +187,24 @@ def test_overlapped_optimizer_bit_identical_to_end_of_step_update():
         assert a[0] == b[0]
         for x, y in zip(a[1:], b[1:]):
             assert (x is None and y is None) or torch.equal(x, y), a[0]
+
+
+def test_reference_written_checkpoint_on_hip(tmp_path):
+    """SURVEY.md §8f-1 on the real kernels: tests/golden/ckpt_tiny (written from the reference model: its key names, its
+    config.json, transformers-4.31 .bin shards) -> checkpoint.from_pretrained -> the reference's logits / loss, and the
+    LLaVA `mm_projector.bin` adapter override (llava_arch.py:64-69)."""
+    import os
+    from test_ckpt_reference_cpu import batch, check_loaded_model, inflate, rel
+    from hvlm import checkpoint
+    d = inflate(str(tmp_path / "ck"))
+    exp = dict(np.load(os.path.join(d, "expected.npz")))
+    m = checkpoint.from_pretrained(d, device="cuda:0", training=False)
+    assert m.tower.is_loaded and m.config.vision.hidden_size == 64
+    check_loaded_model(m, exp, "cuda")
+    m2 = checkpoint.from_pretrained(os.path.join(d, "st"), device="cuda:0", training=False,
+                                    mm_projector_bin=os.path.join(d, "mm_projector.bin"))
+    ids, labels, mask, images, fh, fv = batch()
+    out = m2(input_ids=ids, attention_mask=mask, image=images.to(BF), is_evaluate=True)
+    valid = torch.ones(2, 379, dtype=torch.bool); valid[1, 374:] = False
+    got = out.logits.float().cpu()[:, ::7, ::251][valid[:, ::7]]
+    assert rel(got, exp["logits_slice_adapter"][valid[:, ::7].numpy()]) < 1.5e-2

@@ -78,3 +78,32 @@ def test_prompt_plumbing_vs_reference_golden(golden):
     # image placeholder and hand tokens land where the splice / hand gather expect them
     ids = P.preprocess_v1(PROMPT_SOURCES[0][0], tok, has_image=True)["input_ids"][0]
     assert int((ids == P.IMAGE_TOKEN_INDEX).sum()) == 1 and int((ids == 32100).sum()) == 4
+
+
+def test_collator_vs_reference_golden(golden):
+    """hvlm.data.DataCollatorForSupervisedDataset against the OUTPUT OF THE REFERENCE CLASS
+    (handsonvlm/dataset/hybrid_dataset.py:108-169, run by oracle/gen_golden_collator.py) on the same seeded instances:
+    key set and order, values, dtypes (bf16 zero-fill, dtype promotion when present and zero-filled samples mix), padding,
+    truncation at model_max_length, single-image tiling to 100 frames."""
+    from oracle.synth import collator_instances
+    g = golden("g9_collator.npz")
+    col = DataCollatorForSupervisedDataset(pad_token_id=0, model_max_length=40)
+    for case, inst in enumerate(collator_instances()):
+        b = col(inst)
+        assert list(b.keys()) == [str(k) for k in g[f"c{case}.keys"]]
+        assert [str(p) for p in b["prompt"]] == [str(p) for p in g[f"c{case}.prompt"]]
+        img = b["image"]
+        assert str(img.dtype) == str(g[f"c{case}.image_dtype"])
+        assert np.array_equal(img[:, :, :, ::56, ::56].float().numpy(), g[f"c{case}.image_slice"])
+        assert np.array_equal(img.float().sum(dim=(2, 3, 4)).numpy(), g[f"c{case}.image_sum"])
+        for k, v in b.items():
+            if k in ("prompt", "image"):
+                continue
+            assert torch.is_tensor(v), k
+            assert str(v.dtype) == str(g[f"c{case}.{k}_dtype"]), (k, v.dtype, g[f"c{case}.{k}_dtype"])
+            want = g[f"c{case}.{k}"]
+            got = v.float().numpy() if v.is_floating_point() else v.numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), (case, k)
+    # EK100 tiling pattern (handsonvlm/dataset/epic_dataset.py:90-95): the 10-frame sequence repeated 10 times
+    f = torch.arange(10).float().view(10, 1, 1, 1).expand(10, 3, 2, 2)
+    assert tile_epic_frames(f)[:, 0, 0, 0].tolist() == [float(i % 10) for i in range(100)]
