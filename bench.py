@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
+    ap.add_argument("--recompute", action="store_true",
+                    help="activation recompute (scripts/finetune.sh:36): keep only each layer's input, re-run its forward in backward")
+    ap.add_argument("--varlen", default=None, metavar="LO:HI",
+                    help="per-sample prompt lengths T ~ U{LO..HI} (SURVEY §8d config 3: 64:192), right-padded by the collator")
+    ap.add_argument("--pack", action="store_true", help="packed (unpadded, cu_seqlens) rows through the whole decoder")
     ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
     return ap.parse_args()
 
@@ -68,22 +73,30 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
+    cfg.activation_recompute = args.recompute
+    cfg.pack_sequences = args.pack
     cfg.vision.image_size = args.image_size
     return cfg
 
 
-def make_batch(cfg, B, T, unique, seed, device):
+def make_batch(cfg, B, T, unique, seed, device, lens=None):
     """Synthetic EK100-shaped minibatch: uniform token ids with one <image> marker, labels
     -100 on the first 40 %, four <hand_traj> tokens at the tail; 100 frames = `unique` frames tiled."""
     from hvlm.synthetic import make_text_batch_np
     ids, labels = make_text_batch_np(B, T, seed)
+    mask = np.ones((B, T), dtype=bool)
+    if lens is not None:                         # ragged prompts, right-padded like DataCollatorForSupervisedDataset
+        for b in range(B):
+            one_i, one_l = make_text_batch_np(1, int(lens[b]), seed * 1000 + b)
+            ids[b] = 0; labels[b] = -100; mask[b] = False
+            ids[b, : lens[b]] = one_i[0]; labels[b, : lens[b]] = one_l[0]; mask[b, : lens[b]] = True
     g = torch.Generator(device=device).manual_seed(seed)
     base = torch.randn(B, unique, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
     idx = torch.arange(cfg.num_frames, device=device) % unique      # [f0..f9] x 10, epic_dataset.py:90-95
     image = base[:, idx].contiguous()
     fh = torch.rand(B, 2, 5, 2, device=device, generator=g)
     return dict(input_ids=torch.from_numpy(ids), labels=torch.from_numpy(labels),
-                attention_mask=torch.ones(B, T, dtype=torch.bool), image=image, future_hands=fh,
+                attention_mask=torch.from_numpy(mask), image=image, future_hands=fh,
                 contact_point=torch.zeros(B, 2, device=device), future_valid=torch.ones(B, 2, device=device),
                 gt_label_valid=torch.ones(B, device=device))
 
@@ -367,7 +380,12 @@ def main():
     model = HandsOnVLMForCausalLM(cfg, device=device, training=True).init_random(seed=0)
     opt = AdamW(model, lr=2e-5, weight_decay=0.0, overlap=not args.no_opt_overlap)
     buckets = hdp.attach(model, hdp.GradBuckets(), opt)
-    batch = make_batch(cfg, B, T, args.unique_frames, seed=100 + rank, device=device)
+    lens = None
+    if args.varlen:
+        lo, hi = (int(v) for v in args.varlen.split(":"))
+        lens = np.random.RandomState(100 + rank).randint(lo, hi + 1, size=B)
+        T = int(lens.max())
+    batch = make_batch(cfg, B, T, args.unique_frames, seed=100 + rank, device=device, lens=lens)
     ev = GemmEvents()
     if not args.no_gemm_events:
         ops.set_gemm_hook(ev)
@@ -408,9 +426,13 @@ def main():
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
     if rank == 0:
-        S = T + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
+        nv1 = cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
+        S = T + nv1
         n_frames = B * cfg.num_frames if not args.dedup else B * args.unique_frames
-        flops_llm = 3.0 * model.stack.flops_forward(B, S, cfg.vocab_size)
+        if lens is None:
+            flops_llm = 3.0 * model.stack.flops_forward(B, S, cfg.vocab_size)
+        else:       # algorithmic work = the real tokens of every sample (padding rows are not work)
+            flops_llm = 3.0 * sum(model.stack.flops_forward(1, int(n) + nv1, cfg.vocab_size) for n in lens)
         flops_clip = n_frames * model.tower.flops_per_frame()
         step_flops = flops_llm + flops_clip
         res = {
@@ -426,11 +448,14 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"sft_step_{args.model}_b{B}_T{T}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
-                                   + ("_dedupclip" if args.dedup else "_refequiv"),
+            "config": {"workload": f"sft_step_{args.model}_b{B}_T{T if lens is None else 'U' + args.varlen.replace(':', '-')}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
+                                   + ("_dedupclip" if args.dedup else "_refequiv") + ("_packed" if args.pack else "")
+                                   + ("_recompute" if args.recompute else ""),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "frames_through_clip_per_sample": n_frames // B,
-                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": False},
+                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": bool(args.recompute),
+                       "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",
+                       "packed_rows": bool(args.pack)},
             "step_tflop_algorithmic": step_flops / 1e12,
             "model_tflops_per_gpu": step_flops / (dt / args.steps) / 1e12,
             "mfma_roofline_frac_whole_step": step_flops / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

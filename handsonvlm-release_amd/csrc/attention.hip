@@ -110,8 +110,9 @@ template <int DH, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                        const bf16_t* __restrict__ vt,
                                                        bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int S, int H, int ld,
-                                                       int S_pad, float scale_log2) {
+                                                       float* __restrict__ lse, int S_max, int H, int ld,
+                                                       int S_pad, float scale_log2,
+                                                       const int32_t* __restrict__ cu_seqlens) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;   // K tile bytes ; V^T tile has the same size
   constexpr unsigned STAGE = 2 * KT;
@@ -119,12 +120,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
   constexpr int QB = NW * 32;            // query rows per workgroup
-  const int nqt = (S + QB - 1) / QB;
-  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;  // heavy tiles first
   const int h = blockIdx.y, b = blockIdx.z;
+  // varlen (cu_seqlens != NULL, llama_flash_attn_monkey_patch.py:81-94): sample b owns the packed rows
+  // [cu[b], cu[b+1]); the grid covers max_seqlen and the workgroups past this sample's length leave at once.
+  const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;
+  const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
+  const int nqt = (S + QB - 1) / QB;
+  if ((int)blockIdx.x >= nqt) return;
+  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;  // heavy tiles first
   const int q0 = qt * QB;
   const int qi = q0 + w * 32 + l31;
-  const long tok0 = (long)b * S;
 
   bf16x8 qf[DH / 16];
   {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
                    pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = v;
       }
-    if (lse && hi == 0) lse[((long)b * H + h) * S + qi] = m * LN2 + logf(ltot);
+    if (lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
   }
 }
 
@@ -483,14 +488,15 @@ __global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __res
   }
 }
 
-// delta[b,h,s] = sum_d O[b,s,h,d] * dO[b,s,h,d]   (one thread per 8 elements, dh/8-lane reduce)
+// delta[b,h,s] = sum_d O[b,s,h,d] * dO[b,s,h,d]   (one thread per 8 elements, dh/8-lane reduce).  Rows are token-major
+// [tokens, H*DH]; `row_b` / `row_s` (varlen: sample and position of every packed row) may be NULL (b = row / S, s = row % S).
 template <int DH>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o,
                                                          const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int B, int S,
-                                                         int H) {
+                                                         float* __restrict__ delta, long tokens, int S,
+                                                         int H, const int32_t* __restrict__ cu_seqlens, int B) {
   constexpr int LPH = DH / 8;  // lanes per (token, head)
-  const long total = (long)B * S * H * LPH;
+  const long total = tokens * H * LPH;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   float acc = 0.f;
   long tokh = 0;
@@ -506,9 +512,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   if (i < total && (i % LPH) == 0) {
     const long tok = tokh / H;
     const int h = (int)(tokh % H);
-    const long b = tok / S;
-    const int s = (int)(tok % S);
-    delta[(b * H + h) * S + s] = acc;
+    long b; int s_;
+    if (cu_seqlens) {                      // binary search of the sample that owns packed row `tok`
+      int lo = 0, hi_ = B;
+      while (hi_ - lo > 1) { const int mid = (lo + hi_) >> 1; if ((long)cu_seqlens[mid] <= tok) lo = mid; else hi_ = mid; }
+      b = lo; s_ = (int)(tok - cu_seqlens[lo]);
+    } else {
+      b = tok / S; s_ = (int)(tok % S);
+    }
+    delta[(b * H + h) * S + s_] = acc;
   }
 }
 
@@ -519,19 +531,22 @@ template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt_g /*K^T [B,H,DH,S_pad]*/,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dqkv, int S, int H, int ld, int S_pad, float scale) {
+    bf16_t* __restrict__ dqkv, int S_max, int H, int ld, int S_pad, float scale,
+    const int32_t* __restrict__ cu_seqlens) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
-  const int nqt = (S + 127) / 128;
-  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
+  const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;       // varlen: see attn_fwd_kernel
+  const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
+  const int nqt = (S + 127) / 128;
+  if ((int)blockIdx.x >= nqt) return;
+  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;
   const int q0 = qt * 128;
   const int qi = q0 + w * 32 + l31;
   const int qc = min(qi, S - 1);
-  const long tok0 = (long)b * S;
   const float scale_log2 = scale * LOG2E;
 
   bf16x8 qf[DH / 16], dof[DH / 16];
@@ -544,8 +559,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
       dof[ks] = *reinterpret_cast<const bf16x8*>(dp + ks * 16);
     }
   }
-  const float lse2 = lse[((long)b * H + h) * S + qc] * LOG2E;
-  const float dlt = delta[((long)b * H + h) * S + qc];
+  const float lse2 = lse[((long)b * H + h) * S_max + qc] * LOG2E;
+  const float dlt = delta[((long)b * H + h) * S_max + qc];
 
   f32x16 dq[DH / 32];
 #pragma unroll
@@ -666,18 +681,20 @@ template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt_g /*Q^T*/,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ dot_g /*dO^T*/,
-    const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S,
-    int H, int ld, int S_pad, float scale) {
+    const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S_max,
+    int H, int ld, int S_pad, float scale, const int32_t* __restrict__ cu_seqlens) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
   const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;       // varlen: see attn_fwd_kernel
+  const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
   const int k0 = kblk * 128;
+  if (k0 >= S) return;
   const int ki = k0 + w * 32 + l31;
   const int kc = min(ki, S - 1);
-  const long tok0 = (long)b * S;
   const float scale_log2 = scale * LOG2E;
 
   bf16x8 kf[DH / 16], vf[DH / 16];
@@ -702,8 +719,8 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
   const unsigned mk_lim = ki < S ? (unsigned)(S - mk_base) : 0u;
   const bf16_t* qbase = qkv + tok0 * ld + h * DH;
   const bf16_t* dobase = dout + tok0 * (long)(H * DH) + h * DH;
-  const float* lse_row = lse + ((long)b * H + h) * S;
-  const float* dlt_row = delta + ((long)b * H + h) * S;
+  const float* lse_row = lse + ((long)b * H + h) * S_max;
+  const float* dlt_row = delta + ((long)b * H + h) * S_max;
 
   // two LDS stages (see the dQ kernel): tiles + the 64 lse / delta values of step qt+1 are fetched during step qt.  A stage
   // holds Q and dO only; the Q^T / dO^T fragments of dK^T = Q^T dS and dV^T = dO^T P come from those tiles through
@@ -854,9 +871,9 @@ static int launch_head_transpose(const bf16_t* src, bf16_t* dst, int B, int S, i
 
 template <int DH, bool CAUSAL>
 static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int B, int S, int H, int ld,
-                    float scale, hipStream_t st) {
+                    float scale, hipStream_t st, const int32_t* cu = nullptr) {
   int rc;
-  if constexpr (!CAUSAL && DH == 64) {
+  if (!cu) if constexpr (!CAUSAL && DH == 64) {
     // short sequences: K/V resident in LDS, one workgroup per (batch, head), no V^T pre-pass
     const int nkb = (S + 31) / 32;
     if (nkb <= 9 && !getenv("HVLM_ATTN_NO_RESIDENT")) {
@@ -882,27 +899,29 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
     if (rc) return rc;
     dim3 grid((S + 95) / 96, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 3>), grid, dim3(192), LDS, st, qkv, (const bf16_t*)ws, out,
-                       lse, S, H, ld, spad(S), scale * LOG2E);
+                       lse, S, H, ld, spad(S), scale * LOG2E, cu);
   } else {
     rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4>, LDS, "attn_fwd");
     if (rc) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 4>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)ws, out,
-                       lse, S, H, ld, spad(S), scale * LOG2E);
+                       lse, S, H, ld, spad(S), scale * LOG2E, cu);
   }
   return check_launch("attn_fwd");
 }
 
 template <int DH, bool CAUSAL>
 static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse,
-                    bf16_t* dqkv, char* ws, int B, int S, int H, int ld, float scale, hipStream_t st) {
+                    bf16_t* dqkv, char* ws, int B, int S, int H, int ld, float scale, hipStream_t st,
+                    const int32_t* cu = nullptr, long total_tokens = 0) {
   bf16_t* qT = nullptr; bf16_t* kT = nullptr; bf16_t* doT = nullptr;     // (unused kernel arguments, kept for signature stability)
   float* delta = reinterpret_cast<float*>(ws);
   int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
   {
-    const long total = (long)B * S * H * (DH / 8);
+    const long tokens = cu ? total_tokens : (long)B * S;
+    const long total = tokens * H * (DH / 8);
     hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out,
-                       dout, delta, B, S, H);
+                       dout, delta, tokens, S, H, cu, B);
     if ((rc = check_launch("attn_delta"))) return rc;
   }
   {
@@ -910,7 +929,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = set_lds(attn_bwd_dq_kernel<DH, CAUSAL>, LDS, "attn_bwd_dq"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)kT,
-                       dout, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale);
+                       dout, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
     if ((rc = check_launch("attn_bwd_dq"))) return rc;
   }
   {
@@ -918,7 +937,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
-                       dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale);
+                       dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
     if ((rc = check_launch("attn_bwd_dkv"))) return rc;
   }
   return HVLM_OK;
@@ -968,4 +987,39 @@ extern "C" int hvlm_attn_bwd(const void* qkv, const void* out, const void* dout,
                                : bwd_impl<128, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, S, H, ld, scale, st);
   return causal ? bwd_impl<64, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, S, H, ld, scale, st)
                 : bwd_impl<64, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, S, H, ld, scale, st);
+}
+
+
+// Variable-length (packed) causal attention — the contract of the reference's kernel swap,
+// llava/train/llama_flash_attn_monkey_patch.py:81-96: unpad_input -> flash_attn_varlen_qkvpacked_func(qkv [total, 3, H, dh],
+// cu_seqlens [B+1] int32, max_seqlen, causal=True) -> pad_input.  Here the engine keeps the tokens packed end to end, so
+// there is no unpad / pad step at all.
+extern "C" int hvlm_attn_fwd_varlen(const void* qkv, void* out, float* lse, void* ws, const int32_t* cu_seqlens, int B,
+                                    int max_seqlen, int H, int dh, int ld, int causal, float scale, void* stream) {
+  HVLM_REQUIRE(qkv && out && ws && cu_seqlens, "attn_fwd_varlen: null pointer");
+  HVLM_REQUIRE(B > 0 && max_seqlen > 0 && H > 0 && ld >= 3 * H * dh && ld % 8 == 0, "attn_fwd_varlen: bad shape");
+  HVLM_REQUIRE(dh == 64 || dh == 128, "attn_fwd_varlen: dh must be 64 or 128 (got %d)", dh);
+  hipStream_t st = as_stream(stream);
+  const bf16_t* q = (const bf16_t*)qkv;
+  if (dh == 128) return causal ? fwd_impl<128, true>(q, (bf16_t*)out, lse, (bf16_t*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens)
+                               : fwd_impl<128, false>(q, (bf16_t*)out, lse, (bf16_t*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens);
+  return causal ? fwd_impl<64, true>(q, (bf16_t*)out, lse, (bf16_t*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens)
+                : fwd_impl<64, false>(q, (bf16_t*)out, lse, (bf16_t*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens);
+}
+
+extern "C" int hvlm_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                    void* ws, const int32_t* cu_seqlens, int B, int max_seqlen, long total_tokens, int H,
+                                    int dh, int ld, int causal, float scale, void* stream) {
+  HVLM_REQUIRE(qkv && out && dout && lse && dqkv && ws && cu_seqlens, "attn_bwd_varlen: null pointer");
+  HVLM_REQUIRE(B > 0 && max_seqlen > 0 && total_tokens > 0 && H > 0 && ld >= 3 * H * dh && ld % 8 == 0, "attn_bwd_varlen: bad shape");
+  HVLM_REQUIRE(dh == 64 || dh == 128, "attn_bwd_varlen: dh must be 64 or 128 (got %d)", dh);
+  HVLM_REQUIRE(((uintptr_t)ws & 15) == 0, "attn_bwd_varlen: workspace must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const bf16_t* q = (const bf16_t*)qkv;
+  const bf16_t* o = (const bf16_t*)out;
+  const bf16_t* g = (const bf16_t*)dout;
+  if (dh == 128) return causal ? bwd_impl<128, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens)
+                               : bwd_impl<128, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens);
+  return causal ? bwd_impl<64, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens)
+                : bwd_impl<64, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens);
 }

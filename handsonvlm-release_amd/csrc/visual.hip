@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void splice_fwd_kernel(
     const bf16_t* __restrict__ embed, const bf16_t* __restrict__ visual,
     const int32_t* __restrict__ src, const int32_t* __restrict__ hand_slot,
     const float* __restrict__ hands, const float* __restrict__ hand_scale, bf16_t* __restrict__ out,
-    int B, int S, int D, int NV, int NH) {
+    int B, int S, int D, int NV, int NH, const int32_t* __restrict__ row_sample) {
   const int dv = D / 8;
   const long total = (long)B * S * dv;
   const int D8 = D / 8;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void splice_fwd_kernel(
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % dv) * 8;
     const long row = i / dv;
-    const long b = row / S;
+    const long b = row_sample ? (long)row_sample[row] : row / S;      // packed rows carry their sample index
     const int sidx = src[row];
     u32x4 v = {0u, 0u, 0u, 0u};
     if (sidx >= 0) v = *reinterpret_cast<const u32x4*>(embed + (long)sidx * D + c);
@@ -194,13 +194,13 @@ __global__ __launch_bounds__(256) void splice_bwd_kernel(const bf16_t* __restric
                                                          const int32_t* __restrict__ src,
                                                          float* __restrict__ dembed,
                                                          bf16_t* __restrict__ dvisual, int B, int S,
-                                                         int D, int NV) {
+                                                         int D, int NV, const int32_t* __restrict__ row_sample) {
   const int dv = D / 8;
   const long total = (long)B * S * dv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % dv) * 8;
     const long row = i / dv;
-    const long b = row / S;
+    const long b = row_sample ? (long)row_sample[row] : row / S;
     const int sidx = src[row];
     if (sidx == -1) continue;
     const u32x4 v = *reinterpret_cast<const u32x4*>(dx + row * (long)D + c);
@@ -312,8 +312,29 @@ extern "C" int hvlm_embed_splice_fwd(const void* embed, const void* visual, cons
   const long total = (long)B * S * (D / 8);
   hipLaunchKernelGGL(splice_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                      (const bf16_t*)embed, (const bf16_t*)visual, src, hand_slot, hands, hand_scale,
-                     (bf16_t*)out, B, S, D, NV, NH);
+                     (bf16_t*)out, B, S, D, NV, NH, (const int32_t*)nullptr);
   return check_launch("embed_splice_fwd");
+}
+
+extern "C" int hvlm_embed_splice_fwd_packed(const void* embed, const void* visual, const int32_t* src,
+                                            const int32_t* hand_slot, const float* hands, const float* hand_scale,
+                                            const int32_t* row_sample, void* out, int rows, int D, int NV, int NH,
+                                            void* stream) {
+  HVLM_REQUIRE(embed && src && row_sample && out && rows > 0 && D % 8 == 0, "splice_fwd_packed: bad args");
+  const long total = (long)rows * (D / 8);
+  hipLaunchKernelGGL(splice_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)embed, (const bf16_t*)visual, src, hand_slot, hands, hand_scale,
+                     (bf16_t*)out, 1, rows, D, NV, NH, row_sample);
+  return check_launch("embed_splice_fwd_packed");
+}
+
+extern "C" int hvlm_embed_splice_bwd_packed(const void* dx, const int32_t* src, const int32_t* row_sample, float* dembed,
+                                            void* dvisual, int rows, int D, int NV, void* stream) {
+  HVLM_REQUIRE(dx && src && row_sample && rows > 0 && D % 8 == 0, "splice_bwd_packed: bad args");
+  const long total = (long)rows * (D / 8);
+  hipLaunchKernelGGL(splice_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)dx, src, dembed, (bf16_t*)dvisual, 1, rows, D, NV, row_sample);
+  return check_launch("embed_splice_bwd_packed");
 }
 
 extern "C" int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* dembed, void* dvisual,
@@ -321,7 +342,7 @@ extern "C" int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* 
   HVLM_REQUIRE(dx && src && B > 0 && S > 0 && D % 8 == 0, "splice_bwd: bad args");
   const long total = (long)B * S * (D / 8);
   hipLaunchKernelGGL(splice_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)dx, src, dembed, (bf16_t*)dvisual, B, S, D, NV);
+                     (const bf16_t*)dx, src, dembed, (bf16_t*)dvisual, B, S, D, NV, (const int32_t*)nullptr);
   return check_launch("embed_splice_bwd");
 }
 

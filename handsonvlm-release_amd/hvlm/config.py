@@ -57,6 +57,10 @@ class HandsOnVLMConfig:
     project_after_pool: bool = True    # mm_projector commutes with the mean/avg pooling: 356 rows instead of 25 600
     dedup_frames: bool = False         # run CLIP once per unique frame (EK100 tiles 10 frames x10)
     clip_chunk_frames: int = 400       # frames per CLIP pass (bounds activation memory)
+    activation_recompute: bool = False  # keep only each decoder layer's input, re-run its forward in backward
+                                        # (scripts/finetune.sh:36 `--gradient_checkpointing True`); off: 288 GB hold them
+    pack_sequences: bool = False       # training batches without padding rows (cu_seqlens through the whole decoder: the
+                                        # reference's flash-attn patch unpads around attention only)
     vision: CLIPVisionConfig = field(default_factory=CLIPVisionConfig)
 
     @property

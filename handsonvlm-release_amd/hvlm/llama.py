@@ -8,9 +8,11 @@ MI355X-first choices:
     attention kernel reads in place and whose gradient buffer feeds the qkv dW/dX GEMMs directly —
     no [B,H,S,dh] permutes anywhere;
   * gate|up fused into one [2F, D] GEMM; residual adds fused into the o_proj / down_proj epilogues;
-  * no activation recompute: with 288 GB of HBM3E the ~1.9 GB/layer of saved activations (7B,
-    B=16, S=868) fit, so backward costs 2x forward instead of the reference's 3x (gradient
-    checkpointing, scripts/finetune.sh:36);
+  * activation recompute is OPTIONAL (cfg.activation_recompute): with 288 GB of HBM3E the ~1.9 GB/layer of saved
+    activations (7B, B=16, S=868) fit, so by default backward costs 2x forward instead of the reference's 3x
+    (gradient checkpointing, scripts/finetune.sh:36); with it only every layer's input is kept (113 MB/layer) and
+    the layer forward is re-run inside backward — what lets 13B at S=2048 reach the reference's 16 per device;
+  * packed (unpadded) batches: rows of all samples end to end + cu_seqlens, through the whole decoder;
   * every weight keeps a resident transposed bf16 copy (written by the fused AdamW kernel) so dX
     GEMMs are plain NT GEMMs on K-contiguous operands;
   * weight gradients of one layer are views into ONE flat bf16 bucket (the RCCL all-reduce unit).
@@ -64,9 +66,18 @@ class LayerParams:
             ops.transpose(self.w[k], out=t)
 
 
+class SeqInfo:
+    """Row layout of one batch: padded (cu is None: sample b = rows [b*S, (b+1)*S)) or packed (cu int32 [B+1])."""
+    __slots__ = ("B", "S", "M", "cu", "pos")
+
+    def __init__(self, B, S, M, cu, pos):
+        self.B, self.S, self.M, self.cu, self.pos = B, S, M, cu, pos
+
+
 class LlamaStack:
     def __init__(self, cfg: HandsOnVLMConfig, device, training: bool = True):
         self.cfg = cfg
+        self.recompute = bool(getattr(cfg, "activation_recompute", False))
         self.device = torch.device(device)
         self.training = training
         D, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
@@ -214,47 +225,59 @@ class LlamaStack:
         _lib.check(rc, "llama_decode_step")
         return hidden
 
+    def _layer_forward(self, li: int, x: torch.Tensor, seq: "SeqInfo", save: bool, cache=None):
+        """One decoder layer.  Returns (output, saved-activation dict or None)."""
+        lp = self.layers[li]
+        eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
+        xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
+        probe = getattr(self, "_fp8_probe", None)
+        if probe is not None:
+            probe[li]["qkv"] = float(xn.abs().max())
+        qkv = ops.gemm_nt(xn, lp.w["qkv"])
+        ops.rope_qk_(qkv, self.cos, self.sin, seq.pos, self.H, self.dh)
+        if cache is not None:
+            assert seq.B == 1
+            cache[li][:seq.S].copy_(qkv)
+        ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
+        h = ops.gemm_nt(ao, lp.w["o"], residual=x)
+        hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
+        gu = ops.gemm_nt(hn, lp.w["gu"])
+        act = ops.swiglu_fwd(gu)
+        if probe is not None:
+            probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
+        xo = ops.gemm_nt(act, lp.w["down"], residual=h)
+        sv = dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn, gu=gu, act=act) if save else None
+        return xo, sv
+
     def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
-                all_hidden: bool = False, cache: Optional[List[torch.Tensor]] = None):
-        """x [B*S, D] bf16 -> final-normed hidden [B*S, D].  Saves activations for backward when
-        save (default: self.training)."""
+                all_hidden: bool = False, cache: Optional[List[torch.Tensor]] = None,
+                cu_seqlens: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
+        """x [M, D] bf16 -> final-normed hidden [M, D].
+        Padded batch: M = B*S, sample b owns rows [b*S, (b+1)*S), positions arange(S) (right padding is harmless under the
+        causal mask).  Packed batch (cu_seqlens int32 [B+1] on the device + pos int32 [M]): the B samples are stored end
+        to end without padding rows, S = the longest sample — the unpadded contract of the reference's flash-attention
+        patch (llama_flash_attn_monkey_patch.py:81-96), kept through the WHOLE decoder here, not only around attention.
+        Saves activations for backward when `save` (default: self.training); with self.recompute only each layer's input."""
         save = self.training if save is None else save
         cfg = self.cfg
-        M = B * S
+        M = x.shape[0]
         assert x.shape == (M, self.D) and x.dtype == BF16 and S <= cfg.max_position_embeddings
-        pos = self._positions(B, S)
-        scale = self.dh ** -0.5
-        eps = cfg.rms_norm_eps
+        assert (cu_seqlens is None and M == B * S) or (cu_seqlens is not None and pos is not None and pos.numel() == M)
+        seq = SeqInfo(B=B, S=S, M=M, cu=cu_seqlens, pos=self._positions(B, S) if pos is None else pos)
+        keep_all = save and not self.recompute
         self.saved = []
         hs = [x] if all_hidden else None
-        for li, lp in enumerate(self.layers):
-            xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
-            probe = getattr(self, "_fp8_probe", None)
-            if probe is not None:
-                probe[li]["qkv"] = float(xn.abs().max())
-            qkv = ops.gemm_nt(xn, lp.w["qkv"])
-            ops.rope_qk_(qkv, self.cos, self.sin, pos, self.H, self.dh)
-            if cache is not None:
-                assert B == 1
-                cache[li][:S].copy_(qkv)
-            ao, lse = ops.attn_fwd(qkv, B, S, self.H, self.dh, True, scale, need_lse=save)
-            h = ops.gemm_nt(ao, lp.w["o"], residual=x)
-            hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
-            gu = ops.gemm_nt(hn, lp.w["gu"])
-            act = ops.swiglu_fwd(gu)
-            if probe is not None:
-                probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
-            xo = ops.gemm_nt(act, lp.w["down"], residual=h)
+        for li in range(self.L):
+            xo, sv = self._layer_forward(li, x, seq, keep_all, cache)
             if save:
-                self.saved.append(dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn,
-                                       gu=gu, act=act))
+                self.saved.append(sv if keep_all else dict(x=x))
             x = xo
             if all_hidden:
                 hs.append(x)
-        hidden, rstd_f = ops.rmsnorm_fwd(x, self.norm_w, eps, save_rstd=save)
+        hidden, rstd_f = ops.rmsnorm_fwd(x, self.norm_w, cfg.rms_norm_eps, save_rstd=save)
         if save:
             self.final = dict(x=x, rstd=rstd_f)
-            self.BS = (B, S)
+            self.seq = seq
         if all_hidden:
             hs[-1] = hidden
             return hidden, hs
@@ -341,15 +364,18 @@ class LlamaStack:
         """dhidden [M, D] (grad of the final-normed hidden) -> dx [M, D]; weight grads are written
         (not accumulated) into the per-layer buckets."""
         assert self.training and self.saved, "forward(save=True) must precede backward"
-        B, S = self.BS
-        M = B * S
+        seq = self.seq
+        B, S, M, pos = seq.B, seq.S, seq.M, seq.pos
         mpad = _round_up(M, 64)
         scale = self.dh ** -0.5
-        pos = self._positions(B, S)
         dx, dwn = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"])
         self.norm_g.copy_(dwn)
         for i in range(self.L - 1, -1, -1):
             lp, sv = self.layers[i], self.saved[i]
+            if self.recompute:
+                # activation recompute (the reference's gradient checkpointing, scripts/finetune.sh:36): only the layer input
+                # was kept; its forward is run again here, bit-identical to the first one (deterministic kernels)
+                sv = self._layer_forward(i, sv["x"], seq, True)[1]
             # ---- MLP ----
             dact = ops.gemm_nt(dx, lp.wt["down"])                      # [M,F] = dx @ Wd
             self._dw(dx, sv["act"], lp.g["down"], mpad)                 # dWd[D,F]
@@ -363,7 +389,7 @@ class LlamaStack:
             # ---- attention ----
             dao = ops.gemm_nt(dh, lp.wt["o"])
             self._dw(dh, sv["ao"], lp.g["o"], mpad)
-            dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale)
+            dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale, cu_seqlens=seq.cu)
             ops.rope_qk_(dqkv, self.cos, self.sin, pos, self.H, self.dh, inverse=True)
             dxn = ops.gemm_nt(dqkv, lp.wt["qkv"])
             self._dw(dqkv, sv["xn"], lp.g["qkv"], mpad)
@@ -371,6 +397,7 @@ class LlamaStack:
             dx, dw1 = ops.rmsnorm_bwd(dxn, sv["x"], lp.w["ln1"], sv["rstd1"], add=dh)
             lp.g["ln1"].copy_(dw1)
             self.saved[i] = None
+            del sv
             self._join_side()
             if self.on_layer_grad_ready is not None:
                 self.on_layer_grad_ready(i)

@@ -39,6 +39,7 @@ class CausalLMOutputWithPast:
     hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
     attentions: Optional[object] = None
     loss_components: Optional[Dict[str, torch.Tensor]] = None   # text / traj / kl (the reference logs them to wandb)
+    cu_seqlens: Optional[torch.Tensor] = None   # set when logits / hidden_states are PACKED [M, ...] (config.pack_sequences)
 
     def __getitem__(self, i):
         return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions)
@@ -68,6 +69,11 @@ class SplicePlan:
     has_hand: Optional[np.ndarray]    # bool [B]
     lengths: np.ndarray
     seg: Optional[tuple] = None       # (seg_rows, seg_start, seg_token) int32 device tensors: text rows sorted by token id
+    # packed layout (config.pack_sequences, training): src / hand_slot / targets have M = sum(lengths) rows, no padding
+    M: int = 0                        # rows of inputs_embeds (B*S when padded)
+    cu: Optional[torch.Tensor] = None          # int32 [B+1] cu_seqlens
+    pos: Optional[torch.Tensor] = None         # int32 [M] position of every row inside its sample
+    row_sample: Optional[torch.Tensor] = None  # int32 [M]
 
 
 class _EngineLoss(torch.autograd.Function):
@@ -233,16 +239,25 @@ class HandsOnVLMForCausalLM:
     # splice plan (host)
     # ------------------------------------------------------------------------------------------
     def build_splice_plan(self, input_ids, labels, NV: int, n_hands: int, is_evaluate: bool,
-                          has_future_hands: bool) -> SplicePlan:
-        ids = input_ids.detach().cpu().numpy().astype(np.int64)
-        lab = None if labels is None else labels.detach().cpu().numpy().astype(np.int64)
-        B, T = ids.shape
+                          has_future_hands: bool, pack: bool = False, attention_mask=None) -> SplicePlan:
+        ids_all = input_ids.detach().cpu().numpy().astype(np.int64)
+        lab_all = None if labels is None else labels.detach().cpu().numpy().astype(np.int64)
+        B, T = ids_all.shape
+        # packed rows: the collator's right padding (attention_mask False at the tail, hybrid_dataset.py:151-157) is dropped —
+        # exact, because pads sit after every real token under the causal mask and carry label -100
+        keep = np.full(B, T)
+        if pack and attention_mask is not None:
+            am = attention_mask.detach().cpu().numpy().astype(bool)
+            keep = np.array([int(np.nonzero(am[b])[0][-1]) + 1 if am[b].any() else 1 for b in range(B)])
         rows_src, rows_lab, rows_slot, scales = [], [], [], []
         for b in range(B):
-            img = np.nonzero(ids[b] == IMAGE_TOKEN_INDEX)[0]
+            idb = ids_all[b, :keep[b]]
+            labb = None if lab_all is None else lab_all[b, :keep[b]]
+            T = int(keep[b])
+            img = np.nonzero(idb == IMAGE_TOKEN_INDEX)[0]
             if img.size == 0:
-                src = ids[b].copy()
-                nl = None if lab is None else lab[b].copy()
+                src = idb.copy()
+                nl = None if labb is None else labb.copy()
                 slot = np.full(T, -1, dtype=np.int64)
                 scale = 0.0
             else:
@@ -250,9 +265,9 @@ class HandsOnVLMForCausalLM:
                     raise NotImplementedError("one <image> token per sample (the reference indexes visual tokens "
                                               "with a running counter, handsonvlm.py:231-300)")
                 p = int(img[0])
-                tail = ids[b, p + 1:]
-                src = np.concatenate([ids[b, :p], -2 - np.arange(NV), tail])
-                nl = None if lab is None else np.concatenate([lab[b, :p], np.full(NV, IGNORE_INDEX), lab[b, p + 1:]])
+                tail = idb[p + 1:]
+                src = np.concatenate([idb[:p], -2 - np.arange(NV), tail])
+                nl = None if labb is None else np.concatenate([labb[:p], np.full(NV, IGNORE_INDEX), labb[p + 1:]])
                 slot = np.full(src.shape[0], -1, dtype=np.int64)
                 ts = p + NV
                 scale = 0.0
@@ -273,8 +288,11 @@ class HandsOnVLMForCausalLM:
             rows_src.append(src); rows_lab.append(nl); rows_slot.append(slot); scales.append(scale)
         lengths = np.array([r.shape[0] for r in rows_src])
         S = int(lengths.max())
+        if pack:
+            return self._packed_plan(rows_src, rows_lab, rows_slot, scales, lengths, S, lab_all is not None)
         src = np.full((B, S), -1, dtype=np.int32)
         slot = np.full((B, S), -1, dtype=np.int32)
+        lab = lab_all
         nl = None if lab is None else np.full((B, S), IGNORE_INDEX, dtype=np.int64)
         for b in range(B):
             n = lengths[b]
@@ -298,21 +316,61 @@ class HandsOnVLMForCausalLM:
             hand_rows = torch.from_numpy(hr.reshape(-1)).to(dev)
         seg = None
         if nl is not None and getattr(self, "training", False):
-            # text rows grouped by token id in a FIXED order (stable sort): the embedding gradient is summed segment by
-            # segment without atomics (hvlm_embed_grad_segments), so the step is run-to-run bit-identical
-            flat = src.reshape(-1)
-            rows = np.nonzero(flat >= 0)[0].astype(np.int32)
-            order = np.argsort(flat[rows], kind="stable")
-            rows = rows[order]
-            toks = flat[rows]
-            starts = np.concatenate([[0], np.nonzero(np.diff(toks))[0] + 1, [rows.size]]).astype(np.int32)
-            seg = (torch.from_numpy(rows).to(dev), torch.from_numpy(starts).to(dev),
-                   torch.from_numpy(toks[starts[:-1]].astype(np.int32)).to(dev))
-        return SplicePlan(seg=seg, B=B, S=S, src=torch.from_numpy(src.reshape(-1)).to(dev),
+            seg = self._embed_segments(src.reshape(-1))
+        return SplicePlan(seg=seg, M=B * S, B=B, S=S, src=torch.from_numpy(src.reshape(-1)).to(dev),
                           hand_slot=torch.from_numpy(slot.reshape(-1)).to(dev),
                           hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets,
                           hand_rows=hand_rows, has_hand=has_hand, lengths=lengths)
+
+    def _embed_segments(self, flat_src: np.ndarray):
+        """Text rows grouped by token id in a FIXED order (stable sort): the embedding gradient is summed segment by
+        segment without atomics (hvlm_embed_grad_segments), so the step is run-to-run bit-identical."""
+        dev = self.device
+        rows = np.nonzero(flat_src >= 0)[0].astype(np.int32)
+        order = np.argsort(flat_src[rows], kind="stable")
+        rows = rows[order]
+        toks = flat_src[rows]
+        starts = np.concatenate([[0], np.nonzero(np.diff(toks))[0] + 1, [rows.size]]).astype(np.int32)
+        return (torch.from_numpy(rows).to(dev), torch.from_numpy(starts).to(dev),
+                torch.from_numpy(toks[starts[:-1]].astype(np.int32)).to(dev))
+
+    def _packed_plan(self, rows_src, rows_lab, rows_slot, scales, lengths, S, has_labels) -> SplicePlan:
+        """The same per-sample layouts stored end to end, without padding rows (the reference unpads around attention
+        only, llama_flash_attn_monkey_patch.py:81-96; here every token-wise kernel skips the padding)."""
+        dev = self.device
+        B = len(rows_src)
+        cu = np.zeros(B + 1, dtype=np.int32)
+        cu[1:] = np.cumsum(lengths)
+        M = int(cu[-1])
+        src = np.concatenate(rows_src).astype(np.int32)
+        slot = np.concatenate(rows_slot).astype(np.int32)
+        pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lengths])
+        row_sample = np.repeat(np.arange(B, dtype=np.int32), lengths)
+        nl = targets = hand_rows = has_hand = seg = None
+        if has_labels:
+            nl = np.full((B, S), IGNORE_INDEX, dtype=np.int64)          # padded labels, as the reference returns them
+            tg = np.full(M, IGNORE_INDEX, dtype=np.int32)
+            hr = np.full((B, 4), -1, dtype=np.int32)
+            has_hand = np.zeros(B, dtype=bool)
+            for b in range(B):
+                n = lengths[b]
+                nl[b, :n] = rows_lab[b]
+                tg[cu[b]:cu[b] + n - 1] = rows_lab[b][1:]                 # shifted inside the sample; last row ignored
+                p = np.nonzero(rows_lab[b][1:] == HAND_TOKEN_ID)[0]
+                if p.size:
+                    assert p.size == 4, f"expected 4 <hand_traj> labels, got {p.size}"
+                    hr[b] = cu[b] + p
+                    has_hand[b] = True
+            targets = torch.from_numpy(tg).to(dev)
+            hand_rows = torch.from_numpy(hr.reshape(-1)).to(dev)
+            if getattr(self, "training", False):
+                seg = self._embed_segments(src)
+        return SplicePlan(B=B, S=S, M=M, src=torch.from_numpy(src).to(dev), hand_slot=torch.from_numpy(slot).to(dev),
+                          hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
+                          labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets, hand_rows=hand_rows,
+                          has_hand=has_hand, lengths=lengths, seg=seg, cu=torch.from_numpy(cu).to(dev),
+                          pos=torch.from_numpy(pos).to(dev), row_sample=torch.from_numpy(row_sample).to(dev))
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -343,7 +401,11 @@ class HandsOnVLMForCausalLM:
             vis = self.visual_tokens(image.to(dev), keep_for_backward=training_pass)
         NV = vis.shape[1]
         n_hands = 0 if future_hands is None else future_hands.shape[2]
-        plan = self.build_splice_plan(input_ids, labels, NV, n_hands, is_evaluate, future_hands is not None)
+        # packed (unpadded) rows: training passes only, opt-in (config.pack_sequences); logits / hidden states are then
+        # returned packed too ([M, ...] with out.cu_seqlens), everything else is unchanged
+        pack = bool(cfg.pack_sequences) and training_pass
+        plan = self.build_splice_plan(input_ids, labels, NV, n_hands, is_evaluate, future_hands is not None, pack=pack,
+                                      attention_mask=attention_mask)
         S = plan.S
         assert S <= cfg.max_position_embeddings, f"spliced length {S} exceeds max_position_embeddings"
         hands_dev = None
@@ -351,12 +413,13 @@ class HandsOnVLMForCausalLM:
             hands_dev = future_hands.detach().to(dev, torch.float32).contiguous()
         x = ops.embed_splice_fwd(self.embed, vis, plan.src, plan.hand_slot if hands_dev is not None else None,
                                  hands_dev, plan.hand_scale if hands_dev is not None else None, B, S, self.token_dim,
-                                 NV, max(n_hands, 1))
+                                 NV, max(n_hands, 1), row_sample=plan.row_sample)
+        shape3 = (lambda t: t) if pack else (lambda t: t.view(B, S, -1))
         if output_hidden_states:
-            hidden, hs = self.stack.forward(x, B, S, save=training_pass, all_hidden=True)
-            hs = tuple(h.view(B, S, -1) for h in hs)
+            hidden, hs = self.stack.forward(x, B, S, save=training_pass, all_hidden=True, cu_seqlens=plan.cu, pos=plan.pos)
+            hs = tuple(shape3(h) for h in hs)
         else:
-            hidden, hs = self.stack.forward(x, B, S, save=training_pass), None
+            hidden, hs = self.stack.forward(x, B, S, save=training_pass, cu_seqlens=plan.cu, pos=plan.pos), None
         last_only = kwargs.get("last_logits_only", False) and labels is None
         if last_only:
             rows = torch.from_numpy((np.arange(B) * S + plan.lengths - 1).astype(np.int64)).to(dev)
@@ -365,7 +428,7 @@ class HandsOnVLMForCausalLM:
             logits = logits_p[:, : cfg.vocab_size].unsqueeze(1)
         else:
             logits_p = ops.gemm_nt(hidden, self.lm_head)                     # [M, Vpad] bf16
-            logits = logits_p.view(B, S, -1)[:, :, : cfg.vocab_size]
+            logits = logits_p[:, : cfg.vocab_size] if pack else logits_p.view(B, S, -1)[:, :, : cfg.vocab_size]
         loss = comps = None
         if labels is not None:
             acc, row_lse = ops.ce_fwd(logits_p, plan.targets, cfg.vocab_size)
@@ -384,14 +447,14 @@ class HandsOnVLMForCausalLM:
             comps = {"text loss": loss_text, "traj_loss": tl["traj_loss"].detach(), "traj_kl_loss": tl["traj_kl_loss"].detach()}
             if training_pass:
                 self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb,
-                                 head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1])
+                                 head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1], M=plan.M)
                 loss = _EngineLoss.apply(self._anchor, self, value)
             else:
                 loss = value
         if training_pass and kwargs.get("keep_logits", False):
             logits = logits.clone()
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None,
-                                     loss_components=comps)
+                                     loss_components=comps, cu_seqlens=plan.cu)
         if return_dict is False:
             return (loss, logits) if loss is not None else (logits,)
         return out
@@ -408,7 +471,7 @@ class HandsOnVLMForCausalLM:
         self._ctx = None
         cfg, dev = self.config, self.device
         plan, B, S, NV = c["plan"], c["B"], c["S"], c["NV"]
-        M = B * S
+        M = c["M"]
         mpad = _round_up(M, 64)
         if grad_scale is None:
             grad_scale = torch.ones((), device=dev)
@@ -433,7 +496,7 @@ class HandsOnVLMForCausalLM:
         # zeros, not empty: the splice backward only writes the rows of samples that contain an <image> token; a text-only
         # sample (forward supports it, like handsonvlm.py:234-244) must contribute ZERO projector gradient
         dvis = torch.zeros((B * NV, self.token_dim), dtype=BF16, device=dev)
-        ops.embed_splice_bwd(dx, plan.src, None, dvis, B, S, self.token_dim, NV)          # visual rows only
+        ops.embed_splice_bwd(dx, plan.src, None, dvis, B, S, self.token_dim, NV, row_sample=plan.row_sample)   # visual rows only
         ops.embed_grad_segments(dx, *plan.seg, self.embed_g)
         sv = self._vis_saved
         if cfg.project_after_pool:

@@ -275,27 +275,41 @@ def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos: torch
 
 
 def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, dh: int, causal: bool, scale: float,
-             need_lse: bool = True, out: Optional[torch.Tensor] = None):
+             need_lse: bool = True, out: Optional[torch.Tensor] = None, cu_seqlens: Optional[torch.Tensor] = None):
+    """Padded batch: qkv [B*S, ld].  With cu_seqlens (int32 [B+1], device): the tokens are PACKED (qkv [total, ld]) and
+    S is max_seqlen — flash_attn_varlen_qkvpacked_func's contract (llama_flash_attn_monkey_patch.py:81-94)."""
     _chk(qkv, BF16, "attn.qkv")
-    assert qkv.dim() == 2 and qkv.shape[0] == B * S and qkv.stride(1) == 1
+    assert qkv.dim() == 2 and qkv.stride(1) == 1
     lib = _lib.load()
-    o = torch.empty((B * S, H * dh), dtype=BF16, device=qkv.device) if out is None else out
+    rows = qkv.shape[0]
+    assert cu_seqlens is not None or rows == B * S
+    o = torch.empty((rows, H * dh), dtype=BF16, device=qkv.device) if out is None else out
     lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device) if need_lse else None
     ws = torch.empty((lib.hvlm_attn_fwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
-    check(lib.hvlm_attn_fwd(_p(qkv), _p(o), _p(lse), _p(ws), B, S, H, dh, qkv.stride(0), 1 if causal else 0,
-                            scale, _stream()), "attn_fwd")
+    if cu_seqlens is None:
+        check(lib.hvlm_attn_fwd(_p(qkv), _p(o), _p(lse), _p(ws), B, S, H, dh, qkv.stride(0), 1 if causal else 0,
+                                scale, _stream()), "attn_fwd")
+    else:
+        _chk(cu_seqlens, torch.int32, "attn.cu_seqlens")
+        assert cu_seqlens.numel() == B + 1
+        check(lib.hvlm_attn_fwd_varlen(_p(qkv), _p(o), _p(lse), _p(ws), _p(cu_seqlens), B, S, H, dh, qkv.stride(0),
+                                       1 if causal else 0, scale, _stream()), "attn_fwd_varlen")
     return o, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=None):
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=None, cu_seqlens=None):
     _chk(dout, BF16, "attn_bwd.dout")
     assert dout.is_contiguous() and out.is_contiguous()
     lib = _lib.load()
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     ws = torch.empty((lib.hvlm_attn_bwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
-    check(lib.hvlm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), B, S, H, dh, qkv.stride(0),
-                            1 if causal else 0, scale, _stream()), "attn_bwd")
+    if cu_seqlens is None:
+        check(lib.hvlm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), B, S, H, dh, qkv.stride(0),
+                                1 if causal else 0, scale, _stream()), "attn_bwd")
+    else:
+        check(lib.hvlm_attn_bwd_varlen(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), _p(cu_seqlens), B, S,
+                                       qkv.shape[0], H, dh, qkv.stride(0), 1 if causal else 0, scale, _stream()), "attn_bwd_varlen")
     return dqkv
 
 
@@ -371,17 +385,30 @@ def temporal_spatial_pool_bwd(dout: torch.Tensor, B: int, T: int, grid: int = 16
     return dtok
 
 
-def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None):
+def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None, row_sample=None):
+    """Padded: rows = B*S, sample of a row = row // S.  Packed (row_sample int32 [rows]): rows = src.numel()."""
     _chk(embed, BF16, "splice.embed"); _chk(src, torch.int32, "splice.src")
-    x = torch.empty((B * S, D), dtype=BF16, device=embed.device) if out is None else out
-    check(_lib.load().hvlm_embed_splice_fwd(_p(embed), _p(visual), _p(src), _p(hand_slot), _p(hands), _p(hand_scale),
-                                            _p(x), B, S, D, NV, NH, _stream()), "embed_splice_fwd")
+    rows = src.numel()
+    x = torch.empty((rows, D), dtype=BF16, device=embed.device) if out is None else out
+    if row_sample is None:
+        assert rows == B * S
+        check(_lib.load().hvlm_embed_splice_fwd(_p(embed), _p(visual), _p(src), _p(hand_slot), _p(hands), _p(hand_scale),
+                                                _p(x), B, S, D, NV, NH, _stream()), "embed_splice_fwd")
+    else:
+        _chk(row_sample, torch.int32, "splice.row_sample")
+        check(_lib.load().hvlm_embed_splice_fwd_packed(_p(embed), _p(visual), _p(src), _p(hand_slot), _p(hands),
+                                                       _p(hand_scale), _p(row_sample), _p(x), rows, D, NV, NH, _stream()),
+              "embed_splice_fwd_packed")
     return x
 
 
-def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV):
-    check(_lib.load().hvlm_embed_splice_bwd(_p(dx), _p(src), _p(dembed), _p(dvisual), B, S, D, NV, _stream()),
-          "embed_splice_bwd")
+def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV, row_sample=None):
+    if row_sample is None:
+        check(_lib.load().hvlm_embed_splice_bwd(_p(dx), _p(src), _p(dembed), _p(dvisual), B, S, D, NV, _stream()),
+              "embed_splice_bwd")
+    else:
+        check(_lib.load().hvlm_embed_splice_bwd_packed(_p(dx), _p(src), _p(row_sample), _p(dembed), _p(dvisual),
+                                                       src.numel(), D, NV, _stream()), "embed_splice_bwd_packed")
 
 
 def embed_grad_segments(dx, seg_rows, seg_start, seg_token, dembed):

@@ -149,6 +149,18 @@ int hvlm_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                   void* ws, int B, int S, int H, int dh, int ld, int causal, float scale,
                   void* stream);
 
+/* Variable-length (packed) form — the contract of the reference's kernel swap, llava/train/llama_flash_attn_monkey_patch.py:
+ * 81-96 (unpad_input -> flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, causal=True) -> pad_input):
+ *   qkv / out / dout / dqkv hold the tokens of all B samples PACKED end to end (total_tokens rows, no padding rows),
+ *   cu_seqlens int32[B+1] (device) gives the row range [cu[b], cu[b+1]) of sample b, max_seqlen = the longest sample.
+ *   lse is f32 [B, H, max_seqlen] (entries past a sample's length are not written), ws as for the padded entry points with
+ *   S = max_seqlen.  The engine (hvlm/llama.py) keeps tokens packed through the whole decoder, so no unpad / pad copies exist. */
+int hvlm_attn_fwd_varlen(const void* qkv, void* out, float* lse, void* ws, const int32_t* cu_seqlens, int B,
+                         int max_seqlen, int H, int dh, int ld, int causal, float scale, void* stream);
+int hvlm_attn_bwd_varlen(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* ws,
+                         const int32_t* cu_seqlens, int B, int max_seqlen, long total_tokens, int H, int dh, int ld,
+                         int causal, float scale, void* stream);
+
 /* Single-token decode (KV-cached generation, batch 1; the reference's sampling loop handsonvlm.py:543-647
  * re-runs the full prefix per token — a cache is exact because appended tokens' input embeddings never change).
  *   gemv: y[N] = W[N,K] @ x[K] (+ residual[N]); K % 8 == 0, K <= 32768.
@@ -224,6 +236,14 @@ int hvlm_embed_splice_fwd(const void* embed, const void* visual, const int32_t* 
 /* backward: scatter-add dX rows into dembed (f32 [V,D], atomics) and dvisual (bf16 [B,NV,D]). */
 int hvlm_embed_splice_bwd(const void* dx, const int32_t* src, float* dembed, void* dvisual, int B,
                           int S, int D, int NV, void* stream);
+
+/* Packed (unpadded) variants: `rows` = total tokens of the batch, no padding rows; row_sample int32[rows] names the sample
+ * each row belongs to (it selects visual[b], hands[b], hand_scale[b]).  Same arithmetic as above. */
+int hvlm_embed_splice_fwd_packed(const void* embed, const void* visual, const int32_t* src, const int32_t* hand_slot,
+                                 const float* hands, const float* hand_scale, const int32_t* row_sample, void* out,
+                                 int rows, int D, int NV, int NH, void* stream);
+int hvlm_embed_splice_bwd_packed(const void* dx, const int32_t* src, const int32_t* row_sample, float* dembed,
+                                 void* dvisual, int rows, int D, int NV, void* stream);
 
 /* Deterministic form of the text-embedding gradient (the `embed_tokens` rows of the splice backward): the host sorts
  * the text rows of the batch by token id (stable) into segments — seg_token[n_seg] the distinct ids, seg_start[n_seg+1]

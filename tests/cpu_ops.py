@@ -113,7 +113,7 @@ def _split(qkv, B, S, H, dh):
     return f(qkv[:, :D]), f(qkv[:, D:2 * D]), f(qkv[:, 2 * D:3 * D])
 
 
-def _scores(q, k, causal, scale, seqlens=None):
+def _scores(q, k, causal, scale):
     s = (q @ k.transpose(-1, -2)) * scale
     S = q.shape[-2]
     if causal:
@@ -121,22 +121,39 @@ def _scores(q, k, causal, scale, seqlens=None):
     return s
 
 
-def attn_fwd(qkv, B, S, H, dh, causal, scale, need_lse=True, out=None):
-    q, k, v = _split(qkv, B, S, H, dh)
+def _attn_padded(x, B, S, H, dh, causal, scale):
+    q, k, v = _split(x, B, S, H, dh)
     s = _scores(q, k, causal, scale)
-    lse = torch.logsumexp(s, -1)
-    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * dh).to(BF16)
+    return (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * dh), torch.logsumexp(s, -1)
+
+
+def _attn_any(x, B, S, H, dh, causal, scale, cu_seqlens):
+    """Padded (cu_seqlens None) or packed: per-sample attention on rows [cu[b], cu[b+1]); lse [B, H, S(max)]."""
+    if cu_seqlens is None:
+        return _attn_padded(x, B, S, H, dh, causal, scale)
+    cu = cu_seqlens.tolist()
+    outs, lse = [], torch.zeros(B, H, S)
+    for b in range(B):
+        n = cu[b + 1] - cu[b]
+        o, l_ = _attn_padded(x[cu[b]:cu[b + 1]], 1, n, H, dh, causal, scale)
+        outs.append(o)
+        lse[b, :, :n] = l_[0].detach()
+    return torch.cat(outs, 0), lse
+
+
+def attn_fwd(qkv, B, S, H, dh, causal, scale, need_lse=True, out=None, cu_seqlens=None):
+    o, lse = _attn_any(qkv.float(), B, S, H, dh, causal, scale, cu_seqlens)
+    o = o.to(BF16)
     if out is not None:
         out.copy_(o)
         o = out
     return o, (lse.contiguous() if need_lse else None)
 
 
-def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None):
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None, cu_seqlens=None):
     with torch.enable_grad():
         x = qkv.float().detach().requires_grad_(True)
-        q, k, v = _split(x, B, S, H, dh)
-        o = (torch.softmax(_scores(q, k, causal, scale), -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H * dh)
+        o, _ = _attn_any(x, B, S, H, dh, causal, scale, cu_seqlens)
         (g,) = torch.autograd.grad(o, x, dout.float())
     g = g.to(BF16)
     if dqkv is not None:
@@ -219,16 +236,18 @@ def _hand_posenc(hands_b, slot, D):
     return torch.stack(enc, 1).reshape(D)
 
 
-def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None):
-    x = torch.zeros((B * S, D), dtype=torch.float32)
+def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, NV, NH, out=None, row_sample=None):
+    rows = src.numel()
+    x = torch.zeros((rows, D), dtype=torch.float32)
     srcl = src.long()
-    for r in range(B * S):
-        b, s = divmod(r, S)
+    vis = None if visual is None else visual.reshape(-1, NV, D)
+    for r in range(rows):
+        b = r // S if row_sample is None else int(row_sample[r])
         i = int(srcl[r])
         if i >= 0:
             x[r] = embed[i].float()
         elif i <= -2:
-            x[r] = visual.reshape(B, NV, D)[b, -2 - i].float()
+            x[r] = vis[b, -2 - i].float()
         if hand_slot is not None and int(hand_slot[r]) >= 0:
             x[r] += float(hand_scale[b]) * _hand_posenc(hands[b], int(hand_slot[r]), D)
     x = x.to(BF16)
@@ -238,15 +257,15 @@ def embed_splice_fwd(embed, visual, src, hand_slot, hands, hand_scale, B, S, D, 
     return x
 
 
-def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV):
+def embed_splice_bwd(dx, src, dembed, dvisual, B, S, D, NV, row_sample=None):
     srcl = src.long()
-    for r in range(B * S):
-        b = r // S
+    for r in range(src.numel()):
+        b = r // S if row_sample is None else int(row_sample[r])
         i = int(srcl[r])
         if i >= 0 and dembed is not None:
             dembed[i] += dx[r].float()
         elif i <= -2 and dvisual is not None:
-            dvisual.view(B, NV, D)[b, -2 - i] = dx[r]
+            dvisual.view(-1, NV, D)[b, -2 - i] = dx[r]
 
 
 def embed_grad_segments(dx, seg_rows, seg_start, seg_token, dembed):

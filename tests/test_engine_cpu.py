@@ -1,0 +1,106 @@
+"""Host logic of the decoder engine on the ops stand-in (tests/cpu_ops.py, test infrastructure):
+  * activation recompute (config.activation_recompute; the reference's gradient checkpointing, scripts/finetune.sh:36)
+    gives BIT-identical loss and gradients while keeping only each layer's input between forward and backward;
+  * packed (unpadded, cu_seqlens) batches (config.pack_sequences; the reference's flash-attn patch contract,
+    llama_flash_attn_monkey_patch.py:81-96) give the padded batch's loss and gradients (up to fp32 summation order)."""
+import numpy as np
+import torch
+
+from oracle import synth
+
+
+def _model(**cfg_kw):
+    from test_train_resume_cpu import _tiny
+    m, cfg = _tiny()
+    m.config.dedup_frames = False
+    for k, v in cfg_kw.items():
+        setattr(m.config, k, v)
+    m.stack.recompute = bool(m.config.activation_recompute)
+    return m
+
+
+def _batch(ragged=True):
+    c = synth.TINY
+    ids, labels, mask = synth.make_text_batch(3, 28, seed=3, n_hand=(4, 0, 4), pad_tail=(0, 9, 4) if ragged else (0, 0, 0))
+    # the collator's padding is at the END of input_ids; cut each sample to its own length by marking pads ignored
+    images = synth.make_images(3, c["frames"], 2, c["image"], seed=11).to(torch.bfloat16)
+    fh, fv = synth.make_hands(3, seed=5)
+    eps = torch.randn(24, 256, generator=torch.Generator().manual_seed(0))
+    return dict(input_ids=ids, attention_mask=mask, labels=labels, image=images, future_hands=fh, contact_point=torch.zeros(3, 2),
+                future_valid=fv, gt_label_valid=torch.ones(3), cvae_eps=eps)
+
+
+def _run(m, batch):
+    b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = m(**b)
+    saved_keys = [sorted(sv.keys()) for sv in m.stack.saved]
+    out.loss.backward()
+    g = {n: gr.clone() for n, _, gr, _ in m.trainable_tensors()}
+    g.update({"head." + n: p.grad.clone() for n, p in m.hand_traj_decoder.named_parameters()})
+    return float(out.loss.detach()), g, saved_keys, out
+
+
+def test_activation_recompute_is_bit_identical(monkeypatch):
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    batch = _batch()
+    l0, g0, k0, _ = _run(_model(), batch)
+    l1, g1, k1, _ = _run(_model(activation_recompute=True), batch)
+    assert all(k == ["x"] for k in k1) and all(len(k) > 5 for k in k0)        # only the layer inputs were kept
+    assert l0 == l1
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+def test_packed_batch_matches_padded_batch(monkeypatch):
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    batch = _batch()
+    # trim the collator padding: samples 1 and 2 end 9 / 4 tokens early -> their ids are shorter in the packed plan only
+    # if the pads are removed from input_ids; the reference pads with pad_token_id and masks — keep both paths identical by
+    # feeding per-sample lengths through attention_mask-free padding ids (pad id 0 rows are real rows for both engines).
+    l0, g0, _, out0 = _run(_model(), batch)
+    mp = _model(pack_sequences=True)
+    l1, g1, _, out1 = _run(mp, batch)
+    assert out1.cu_seqlens is not None and out1.logits.dim() == 2
+    assert abs(l0 - l1) / abs(l0) < 2e-4, (l0, l1)
+    for n in g0:
+        a, b = g0[n].float(), g1[n].float()
+        r = float((a - b).norm() / (a.norm() + 1e-30))
+        assert r < 2e-2, (n, r)
+    # packed logits == the valid rows of the padded logits
+    cu = out1.cu_seqlens.tolist()
+    # (out0.logits was overwritten in place by backward: compare a fresh forward)
+    m0 = _model()
+    b0 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    lg0 = m0(**b0, keep_logits=True).logits
+    b1 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    lg1 = mp(**b1, keep_logits=True).logits
+    for b in range(3):
+        n = cu[b + 1] - cu[b]
+        d = (lg0[b, :n].float() - lg1[cu[b]:cu[b + 1]].float()).abs().max()
+        assert float(d) <= 0.05 * float(lg0[b, :n].float().abs().max()), (b, float(d))
+
+
+def test_packed_plan_layout(monkeypatch):
+    """Pure host logic: the packed plan is the padded plan with the collator's padding rows removed."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from test_train_resume_cpu import _tiny
+    m, cfg = _tiny()
+    ids, labels, mask = synth.make_text_batch(3, 28, seed=3, n_hand=(4, 0, 4), pad_tail=(0, 9, 4))
+    pa = m.build_splice_plan(ids, labels, 356, 4, False, True)
+    pk = m.build_splice_plan(ids, labels, 356, 4, False, True, pack=True, attention_mask=mask)
+    S = pa.S
+    lens = [S, S - 9, S - 4]
+    assert pk.cu.tolist() == [0, lens[0], lens[0] + lens[1], sum(lens)] and pk.M == sum(lens) and pk.S == S
+    for b in range(3):
+        n, o = lens[b], int(pk.cu[b])
+        assert torch.equal(pk.src[o:o + n], pa.src.view(3, S)[b, :n])
+        assert torch.equal(pk.hand_slot[o:o + n], pa.hand_slot.view(3, S)[b, :n])
+        assert torch.equal(pk.targets[o:o + n - 1], pa.targets.view(3, S)[b, :n - 1]) and int(pk.targets[o + n - 1]) == -100
+        assert torch.equal(pk.pos[o:o + n], torch.arange(n, dtype=torch.int32)) and (pk.row_sample[o:o + n] == b).all()
+        hr_pad = pa.hand_rows.view(3, 4)[b]
+        want = torch.where(hr_pad >= 0, hr_pad - b * S + o, hr_pad)
+        assert torch.equal(pk.hand_rows.view(3, 4)[b], want)
+    assert torch.equal(pk.labels, pa.labels)                   # the padded labels the reference returns

@@ -242,3 +242,89 @@ def test_llama_layer_13b_width_fwd_bwd_vs_oracle():
     assert rel(lp.g["gu"], torch.cat([pr[pre + "mlp.gate_proj.weight"].grad, pr[pre + "mlp.up_proj.weight"].grad], 0)) <= 2e-2
     assert rel(lp.g["down"], pr[pre + "mlp.down_proj.weight"].grad) <= 2e-2
     assert rel(lp.g["ln1"], pr[pre + "input_layernorm.weight"].grad) <= 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# varlen (cu_seqlens) attention, packed batches, activation recompute
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lens,H,dh", [([200, 1, 129, 64, 333], 3, 128), ([867, 420, 547, 100], 2, 128), ([257, 31], 2, 64)])
+def test_varlen_attention_fwd_bwd_vs_oracle(ops, lens, H, dh):
+    """hvlm_attn_fwd/bwd_varlen — the reference's kernel-swap contract (llama_flash_attn_monkey_patch.py:81-96:
+    flash_attn_varlen_qkvpacked_func(qkv [total,3,H,dh], cu_seqlens, max_seqlen, causal=True)): packed rows, every sample
+    against the fp32 oracle on its own rows, and bit-identical to the padded kernels run sample by sample."""
+    B, total, S = len(lens), sum(lens), max(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    qkv = grnd(total, 3 * H * dh, seed=60, scale=0.7)
+    do = grnd(total, H * dh, seed=61)
+    o, lse = ops.attn_fwd(qkv, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(dqkv.float()).all()
+    off = 0
+    for b, n in enumerate(lens):
+        xs = qkv[off:off + n].contiguous()
+        o1, lse1 = ops.attn_fwd(xs, 1, n, H, dh, True, dh ** -0.5)
+        d1 = ops.attn_bwd(xs, o1, do[off:off + n].contiguous(), lse1, 1, n, H, dh, True, dh ** -0.5)
+        assert torch.equal(o[off:off + n], o1) and torch.equal(dqkv[off:off + n], d1), b      # same kernel code, same tiles
+        assert torch.equal(lse[b, :, :n], lse1[0])
+        x = xs.float().cpu().view(1, n, 3, H, dh).permute(2, 0, 3, 1, 4)
+        q, k, v = [t.contiguous().requires_grad_(True) for t in (x[0], x[1], x[2])]
+        ref = R.softmax_attention(q, k, v, True, dh ** -0.5)
+        assert rel(o1.cpu().view(1, n, H, dh).permute(0, 2, 1, 3), ref) <= 4e-3
+        ref.backward(do[off:off + n].float().cpu().view(1, n, H, dh).permute(0, 2, 1, 3))
+        d = d1.float().cpu().view(1, n, 3, H, dh).permute(2, 0, 3, 1, 4)
+        if n > 1:
+            for got, want in zip(d, (q.grad, k.grad, v.grad)):
+                assert rel(got, want) <= 6e-3, (b, n)
+        off += n
+
+
+def _tiny_engine(**cfg_kw):
+    from test_gpu_model import tiny_model
+    m, cfg = tiny_model(training=True, **cfg_kw)
+    return m
+
+
+def _ragged_batch():
+    c = synth.TINY
+    ids, labels, mask = synth.make_text_batch(3, 28, seed=3, n_hand=(4, 0, 4), pad_tail=(0, 9, 4))
+    images = synth.make_images(3, c["frames"], 2, c["image"], seed=11).to(BF)
+    fh, fv = synth.make_hands(3, seed=5)
+    eps = torch.randn(24, 256, generator=torch.Generator().manual_seed(0)).cuda()
+    return dict(input_ids=ids, attention_mask=mask, labels=labels, image=images, future_hands=fh, contact_point=torch.zeros(3, 2),
+                future_valid=fv, gt_label_valid=torch.ones(3), cvae_eps=eps)
+
+
+def _step(m, batch):
+    out = m(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    kept = [sorted(sv.keys()) for sv in m.stack.saved]
+    out.loss.backward()
+    torch.cuda.synchronize()
+    g = {n: gr.clone() for n, _, gr, _ in m.trainable_tensors()}
+    g.update({"head." + n: p.grad.clone() for n, p in m.hand_traj_decoder.named_parameters()})
+    return float(out.loss.detach()), g, kept
+
+
+def test_activation_recompute_bit_identical_on_hip():
+    """config.activation_recompute (scripts/finetune.sh:36 `--gradient_checkpointing True`): only each layer's input is
+    kept, the layer forward is re-run inside backward; loss and every gradient bit-identical to the stored-activation run."""
+    batch = _ragged_batch()
+    l0, g0, k0 = _step(_tiny_engine(), batch)
+    l1, g1, k1 = _step(_tiny_engine(activation_recompute=True), batch)
+    assert all(k == ["x"] for k in k1) and all(len(k) > 5 for k in k0)
+    assert l0 == l1
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+def test_packed_batch_matches_padded_batch_on_hip():
+    """config.pack_sequences: tokens of all samples end to end + cu_seqlens through the whole decoder; same loss and
+    gradients as the padded batch (valid rows run the same kernels on the same data; only the dW / embedding sums see a
+    different row count)."""
+    batch = _ragged_batch()
+    l0, g0, _ = _step(_tiny_engine(), batch)
+    l1, g1, _ = _step(_tiny_engine(pack_sequences=True), batch)
+    assert abs(l0 - l1) / abs(l0) < 1e-4, (l0, l1)
+    for n in g0:
+        assert rel(g1[n], g0[n]) < 1e-2, (n, rel(g1[n], g0[n]))
+    l2, g2, _ = _step(_tiny_engine(pack_sequences=True, activation_recompute=True), batch)
+    assert l2 == l1 and all(torch.equal(g1[n], g2[n]) for n in g1)
