@@ -51,11 +51,16 @@ def parse():
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
-    ap.add_argument("--recompute", action="store_true",
-                    help="activation recompute (scripts/finetune.sh:36): keep only each layer's input, re-run its forward in backward")
+    ap.add_argument("--recompute", nargs="?", const=-1, default=0, type=int, metavar="N",
+                    help="activation recompute (scripts/finetune.sh:36): keep only the layer input and re-run the layer forward in "
+                         "backward, for the first N layers (no value: all layers)")
     ap.add_argument("--varlen", default=None, metavar="LO:HI",
                     help="per-sample prompt lengths T ~ U{LO..HI} (SURVEY §8d config 3: 64:192), right-padded by the collator")
     ap.add_argument("--pack", action="store_true", help="packed (unpadded, cu_seqlens) rows through the whole decoder")
+    ap.add_argument("--fp8-eval", action="store_true",
+                    help="BASELINE config 5 instead of the SFT step: batch evaluation (CLIP on 8-frame clips tiled to 100 -> fp8 e4m3 "
+                         "decoder prefill -> lm_head -> 12 generated tokens with 4 decoded hands), eval samples/s")
+    ap.add_argument("--eval-batch", type=int, default=32)
     ap.add_argument("--layers", type=int, default=None, help="debug only: override layer count (marks result invalid)")
     return ap.parse_args()
 
@@ -73,7 +78,7 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
-    cfg.activation_recompute = args.recompute
+    cfg.activation_recompute = True if args.recompute < 0 else args.recompute
     cfg.pack_sequences = args.pack
     cfg.vision.image_size = args.image_size
     return cfg
@@ -355,10 +360,93 @@ def spawn_ranks(args):
     return rc
 
 
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense fp8 MFMA peak, MI355X_MICROARCH.md
+
+
+def fp8_eval_main(args, real_stdout):
+    """BASELINE config 5: HandsOnVLM-7B fp8 (CDNA4 e4m3 scaled MFMA) forward, 8-frame video input, batch-32 evaluation
+    throughput.  One "step" = one batch of `--eval-batch` samples evaluated end to end the way the reference evaluates a
+    sample (handsonvlm_inference.py:99-113) — CLIP on the 100 frames of every sample (8 distinct frames tiled), projector,
+    splice, decoder prefill of the 512-token prompt, then 12 generated tokens of which 4 are <hand_traj> (each decoded by the
+    CVAE head and fed back) — but B samples in lock step (model.sample_batch) with the QKV / O / gate|up / down GEMMs of the
+    prefill on e4m3 operands (per-token activation scales, per-output-channel weight scales) and everything else in bf16.
+    Reported beside it: the same batch in bf16, and both with exact frame de-duplication."""
+    from hvlm import ops
+    from hvlm.model import HandsOnVLMForCausalLM
+    from hvlm.synthetic import make_text_batch_np
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    cfg = make_config(args)
+    B, T = args.eval_batch, args.text_len
+    model = HandsOnVLMForCausalLM(cfg, device=device, training=False).init_random(seed=0)
+    ids, _ = make_text_batch_np(B, T, 7, n_hand=0)
+    ids = torch.from_numpy(ids)
+    g = torch.Generator(device=device).manual_seed(7)
+    base = torch.randn(B, 8, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
+    img = base[:, torch.arange(cfg.num_frames, device=device) % 8].contiguous()
+    forced = [11, 12, 32100, 13, 32100, 14, 32100, 15, 32100, 16, 17, 2]
+
+    def force(cur, scores):
+        s_ = torch.full_like(scores, -1e9)
+        s_[:, forced[cur.shape[1] - T]] = 0.0
+        return s_
+
+    ev = GemmEvents()
+    ops.set_gemm_hook(ev)
+
+    def run(fp8, dedup, steps, warmup):
+        model.config.dedup_frames = dedup
+        for _ in range(warmup):
+            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8)
+        torch.cuda.synchronize()
+        ev.pairs, ev.kernels, ev.enabled = [], 0, True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ev.enabled = False
+        assert out.num_hands == [4] * B and out.lengths == [T + len(forced)] * B
+        # fp8 GEMM launches of the timed region = the K % 128 == 0 decoder GEMMs at M = B*S (prefill)
+        S = T + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
+        pre = [(a, b, f) for a, b, f, shp in ev.pairs if shp[0] == B * S and shp[1] != cfg.vocab_padded]
+        ms = sum(a.elapsed_time(b) for a, b, _ in pre)
+        fl = sum(f for _, _, f in pre)
+        return dt, (fl / (ms * 1e-3) / 1e12 if ms > 0 else None), (ms / max(1, len(pre)) * 1e3), fl / max(1, len(pre)) / 1e9, len(pre) // steps
+
+    steps, warm = max(1, args.steps), max(1, args.warmup)
+    dt8, tf8, us8, gf8, n8 = run(True, False, steps, warm)
+    dt16, tf16, _, _, _ = run(False, False, steps, warm)
+    dt8d, _, _, _, _ = run(True, True, steps, warm)
+    dt16d, _, _, _, _ = run(False, True, steps, warm)
+    S = T + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
+    flops = B * (model.stack.flops_forward(1, S, 0) + cfg.num_frames * model.tower.flops_per_frame())
+    res = {"metric": "eval samples/sec HandsOnVLM-7B fp8 forward (batch evaluation)", "value": B / dt8, "unit": "samples/s", "n_gpus": 1,
+           "steps": steps, "warmup": warm, "ms_per_step": dt8 * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp8 e4m3 (decoder prefill GEMMs) + bf16", "data": "synthetic",
+           "config": {"workload": f"eval_batch{B}_T{T}_S{S}_8frames_tiled_to_{cfg.num_frames}_12new_tokens_4hands_fp8", "global_batch": B,
+                      "seq_len": S, "parallelism": "dp1", "frames_through_clip_per_sample": cfg.num_frames,
+                      "weight_scales": "per output channel", "activation_scales": "per token (dynamic)"},
+           "prefill_plus_clip_tflop_algorithmic": flops / 1e12,
+           "bf16_same_batch": {"samples_per_s": B / dt16, "ms_per_batch": dt16 * 1e3, "decoder_gemm_tflops": tf16},
+           "dedup_clip": {"fp8_samples_per_s": B / dt8d, "bf16_samples_per_s": B / dt16d,
+                          "note": "CLIP once per distinct frame (8 of 100 per sample), bit-identical visual tokens"},
+           "roofline": {"bound": "mfma", "kernel": "gemm_pp4_fp8_kernel", "achieved": tf8, "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": None if tf8 is None else tf8 / MFMA_FP8_PEAK_TFLOPS, "traffic": None, "launches_per_step": n8,
+                        "avg_launch_us": us8, "avg_launch_gflop": gf8},
+           "peak_mem_gib": torch.cuda.max_memory_allocated(device) / 2 ** 30}
+    os.write(real_stdout, (json.dumps(res) + "\n").encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         sys.exit(spawn_ranks(args))
+    if args.fp8_eval:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+        return fp8_eval_main(args, real_stdout)
     # exactly ONE line on stdout (the JSON): libraries that print to stdout (RCCL's "Librccl path : ..." banner, the CPU
     # oracle's progress) are sent to stderr by swapping file descriptor 1 for the duration of the run
     sys.stdout.flush()
@@ -453,7 +541,7 @@ def main():
                                    + ("_recompute" if args.recompute else ""),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "frames_through_clip_per_sample": n_frames // B,
-                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": bool(args.recompute),
+                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
                        "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",
                        "packed_rows": bool(args.pack)},
             "step_tflop_algorithmic": step_flops / 1e12,

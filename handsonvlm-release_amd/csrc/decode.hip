@@ -405,6 +405,87 @@ static int gemv_pre(const void* W, const void* x, void* y, const void* residual,
   return check_launch("gemv");
 }
 
+// Batched form of attn_decode_kernel for lock-step generation of B samples (BASELINE config 5: batch-32 evaluation):
+// grid (H, B); sample b has its own query row, its own cache slab (sample_stride elements apart) and its own length
+// lens[b] (device int32: keys 0 .. lens[b]-1, the new token's key included).  Same three phases as the batch-1 kernel.
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_batched_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                                  const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                                                  long sample_stride, const int32_t* __restrict__ lens,
+                                                                  bf16_t* __restrict__ out, int ldo, int ld, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);          // [DH]
+  float* red = qs + DH;                                  // [8]
+  float* part = red + 8;                                 // [G][DH] partial outputs
+  constexpr int CP = DH / 2;
+  constexpr int G = 256 / CP;
+  float* sc = part + G * DH;                             // [S] scores / probabilities
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int S = lens[b];
+  kc += (long)b * sample_stride;
+  vc += (long)b * sample_stride;
+  if (t < DH) qs[t] = bf2f(q[(long)b * ldq + h * DH + t]) * scale;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int s0 = t; s0 < S; s0 += 256) {
+    const bf16_t* kp = kc + (size_t)s0 * ld + h * DH;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 8) {
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += bf_lo(kv[e]) * qs[c + 2 * e] + bf_hi(kv[e]) * qs[c + 2 * e + 1];
+    }
+    sc[s0] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = block_max<4>(mx, red);
+  float sum = 0.f;
+  for (int s0 = t; s0 < S; s0 += 256) {
+    const float p = __expf(sc[s0] - mx);
+    sc[s0] = p;
+    sum += p;
+  }
+  sum = block_sum<4>(sum, red + 4);
+  __syncthreads();
+  const int cp = t % CP, g = t / CP;
+  float a0 = 0.f, a1 = 0.f;
+  const bf16_t* vbase = vc + h * DH + 2 * cp;
+#pragma unroll 8
+  for (int s0 = g; s0 < S; s0 += G) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(vbase + (size_t)s0 * ld);
+    const float p = sc[s0];
+    a0 += p * bf_lo(v);
+    a1 += p * bf_hi(v);
+  }
+  part[g * DH + 2 * cp] = a0;
+  part[g * DH + 2 * cp + 1] = a1;
+  __syncthreads();
+  if (t < DH) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < G; ++i) acc += part[i * DH + t];
+    out[(long)b * ldo + h * DH + t] = f2bf(acc / sum);
+  }
+}
+
+extern "C" int hvlm_attn_decode_batched(const void* q, int ldq, const void* k_cache, const void* v_cache, long sample_stride,
+                                        const int32_t* lens, void* out, int ldo, int B, int max_S, int H, int dh, int ld,
+                                        float scale, void* stream) {
+  HVLM_REQUIRE(q && k_cache && v_cache && lens && out, "attn_decode_batched: null pointer");
+  HVLM_REQUIRE(B > 0 && max_S > 0 && H > 0 && ld >= H * dh && ldq >= H * dh && ldo >= H * dh, "attn_decode_batched: bad shape");
+  HVLM_REQUIRE(dh == 64 || dh == 128, "attn_decode_batched: dh must be 64 or 128 (got %d)", dh);
+  const size_t lds = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + max_S) * 4;
+  HVLM_REQUIRE(lds <= 64 * 1024, "attn_decode_batched: max_S=%d too long for the LDS score buffer", max_S);
+  if (dh == 128)
+    hipLaunchKernelGGL((attn_decode_batched_kernel<128>), dim3(H, B), dim3(256), lds, as_stream(stream), (const bf16_t*)q, ldq,
+                       (const bf16_t*)k_cache, (const bf16_t*)v_cache, sample_stride, lens, (bf16_t*)out, ldo, ld, scale);
+  else
+    hipLaunchKernelGGL((attn_decode_batched_kernel<64>), dim3(H, B), dim3(256), lds, as_stream(stream), (const bf16_t*)q, ldq,
+                       (const bf16_t*)k_cache, (const bf16_t*)v_cache, sample_stride, lens, (bf16_t*)out, ldo, ld, scale);
+  return check_launch("attn_decode_batched");
+}
+
 extern "C" int hvlm_gemv_bf16(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw,
                               void* stream) {
   HVLM_REQUIRE(W && x && y, "gemv: null pointer");

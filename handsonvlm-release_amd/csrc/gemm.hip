@@ -668,9 +668,74 @@ extern "C" int hvlm_quantize_fp8(const void* x, void* out, const float* scale_de
   return check_launch("quantize_fp8");
 }
 
+namespace hvlm {
+namespace {
+// Per-row (per-token / per-output-channel) quantisation: s = 448 / amax(row); out = e4m3(x * s); inv_scale[row] = amax / 448.
+// One workgroup per row; the row is read twice (amax, then convert) — the second read hits L2.
+__global__ __launch_bounds__(256) void quantize_fp8_rowwise_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ out,
+                                                                   float* __restrict__ inv_scale, int K, long ldx, long ldo) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  const bf16_t* xr = x + row * ldx;
+  float mx = 0.f;
+  for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(bf_lo(v[e])), fabsf(bf_hi(v[e]))));
+  }
+  mx = block_max<4>(mx, red);
+  const float amax = fmaxf(mx, 1e-12f);
+  const float sc = 448.f / amax;
+  if (threadIdx.x == 0) inv_scale[row] = amax / 448.f;
+  unsigned char* orow = out + row * ldo;
+  for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + i);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = bf_lo(v[e]) * sc; f[2 * e + 1] = bf_hi(v[e]) * sc; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], -448.f), 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    const u32x2 o = {lo, hi};
+    *reinterpret_cast<u32x2*>(orow + i) = o;
+  }
+}
+}  // namespace
+}  // namespace hvlm
+
+extern "C" int hvlm_quantize_fp8_rowwise(const void* x, void* out, float* inv_scale, int rows, int K, int ldx, int ldo,
+                                         void* stream) {
+  HVLM_REQUIRE(x && out && inv_scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ldx >= K && ldo >= K,
+               "quantize_fp8_rowwise: bad args (K, ldx, ldo multiples of 8)");
+  HVLM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0, "quantize_fp8_rowwise: alignment");
+  hipLaunchKernelGGL(quantize_fp8_rowwise_kernel, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                     (unsigned char*)out, inv_scale, K, (long)ldx, (long)ldo);
+  return check_launch("quantize_fp8_rowwise");
+}
+
+static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                         const void* residual, int ldr, int act, int out_f32, void* stream);
+
 extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                 float alpha, const void* bias, const void* residual, int ldr, int act, int out_f32,
                                 void* stream) {
+  return gemm_fp8_impl(A, B, C, M, N, K, lda, ldb, ldc, alpha, nullptr, nullptr, bias, residual, ldr, act, out_f32, stream);
+}
+
+extern "C" int hvlm_gemm_fp8_nt_scaled(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                       float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                                       const void* residual, int ldr, int act, int out_f32, void* stream) {
+  return gemm_fp8_impl(A, B, C, M, N, K, lda, ldb, ldc, alpha, row_scale, col_scale, bias, residual, ldr, act, out_f32, stream);
+}
+
+static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                         float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                         const void* residual, int ldr, int act, int out_f32, void* stream) {
   HVLM_REQUIRE(A && B && C, "gemm_fp8: null operand");
   HVLM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128", K);
   HVLM_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 4 == 0, "gemm_fp8: bad leading dimensions");
@@ -683,6 +748,7 @@ extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, in
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
   p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0; p.dbg = 0;
+  p.row_scale = row_scale; p.col_scale = col_scale;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;

@@ -16,6 +16,8 @@ struct GemmArgs {
   int dyn;                      // gemm_pp: 0 = static tile assignment, s+1 = dynamic scheduling on state slot s (pp_sched_slot)
   int dbg;                      // development ablations (HVLM_GEMM_DBG), 0 in production
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
+  const float* row_scale = nullptr;   // fp8 kernel only, optional: C[m, :] *= row_scale[m]  (per-token activation de-scale)
+  const float* col_scale = nullptr;   // fp8 kernel only, optional: C[:, n] *= col_scale[n]  (per-output-channel weight de-scale)
 };
 
 // gemm_pp.hip: 8-phase ping-pong kernel (persistent 256x256 tiles); grid = workgroups to launch.

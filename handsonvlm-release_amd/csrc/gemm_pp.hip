@@ -691,12 +691,27 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       t_aft_v = __hip_atomic_load(&g_pp.slots[blockIdx.x][(it + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (FP8) {
+      // de-quantisation: tensor scale (alpha) x per-token scale of the row x per-output-channel scale of the column
+      float rs[4] = {p.alpha, p.alpha, p.alpha, p.alpha};
+      if (p.row_scale) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rs[i] *= p.row_scale[min(row_of(m0, i), p.M - 1)];
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float cs[4] = {1.f, 1.f, 1.f, 1.f};
+          if (p.col_scale) {
+            const int nb = col_of(n0, j, g4);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j][i][r] *= p.alpha;
+            for (int e = 0; e < 4; ++e) cs[e] = p.col_scale[min(nb + e, p.N - 1)];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][i][4 * g4 + e] *= rs[i] * cs[e];
+        }
     }
     epilogue(m0, n0, (size_t)ksl * p.slab);
     int t_aft = -1;

@@ -68,16 +68,19 @@ class LayerParams:
 
 class SeqInfo:
     """Row layout of one batch: padded (cu is None: sample b = rows [b*S, (b+1)*S)) or packed (cu int32 [B+1])."""
-    __slots__ = ("B", "S", "M", "cu", "pos")
+    __slots__ = ("B", "S", "M", "cu", "pos", "fp8")
 
-    def __init__(self, B, S, M, cu, pos):
-        self.B, self.S, self.M, self.cu, self.pos = B, S, M, cu, pos
+    def __init__(self, B, S, M, cu, pos, fp8=False):
+        self.B, self.S, self.M, self.cu, self.pos, self.fp8 = B, S, M, cu, pos, fp8
 
 
 class LlamaStack:
     def __init__(self, cfg: HandsOnVLMConfig, device, training: bool = True):
         self.cfg = cfg
-        self.recompute = bool(getattr(cfg, "activation_recompute", False))
+        # activation recompute: False / 0 = keep everything; True = every layer; an int n = only the FIRST n layers (their
+        # activations would live longest), the rest keep theirs — spend whatever HBM is left on speed
+        ar = getattr(cfg, "activation_recompute", False)
+        self.recompute = cfg.num_hidden_layers if ar is True else int(ar or 0)
         self.device = torch.device(device)
         self.training = training
         D, F, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
@@ -145,9 +148,18 @@ class LlamaStack:
         return self._pos_cache[key]
 
     # -- forward --------------------------------------------------------------------------------
-    def new_cache(self, max_len: Optional[int] = None) -> List[torch.Tensor]:
-        """Per-layer [max_len, 3D] buffers in the fused qkv layout (k at column D, v at 2D)."""
+    def new_cache(self, max_len: Optional[int] = None, batch: Optional[int] = None) -> List[torch.Tensor]:
+        """Per-layer [max_len, 3D] buffers in the fused qkv layout (k at column D, v at 2D); with `batch`: [B, max_len, 3D]
+        (lock-step generation of B samples)."""
         n = max_len or self.cfg.max_position_embeddings
+        if batch is not None:
+            kept = getattr(self, "_kv_cache_b", None)
+            if kept is None or kept[0].shape[0] != batch or kept[0].shape[1] < n:
+                kept = None
+                self._kv_cache_b = None                     # free the old one before allocating (22 GB at B = 32)
+                kept = [torch.empty((batch, n, 3 * self.D), dtype=BF16, device=self.device) for _ in range(self.L)]
+                self._kv_cache_b = kept
+            return kept
         # kept across samples (evaluation generates one sample after the other: 1.6 GB for 7B at n = 1100; allocating it
         # per sample cost 7.8 ms of an 80 ms sample) — and the decode-step pointer tables keyed on it stay valid
         kept = getattr(self, "_kv_cache", None)
@@ -229,29 +241,34 @@ class LlamaStack:
         """One decoder layer.  Returns (output, saved-activation dict or None)."""
         lp = self.layers[li]
         eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
+        mm = (lambda a, k, residual=None: self._mm_fp8(li, k, a, residual)) if seq.fp8 else \
+             (lambda a, k, residual=None: ops.gemm_nt(a, lp.w[k], residual=residual))
         xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
         probe = getattr(self, "_fp8_probe", None)
         if probe is not None:
             probe[li]["qkv"] = float(xn.abs().max())
-        qkv = ops.gemm_nt(xn, lp.w["qkv"])
+        qkv = mm(xn, "qkv")
         ops.rope_qk_(qkv, self.cos, self.sin, seq.pos, self.H, self.dh)
         if cache is not None:
-            assert seq.B == 1
-            cache[li][:seq.S].copy_(qkv)
+            if cache[li].dim() == 2:                       # batch-1 cache [max_len, 3D] (native decode step)
+                assert seq.B == 1
+                cache[li][:seq.S].copy_(qkv)
+            else:                                          # batched cache [B, max_len, 3D]
+                cache[li][:, :seq.S].copy_(qkv.view(seq.B, seq.S, -1))
         ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
-        h = ops.gemm_nt(ao, lp.w["o"], residual=x)
+        h = mm(ao, "o", residual=x)
         hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
-        gu = ops.gemm_nt(hn, lp.w["gu"])
+        gu = mm(hn, "gu")
         act = ops.swiglu_fwd(gu)
         if probe is not None:
             probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
-        xo = ops.gemm_nt(act, lp.w["down"], residual=h)
+        xo = mm(act, "down", residual=h)
         sv = dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn, gu=gu, act=act) if save else None
         return xo, sv
 
     def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
                 all_hidden: bool = False, cache: Optional[List[torch.Tensor]] = None,
-                cu_seqlens: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None):
+                cu_seqlens: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, fp8: bool = False):
         """x [M, D] bf16 -> final-normed hidden [M, D].
         Padded batch: M = B*S, sample b owns rows [b*S, (b+1)*S), positions arange(S) (right padding is harmless under the
         causal mask).  Packed batch (cu_seqlens int32 [B+1] on the device + pos int32 [M]): the B samples are stored end
@@ -263,11 +280,14 @@ class LlamaStack:
         M = x.shape[0]
         assert x.shape == (M, self.D) and x.dtype == BF16 and S <= cfg.max_position_embeddings
         assert (cu_seqlens is None and M == B * S) or (cu_seqlens is not None and pos is not None and pos.numel() == M)
-        seq = SeqInfo(B=B, S=S, M=M, cu=cu_seqlens, pos=self._positions(B, S) if pos is None else pos)
-        keep_all = save and not self.recompute
+        assert not (fp8 and save), "the fp8 GEMMs are an inference path (BASELINE config 5)"
+        if fp8 and getattr(self, "_fp8_rw", None) is None:
+            self.fp8_prepare_rowwise()
+        seq = SeqInfo(B=B, S=S, M=M, cu=cu_seqlens, pos=self._positions(B, S) if pos is None else pos, fp8=fp8)
         self.saved = []
         hs = [x] if all_hidden else None
         for li in range(self.L):
+            keep_all = save and li >= self.recompute
             xo, sv = self._layer_forward(li, x, seq, keep_all, cache)
             if save:
                 self.saved.append(sv if keep_all else dict(x=x))
@@ -283,7 +303,44 @@ class LlamaStack:
             return hidden, hs
         return hidden
 
-    # -- fp8 inference forward (BASELINE config 5) -----------------------------------------------
+    # -- fp8 GEMMs with per-output-channel weight scales and per-token activation scales (BASELINE config 5) -----------
+    def fp8_prepare_rowwise(self) -> None:
+        """e4m3 copies of the four GEMM weights of every layer, one scale per OUTPUT CHANNEL (row of W); activations are
+        quantised per TOKEN at run time (ops.quantize_fp8_rowwise), so nothing has to be calibrated."""
+        with torch.no_grad():
+            self._fp8_rw = [{k: ops.quantize_fp8_rowwise(lp.w[k]) for k in ("qkv", "o", "gu", "down")} for lp in self.layers]
+
+    def _mm_fp8(self, li: int, key: str, a: torch.Tensor, residual=None) -> torch.Tensor:
+        w8, inv_w = self._fp8_rw[li][key]
+        a8, inv_a = ops.quantize_fp8_rowwise(a)
+        return ops.gemm_fp8_nt_scaled(a8, w8, inv_a, inv_w, residual=residual)
+
+    def decode_step_batched(self, x1: torch.Tensor, lens: torch.Tensor, cache: List[torch.Tensor], fp8: bool = False) -> torch.Tensor:
+        """One new token for each of B samples in lock step: x1 [B, D], lens int32 [B] (device) = position of the new token
+        of every sample = its current cache length; cache[l] [B, max_len, 3D].  Returns the final-normed hidden [B, D].
+        Weights are streamed once per step for all B samples (GEMMs at M = B) instead of once per sample."""
+        B = x1.shape[0]
+        eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
+        rows = torch.arange(B, device=self.device)
+        idx = lens.long()
+        lens1 = (lens + 1).contiguous()
+        x = x1
+        for li, lp in enumerate(self.layers):
+            mm = (lambda a, k, residual=None: self._mm_fp8(li, k, a, residual)) if fp8 else \
+                 (lambda a, k, residual=None: ops.gemm_nt(a, lp.w[k], residual=residual))
+            xn, _ = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=False)
+            qkv = mm(xn, "qkv")
+            ops.rope_qk_(qkv, self.cos, self.sin, lens, self.H, self.dh)
+            cache[li][rows, idx] = qkv                                   # the new token's k / v row of every sample
+            ao = ops.attn_decode_batched(qkv, cache[li], lens1, self.H, self.dh, scale)
+            h = mm(ao, "o", residual=x)
+            hn, _ = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=False)
+            act = ops.swiglu_fwd(mm(hn, "gu"))
+            x = mm(act, "down", residual=h)
+        hidden, _ = ops.rmsnorm_fwd(x, self.norm_w, eps, save_rstd=False)
+        return hidden
+
+    # -- fp8 inference forward, per-tensor static scales (round-1 variant, kept for A/B) -------------------------------
     FP8_MAX = 448.0
 
     def fp8_prepare(self, x: torch.Tensor, B: int, S: int, margin: float = 1.25) -> None:
@@ -372,7 +429,7 @@ class LlamaStack:
         self.norm_g.copy_(dwn)
         for i in range(self.L - 1, -1, -1):
             lp, sv = self.layers[i], self.saved[i]
-            if self.recompute:
+            if i < self.recompute:
                 # activation recompute (the reference's gradient checkpointing, scripts/finetune.sh:36): only the layer input
                 # was kept; its forward is run again here, bit-identical to the first one (deterministic kernels)
                 sv = self._layer_forward(i, sv["x"], seq, True)[1]

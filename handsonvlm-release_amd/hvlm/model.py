@@ -633,6 +633,100 @@ class HandsOnVLMForCausalLM:
                                        pred_hands=ph)
 
     @torch.no_grad()
+    def sample_batch(self, input_ids, logits_processor=None, max_length=None, eos_token_id=None, pad_token_id=None,
+                     attention_mask=None, image=None, hand_noise=None, fp8: bool = False, fp8_decode: bool = False,
+                     output_scores: bool = False):
+        """Lock-step generation of B samples (BASELINE config 5: batch-32 evaluation).  The reference's sample() is batch 1
+        (`.item()` at handsonvlm.py:609) and re-runs CLIP + the whole prefix per token; this is the same per-sample function
+        — multinomial sampling, a CVAE hand decoded from the last hidden state whenever token 32100 is drawn, that hand's
+        sinusoidal encoding added to the token's embedding when it is fed back (handsonvlm.py:380-396,543-647) — with one
+        batched prefill (bf16, or the e4m3 GEMMs with `fp8`) filling a [B, max_len, 3D] KV cache per layer and one batched
+        decode step per generated token (weights streamed once for all B samples).  Right-padded prompts (attention_mask)
+        are supported: a sample's pad rows are never attended (its own length bounds its keys).
+        `logits_processor`: callables (input_ids [B, cur], scores [B, V]) -> scores.  `hand_noise[b][j]`: optional z for the
+        j-th hand of sample b.  Returns SampleDecoderOnlyOutput(sequences [B, T_max] padded with pad_token_id,
+        pred_hands [B, 2, n_max, 2] zero-padded) plus `.lengths` / `.num_hands` lists."""
+        cfg, dev = self.config, self.device
+        B, T = input_ids.shape
+        procs = list(logits_processor or [])
+        pad_token_id = cfg.pad_token_id if pad_token_id is None else pad_token_id
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        eos = [eos] if isinstance(eos, int) else list(eos)
+        vis = self.visual_tokens(image.to(dev))
+        NV = vis.shape[1]
+        plan = self.build_splice_plan(input_ids, None, NV, 0, True, False, pack=False)
+        if attention_mask is not None:          # true prompt lengths (right padding): rows past them are pads
+            am = attention_mask.detach().cpu().numpy().astype(bool)
+            npad = np.array([T - (int(np.nonzero(am[b])[0][-1]) + 1) for b in range(B)])
+        else:
+            npad = np.zeros(B, dtype=np.int64)
+        S = plan.S
+        lengths = plan.lengths - npad
+        n_gen = 160 if max_length is None else max(1, max_length - T)
+        max_len = min(cfg.max_position_embeddings, S + n_gen)
+        cache = self.stack.new_cache(max_len, batch=B)
+        x = ops.embed_splice_fwd(self.embed, vis, plan.src, None, None, None, B, S, self.token_dim, NV, 1)
+        hidden = self.stack.forward(x, B, S, save=False, cache=cache, fp8=fp8)
+        rows = torch.from_numpy((np.arange(B) * S + lengths - 1).astype(np.int64)).to(dev)
+        last = hidden[rows].contiguous()                                        # [B, D]
+        del hidden, x
+        lens = torch.from_numpy(lengths.astype(np.int32)).to(dev)
+        seqs = [input_ids[b, : T - npad[b]].tolist() for b in range(B)]
+        hands: List[List[torch.Tensor]] = [[] for _ in range(B)]
+        done = np.zeros(B, dtype=bool)
+        scores_out = []
+        cur = input_ids.to(dev)
+        while True:
+            logits = ops.gemm_nt(last, self.lm_head)[:, : cfg.vocab_size].float()
+            for proc in procs:
+                logits = proc(cur, logits)
+            if output_scores:
+                scores_out.append(logits)
+            toks = torch.multinomial(torch.softmax(logits, dim=-1), num_samples=1).squeeze(1)
+            tl = toks.tolist()
+            is_hand = [(not done[b]) and tl[b] == HAND_TOKEN_ID for b in range(B)]
+            hb = [b for b in range(B) if is_hand[b]]
+            hand_new = torch.zeros(B, 2, 1, 2, dtype=torch.float32, device=dev)
+            if hb:
+                emb = last[hb].float().reshape(len(hb), self.token_dim // 2, 2).permute(0, 2, 1).unsqueeze(2)   # [n,2,1,D/2]
+                z = None
+                if hand_noise is not None:
+                    z = torch.cat([hand_noise[b][len(hands[b])].to(dev, torch.float32).reshape(2, -1) for b in hb], 0)
+                ph = self.hand_traj_decoder.inference(emb, z).squeeze(2)       # [n, 2, 2]
+                for i, b in enumerate(hb):
+                    hands[b].append(ph[i])
+                    hand_new[b, :, 0] = ph[i]
+            for b in range(B):
+                if not done[b]:
+                    seqs[b].append(tl[b])
+                    n_new = len(seqs[b]) - (T - int(npad[b]))                # tokens generated by this sample so far
+                    if tl[b] in eos or (max_length is not None and n_new >= max_length - T):
+                        done[b] = True
+            cur = torch.cat([cur, toks[:, None]], dim=1)
+            if done.all() or int(lens.max()) + 1 >= max_len:
+                break
+            # feed the drawn tokens back: embedding (+ the sinusoidal encoding of the hand this token just produced)
+            src = toks.to(torch.int32)
+            slot = torch.tensor([0 if h else -1 for h in is_hand], dtype=torch.int32, device=dev)
+            x1 = ops.embed_splice_fwd(self.embed, None, src, slot, hand_new.contiguous(), torch.ones(B, device=dev), B, 1,
+                                      self.token_dim, 0, 1)
+            last = self.stack.decode_step_batched(x1, lens, cache, fp8=fp8_decode)
+            lens = lens + 1
+        tmax = max(len(q) for q in seqs)
+        out_ids = torch.full((B, tmax), pad_token_id, dtype=torch.long)
+        for b in range(B):
+            out_ids[b, : len(seqs[b])] = torch.tensor(seqs[b])
+        nmax = max((len(h) for h in hands), default=0)
+        ph = torch.zeros(B, 2, nmax, 2, device=dev)
+        for b in range(B):
+            if hands[b]:
+                ph[b, :, : len(hands[b])] = torch.stack(hands[b], dim=1)
+        out = SampleDecoderOnlyOutput(sequences=out_ids, scores=tuple(scores_out) if output_scores else None, pred_hands=ph)
+        out.lengths = [len(q) for q in seqs]
+        out.num_hands = [len(h) for h in hands]
+        return out
+
+    @torch.no_grad()
     def generate(self, input_ids, image=None, do_sample=True, temperature=1.0, top_p=1.0, num_beams=1,
                  max_new_tokens=100, use_cache=False, output_hidden_states=True, return_dict_in_generate=True, **kw):
         """The call made by handsonvlm/evaluation/handsonvlm_inference.py:99-109."""

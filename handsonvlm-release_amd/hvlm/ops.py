@@ -198,6 +198,42 @@ def gemm_fp8_nt(a8: torch.Tensor, b8: torch.Tensor, alpha: float, bias: Optional
     return out
 
 
+def quantize_fp8_rowwise(x: torch.Tensor):
+    """bf16 [R, K] -> (e4m3 bytes [R, K], inv_scale f32 [R]) with one scale per row (token / output channel):
+    x[r, :] ~= inv_scale[r] * e4m3[r, :]."""
+    _chk(x, BF16, "quantize_fp8_rowwise.x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, K = x.shape
+    out = torch.empty((R, K), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((R,), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvlm_quantize_fp8_rowwise(_p(x), _p(out), _p(inv), R, K, x.stride(0), out.stride(0), _stream()),
+          "quantize_fp8_rowwise")
+    return out, inv
+
+
+def gemm_fp8_nt_scaled(a8, b8, row_scale, col_scale, alpha: float = 1.0, bias=None, residual=None, act: int = ACT_NONE,
+                       out=None, out_dtype=BF16):
+    """out[M,N] = act(alpha * row_scale[m] * col_scale[n] * a8[M,K] @ b8[N,K]^T + bias) + residual (e4m3 operands)."""
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.is_cuda and b8.is_cuda
+    assert a8.dim() == 2 and b8.dim() == 2 and a8.shape[1] == b8.shape[1] and a8.stride(1) == 1 and b8.stride(1) == 1
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert row_scale is None or (row_scale.dtype == torch.float32 and row_scale.numel() == M)
+    assert col_scale is None or (col_scale.dtype == torch.float32 and col_scale.numel() == N)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    ldr = residual.stride(0) if residual is not None else 0
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_fp8_nt_scaled(_p(a8), _p(b8), _p(out), M, N, K, a8.stride(0), b8.stride(0), out.stride(0),
+                                              float(alpha), _p(row_scale), _p(col_scale), _p(bias), _p(residual), ldr, act,
+                                              1 if out.dtype == torch.float32 else 0, _stream()), "gemm_fp8_nt_scaled")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
 def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
     _chk(x, BF16, "transpose.x")
@@ -329,6 +365,21 @@ def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, S
     out = torch.empty((H * dh,), dtype=BF16, device=q.device)
     check(_lib.load().hvlm_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(out), S, H, dh, k_cache.stride(0), scale,
                                        _stream()), "attn_decode")
+    return out
+
+
+def attn_decode_batched(q: torch.Tensor, cache: torch.Tensor, lens: torch.Tensor, H: int, dh: int, scale: float):
+    """q [B, >= H*dh] (row b = the new token of sample b, RoPE'd; may be a view of the fused qkv rows), cache [B, max_S, 3*H*dh]
+    (fused qkv layout: k at column H*dh, v at 2*H*dh), lens int32 [B] on the device -> out [B, H*dh]."""
+    _chk(q, BF16, "attn_decode_batched.q"); _chk(cache, BF16, "attn_decode_batched.cache"); _chk(lens, torch.int32, "attn_decode_batched.lens")
+    B, max_S, ld = cache.shape
+    assert q.shape[0] == B and q.stride(1) == 1 and cache.is_contiguous() and ld == 3 * H * dh
+    D = H * dh
+    out = torch.empty((B, D), dtype=BF16, device=q.device)
+    kc = ctypes.c_void_p(cache.data_ptr() + 2 * D)
+    vc = ctypes.c_void_p(cache.data_ptr() + 4 * D)
+    check(_lib.load().hvlm_attn_decode_batched(_p(q), q.stride(0), kc, vc, cache.stride(0), _p(lens), _p(out), D, B, max_S, H, dh,
+                                               ld, scale, _stream()), "attn_decode_batched")
     return out
 
 

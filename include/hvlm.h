@@ -80,6 +80,21 @@ int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, int N, int K,
                      float alpha, const void* bias, const void* residual, int ldr, int act, int out_f32,
                      void* stream);
 
+/* Finer-grained scaling for the fp8 forward (BASELINE config 5): per-TOKEN activation scales and per-OUTPUT-CHANNEL weight
+ * scales instead of one scale per tensor.
+ *   hvlm_quantize_fp8_rowwise: for every row r of x [rows, K] (bf16, ldx): amax_r = max |x[r, :]|,
+ *       out[r, :] = e4m3(x[r, :] * 448 / amax_r)  (ldo bytes per row), inv_scale[r] = amax_r / 448.
+ *       Used on activations (rows = tokens) at run time and on weights (rows = output channels) once.
+ *   hvlm_gemm_fp8_nt_scaled: C[m, n] = act(alpha * row_scale[m] * col_scale[n] * sum_k A[m,k] B[n,k] + bias) + residual;
+ *       row_scale (f32[M]) / col_scale (f32[N]) may be NULL (= 1).  With A, B from the row-wise quantiser:
+ *       row_scale = inv_scale of A, col_scale = inv_scale of B, alpha = 1.
+ * Reference arithmetic replaced: none (the reference has no fp8 path); parity = the fp64 product of the de-quantised
+ * operands (exact up to fp32 accumulation), accuracy = against the bf16 forward (tests/test_gpu_fp8.py). */
+int hvlm_quantize_fp8_rowwise(const void* x, void* out, float* inv_scale, int rows, int K, int ldx, int ldo, void* stream);
+int hvlm_gemm_fp8_nt_scaled(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                            float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                            const void* residual, int ldr, int act, int out_f32, void* stream);
+
 /* General form with K-strided operands (no transposed copies for the backward GEMMs):
  *   trans_a: A is stored [K, M] (M contiguous, lda >= M); trans_b: B is stored [K, N] (ldb >= N).
  *   dX = dY @ W  -> trans_b with B = W as stored;  dW = dY^T @ X -> trans_a + trans_b with A = dY, B = X as stored.
@@ -170,6 +185,12 @@ int hvlm_gemv_bf16(const void* W, const void* x, void* y, const void* residual, 
                    void* stream);
 int hvlm_attn_decode(const void* q, const void* k_cache, const void* v_cache, void* out, int S, int H,
                      int dh, int ld, float scale, void* stream);
+/* Batched single-token attention for lock-step generation of B samples (batch evaluation, BASELINE config 5): sample b has
+ * query row q + b*ldq (already RoPE'd), cache slabs k_cache / v_cache + b*sample_stride ([max_S, ld] each, fused qkv layout)
+ * and its own length lens[b] (device int32; keys 0..lens[b]-1 include the new token's).  out row b at out + b*ldo. */
+int hvlm_attn_decode_batched(const void* q, int ldq, const void* k_cache, const void* v_cache, long sample_stride,
+                             const int32_t* lens, void* out, int ldo, int B, int max_S, int H, int dh, int ld, float scale,
+                             void* stream);
 /* One decode step of the whole decoder stack from native code (replaces LlamaModel.forward for one new token at
  * position `pos`): pointer tables are HOST arrays [L] of DEVICE pointers (fused weights as in hvlm/llama.py;
  * kv_cache[l] is [max_len, cache_ld] in the fused qkv layout, row `pos` is written).  pos_dev points at a device

@@ -162,6 +162,44 @@ def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None, cu_seql
     return g
 
 
+def attn_decode_batched(q, cache, lens, H, dh, scale):
+    B, max_S, ld = cache.shape
+    D = H * dh
+    out = torch.zeros((B, D), dtype=torch.float32)
+    for b in range(B):
+        n = int(lens[b])
+        qb = q[b, :D].float().view(H, 1, dh)
+        k = cache[b, :n, D:2 * D].float().view(n, H, dh).permute(1, 0, 2)
+        v = cache[b, :n, 2 * D:].float().view(n, H, dh).permute(1, 0, 2)
+        p = torch.softmax((qb @ k.transpose(1, 2)) * scale, -1)
+        out[b] = (p @ v).reshape(D)
+    return out.to(BF16)
+
+
+def quantize_fp8_rowwise(x):
+    amax = x.float().abs().amax(dim=1).clamp(min=1e-12)
+    q = (x.float() * (448.0 / amax)[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), (amax / 448.0)
+
+
+def gemm_fp8_nt_scaled(a8, b8, row_scale, col_scale, alpha=1.0, bias=None, residual=None, act=ACT_NONE, out=None, out_dtype=BF16):
+    y = a8.view(torch.float8_e4m3fn).float() @ b8.view(torch.float8_e4m3fn).float().t() * alpha
+    if row_scale is not None:
+        y = y * row_scale[:, None]
+    if col_scale is not None:
+        y = y * col_scale[None, :]
+    if bias is not None:
+        y = y + bias.float()
+    y = _act(y, act)
+    if residual is not None:
+        y = y + residual.float()
+    y = y.to(out_dtype if out is None else out.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def swiglu_fwd(gu, out=None):
     Fh = gu.shape[1] // 2
     y = (F.silu(gu[:, :Fh].float()) * gu[:, Fh:].float()).to(BF16)

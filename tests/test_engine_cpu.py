@@ -15,7 +15,8 @@ def _model(**cfg_kw):
     m.config.dedup_frames = False
     for k, v in cfg_kw.items():
         setattr(m.config, k, v)
-    m.stack.recompute = bool(m.config.activation_recompute)
+    ar = m.config.activation_recompute
+    m.stack.recompute = m.config.num_hidden_layers if ar is True else int(ar or 0)
     return m
 
 
@@ -50,6 +51,8 @@ def test_activation_recompute_is_bit_identical(monkeypatch):
     assert l0 == l1
     for n in g0:
         assert torch.equal(g0[n], g1[n]), n
+    l2, g2, k2, _ = _run(_model(activation_recompute=1), batch)               # first layer only
+    assert k2[0] == ["x"] and len(k2[1]) > 5 and l2 == l0 and all(torch.equal(g0[n], g2[n]) for n in g0)
 
 
 def test_packed_batch_matches_padded_batch(monkeypatch):
@@ -104,3 +107,49 @@ def test_packed_plan_layout(monkeypatch):
         want = torch.where(hr_pad >= 0, hr_pad - b * S + o, hr_pad)
         assert torch.equal(pk.hand_rows.view(3, 4)[b], want)
     assert torch.equal(pk.labels, pa.labels)                   # the padded labels the reference returns
+
+
+def test_sample_batch_equals_per_sample_sampling(monkeypatch):
+    """model.sample_batch (batched prefill into a [B, max_len, 3D] cache + one batched decode step per token) reproduces,
+    sample by sample, what the reference-shaped batch-1 sample() loop produces (forced tokens, pinned CVAE noise): same
+    sequences, same hands — with different prompt lengths (right padding) and different hand counts per sample."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from test_train_resume_cpu import _tiny
+    m, cfg = _tiny(training=False)
+    m.config.dedup_frames = False
+    c = synth.TINY
+    ids, _, mask = synth.make_text_batch(3, 16, seed=8, n_hand=(0, 0, 0), pad_tail=(0, 5, 2))
+    images = synth.make_images(3, c["frames"], 2, c["image"], seed=12).to(torch.bfloat16)
+    forced = [[512, 32100, 32100, 77, 2], [32100, 9, 32100, 32100, 2], [600, 601, 2, 2, 2]]
+    T = ids.shape[1]
+    lens0 = [16, 11, 14]
+    g = torch.Generator().manual_seed(4)
+    noise = [[2.0 * torch.randn(2, 256, generator=g) for _ in range(4)] for _ in range(3)]
+
+    def force_batch(cur, scores):
+        out = torch.full_like(scores, -1e9)
+        step = cur.shape[1] - T
+        for b in range(3):
+            out[b, forced[b][min(step, 4)]] = 0.0
+        return out
+
+    ob = m.sample_batch(ids, logits_processor=[force_batch], max_length=T + 5, eos_token_id=2, attention_mask=mask, image=images,
+                        hand_noise=noise)
+    for b in range(3):
+        prompt = ids[b:b + 1, : lens0[b]]
+
+        def force_one(cur, scores, b=b, n0=lens0[b]):
+            out = torch.full_like(scores, -1e9)
+            out[:, forced[b][cur.shape[1] - n0]] = 0.0
+            return out
+
+        o1 = m.sample(prompt, logits_processor=[force_one], max_length=lens0[b] + 5, eos_token_id=2, image=images[b:b + 1],
+                      hand_noise=noise[b], use_kv_cache=False)
+        n = ob.lengths[b]
+        assert ob.sequences[b, :n].tolist() == o1.sequences[0].tolist(), b
+        assert ob.num_hands[b] == o1.pred_hands.shape[2]
+        if ob.num_hands[b]:
+            a, r = ob.pred_hands[b, :, : ob.num_hands[b]].float(), o1.pred_hands[0].float()
+            assert float((a - r).abs().max()) <= 2e-2 * float(r.abs().max()), (b, a, r)
+    assert ob.num_hands == [2, 3, 0] and ob.lengths == [21, 16, 17]

@@ -1,0 +1,154 @@
+"""BASELINE config 5 (fp8 e4m3 forward on the CDNA4 scaled MFMA, batch evaluation) — GPU tests.
+  * hvlm_quantize_fp8_rowwise / hvlm_gemm_fp8_nt_scaled: exact against the fp64 product of the de-quantised operands;
+  * accuracy of the fp8 decoder forward against the bf16 forward on a NON-pathological weight distribution (trained-like:
+    log-normal per-channel norms, residual branches small against the stream, a few outlier activation channels), per-token +
+    per-channel scales vs the round-1 per-tensor static scales;
+  * hvlm_attn_decode_batched against the oracle; model.sample_batch against the batch-1 sample() loop, bf16 and fp8."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle import synth  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hvlm import ops as o
+    return o
+
+
+def test_rowwise_quantiser_and_scaled_gemm_exact(ops):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, N, K = 300, 520, 512
+    a = (torch.randn(M, K, device="cuda", generator=g) * torch.logspace(-2, 1, M, device="cuda")[:, None]).to(BF)
+    w = (torch.randn(N, K, device="cuda", generator=g) * torch.logspace(-1.5, 0.5, N, device="cuda")[:, None]).to(BF)
+    a[5] = 0                                                                  # an all-zero token must not produce NaN / inf
+    a8, ia = ops.quantize_fp8_rowwise(a)
+    w8, iw = ops.quantize_fp8_rowwise(w)
+    # the quantiser: scale = 448 / amax per row, round-to-nearest-even e4m3 (torch's own cast as the checker)
+    amax = a.float().abs().amax(1).clamp(min=1e-12)
+    assert torch.allclose(ia, amax / 448.0, rtol=1e-6)
+    want8 = (a.float() * (448.0 / amax)[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (a8 != want8).float().mean() < 1e-3                               # (ties / fma rounding of x*scale: a handful)
+    da = a8.view(torch.float8_e4m3fn).double() * ia.double()[:, None]
+    dw = w8.view(torch.float8_e4m3fn).double() * iw.double()[:, None]
+    assert rel(da, a.double()) < 0.04 and rel(dw, w.double()) < 0.04          # e4m3: 3 mantissa bits
+    res = torch.randn(M, N, device="cuda", generator=g).to(BF)
+    c = ops.gemm_fp8_nt_scaled(a8, w8, ia, iw, residual=res, out_dtype=torch.float32)
+    assert rel(c, da @ dw.t() + res.double()) < 2e-6                          # exact product of the de-quantised operands
+    cb = ops.gemm_fp8_nt_scaled(a8, w8, ia, iw)
+    assert rel(cb, (da @ dw.t()).float().to(BF)) < 1e-3 and torch.isfinite(cb.float()).all()
+    c1 = ops.gemm_fp8_nt_scaled(a8, w8, None, iw, alpha=0.5, out_dtype=torch.float32)
+    assert rel(c1, 0.5 * (a8.view(torch.float8_e4m3fn).double() @ dw.t())) < 2e-6
+
+
+def _trained_like_stack(L=8, D=512, F=1408, H=4, seed=0):
+    """Weights with log-normal per-output-channel norms, residual-branch outputs ~0.2x the stream (as in a trained network,
+    unlike N(0, 0.02) everywhere), and RMSNorm gains that create a few large activation channels."""
+    from hvlm.config import HandsOnVLMConfig
+    from hvlm.llama import LlamaStack
+    cfg = HandsOnVLMConfig(hidden_size=D, intermediate_size=F, num_hidden_layers=L, num_attention_heads=H)
+    st = LlamaStack(cfg, device="cuda:0", training=False)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for lp in st.layers:
+        for k, shp in (("qkv", (3 * D, D)), ("o", (D, D)), ("gu", (2 * F, D)), ("down", (D, F))):
+            rown = torch.exp(0.5 * torch.randn(shp[0], 1, device="cuda", generator=g))
+            base = shp[1] ** -0.5 * (0.25 if k in ("o", "down") else 1.0)
+            lp.w[k].copy_((torch.randn(shp, device="cuda", generator=g) * base * rown).to(BF))
+        for k in ("ln1", "ln2"):
+            gain = torch.ones(D, device="cuda")
+            gain[torch.randint(0, D, (6,), device="cuda", generator=g)] = 12.0          # outlier channels
+            lp.w[k].copy_(gain.to(BF))
+    st.norm_w.fill_(1.0)
+    return st, cfg
+
+
+def test_fp8_forward_accuracy_on_trained_like_weights():
+    st, cfg = _trained_like_stack()
+    B, S, D = 2, 320, cfg.hidden_size
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B * S, D, device="cuda", generator=g).to(BF)
+    ref = st.forward(x, B, S, save=False).float()
+    rowwise = st.forward(x, B, S, save=False, fp8=True).float()
+    st.fp8_prepare(x, B, S)
+    per_tensor = st.forward_fp8(x, B, S).float()
+    r_row, r_ten = rel(rowwise, ref), rel(per_tensor, ref)
+    print(f"8-layer fp8 forward vs bf16: per-token/per-channel scales {r_row:.4f}, per-tensor static scales {r_ten:.4f}")
+    assert torch.isfinite(rowwise).all()
+    assert r_row < 0.06, r_row                      # a few % through 32 e4m3 GEMMs
+    assert r_row < r_ten                            # and better than one scale per tensor on this distribution
+    # what matters downstream: the argmax token of an lm_head over these hidden states
+    wl = (torch.randn(1024, D, device="cuda", generator=g) * D ** -0.5).to(BF)
+    a0 = (ref @ wl.float().t()).argmax(-1)
+    a1 = (rowwise @ wl.float().t()).argmax(-1)
+    assert (a0 == a1).float().mean() > 0.9
+
+
+def test_attn_decode_batched_vs_oracle(ops):
+    B, H, dh, maxS = 5, 4, 128, 300
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cache = (torch.randn(B, maxS, 3 * H * dh, device="cuda", generator=g) * 0.7).to(BF)
+    q = (torch.randn(B, 3 * H * dh, device="cuda", generator=g) * 0.7).to(BF)
+    lens = torch.tensor([300, 1, 77, 256, 129], dtype=torch.int32, device="cuda")
+    out = ops.attn_decode_batched(q, cache, lens, H, dh, dh ** -0.5)
+    D = H * dh
+    for b in range(B):
+        n = int(lens[b])
+        qq = q[b, :D].float().cpu().view(1, H, 1, dh)
+        k = cache[b, :n, D:2 * D].float().cpu().view(1, n, H, dh).permute(0, 2, 1, 3)
+        v = cache[b, :n, 2 * D:].float().cpu().view(1, n, H, dh).permute(0, 2, 1, 3)
+        ref = R.softmax_attention(qq, k, v, False, dh ** -0.5).reshape(D)
+        assert rel(out[b], ref) < 4e-3, b
+
+
+def _tiny_eval_model():
+    from test_gpu_model import tiny_model
+    m, cfg = tiny_model(training=False)
+    return m
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_sample_batch_vs_per_sample_loop(fp8):
+    """Lock-step batched generation == the batch-1 sample() loop (reference recipe handsonvlm.py:478-672), sample by sample:
+    ragged prompts, different hand counts, EOS at different steps; bf16 exactly the same tokens and hands to bf16 accuracy;
+    with the fp8 prefill the forced tokens are the same and the hands stay close (e4m3 GEMMs feed the CVAE condition)."""
+    m = _tiny_eval_model()
+    c = synth.TINY
+    ids, _, mask = synth.make_text_batch(3, 16, seed=8, n_hand=(0, 0, 0), pad_tail=(0, 5, 2))
+    images = synth.make_images(3, c["frames"], 2, c["image"], seed=12).to(BF)
+    forced = [[512, 32100, 32100, 77, 2], [32100, 9, 32100, 32100, 2], [600, 601, 2, 2, 2]]
+    T, lens0 = ids.shape[1], [16, 11, 14]
+    g = torch.Generator().manual_seed(4)
+    noise = [[2.0 * torch.randn(2, 256, generator=g) for _ in range(4)] for _ in range(3)]
+
+    def force_batch(cur, scores):
+        out = torch.full_like(scores, -1e9)
+        for b in range(3):
+            out[b, forced[b][min(cur.shape[1] - T, 4)]] = 0.0
+        return out
+
+    ob = m.sample_batch(ids, logits_processor=[force_batch], max_length=T + 5, eos_token_id=2, attention_mask=mask, image=images,
+                        hand_noise=noise, fp8=fp8, fp8_decode=fp8)
+    assert ob.num_hands == [2, 3, 0] and ob.lengths == [21, 16, 17]
+    for b in range(3):
+        def force_one(cur, scores, b=b, n0=lens0[b]):
+            out = torch.full_like(scores, -1e9)
+            out[:, forced[b][cur.shape[1] - n0]] = 0.0
+            return out
+        o1 = m.sample(ids[b:b + 1, : lens0[b]], logits_processor=[force_one], max_length=lens0[b] + 5, eos_token_id=2,
+                      image=images[b:b + 1], hand_noise=noise[b])
+        assert ob.sequences[b, : ob.lengths[b]].tolist() == o1.sequences[0].tolist()
+        if ob.num_hands[b]:
+            a, r = ob.pred_hands[b, :, : ob.num_hands[b]].float().cpu(), o1.pred_hands[0].float().cpu()
+            tol = 0.15 if fp8 else 2e-2
+            assert float((a - r).abs().max()) <= tol * float(r.abs().max()), (b, a, r)
