@@ -322,8 +322,35 @@ def eval_leg(model, cfg, T, device):
         out = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    return {"samples_per_s": 1.0 / dt, "ms_per_sample": dt * 1e3, "new_tokens": len(forced), "hands_decoded": int(out.pred_hands.shape[2]),
-            "batch": 1, "kv_cache": True, "note": "reference recipe re-runs CLIP + full prefill per token (use_cache=False)"}
+    res = {"samples_per_s": 1.0 / dt, "ms_per_sample": dt * 1e3, "new_tokens": len(forced), "hands_decoded": int(out.pred_hands.shape[2]),
+           "batch": 1, "kv_cache": True, "note": "reference recipe re-runs CLIP + full prefill per token (use_cache=False)"}
+    # the same evaluation with 32 samples in lock step (model.sample_batch: batched prefill + one batched decode step per token)
+    try:
+        Bb = 32
+        idb, _ = make_text_batch_np(Bb, T, 9, n_hand=0)
+        idb = torch.from_numpy(idb)
+        baseb = torch.randn(Bb, 10, 3, cfg.vision.image_size, cfg.vision.image_size, device=device, generator=g).to(torch.bfloat16)
+        imgb = baseb[:, torch.arange(cfg.num_frames, device=device) % 10].contiguous()
+
+        def force_b(cur, scores):
+            s = torch.full_like(scores, -1e9)
+            s[:, forced[cur.shape[1] - T]] = 0.0
+            return s
+
+        def run_b():
+            return model.sample_batch(idb, logits_processor=[force_b], max_length=T + len(forced), eos_token_id=2, image=imgb)
+        ob = run_b()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ob = run_b()
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        res["batched"] = {"batch": Bb, "samples_per_s": Bb / dtb, "ms_per_batch": dtb * 1e3, "hands_decoded": ob.num_hands[0],
+                          "note": "lock-step generation of 32 samples, CLIP on all 100 frames of each (bench.py --fp8-eval: fp8 prefill, de-dup)"}
+        model.stack._kv_cache_b = None
+    except Exception as ex:  # noqa
+        res["batched"] = {"error": str(ex)[:200]}
+    return res
 
 
 def spawn_ranks(args):
