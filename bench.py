@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
+    ap.add_argument("--clip-dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="CLIP tower dtype: fp16 = the reference's (handsonvlm/train/train.py:316), same MFMA rate")
     ap.add_argument("--recompute", nargs="?", const=-1, default=0, type=int, metavar="N",
                     help="activation recompute (scripts/finetune.sh:36): keep only the layer input and re-run the layer forward in "
                          "backward, for the first N layers (no value: all layers)")
@@ -78,6 +80,7 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
+    cfg.vision_dtype = args.clip_dtype
     cfg.activation_recompute = True if args.recompute < 0 else args.recompute
     cfg.pack_sequences = args.pack
     cfg.vision.image_size = args.image_size
@@ -568,7 +571,7 @@ def main():
                                    + ("_recompute" if args.recompute else ""),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "frames_through_clip_per_sample": n_frames // B,
-                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
+                       "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "clip_tower_dtype": args.clip_dtype, "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
                        "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",
                        "packed_rows": bool(args.pack)},
             "step_tflop_algorithmic": step_flops / 1e12,

@@ -85,8 +85,9 @@ __device__ __forceinline__ bf16x8 lds_frag64x2(const char* smem, unsigned off0, 
   u32x4 v = {a[0], a[1], b[0], b[1]};
   return __builtin_bit_cast(bf16x8, v);
 }
+template <bool F16 = false>
 __device__ __forceinline__ bf16x8 pack8(const float* p) {
-  u32x4 v = {pack_bf2(p[0], p[1]), pack_bf2(p[2], p[3]), pack_bf2(p[4], p[5]), pack_bf2(p[6], p[7])};
+  u32x4 v = {E16<F16>::pack2(p[0], p[1]), E16<F16>::pack2(p[2], p[3]), E16<F16>::pack2(p[4], p[5]), E16<F16>::pack2(p[6], p[7])};
   return __builtin_bit_cast(bf16x8, v);
 }
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -106,7 +107,7 @@ constexpr float LN2 = 0.6931471805599453f;
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH, bool CAUSAL, int NW>
+template <int DH, bool CAUSAL, int NW, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
                                                        const bf16_t* __restrict__ vt,
                                                        bf16_t* __restrict__ out,
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
           const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+          s[kb] = E16<F16>::mfma32(kf, qf[ks], s[kb]);
         }
       const bool need_mask = (kv0 + 32 * NKB > S) || (CAUSAL && kv0 + 32 * NKB - 1 > q0 + w * 32);
       float mx = -INFINITY;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
           float pv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
-          const bf16x8 pf = pack8(pv);
+          const bf16x8 pf = pack8<F16>(pv);
           const unsigned kbytes = sV + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
           s16x4_t lo[DH / 32], hi4[DH / 32];
 #pragma unroll
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
           for (int db = 0; db < DH / 32; ++db) {
             s16x8_t vv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
             asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[db], 0, 0, 0);
+            o[db] = E16<F16>::mfma32(__builtin_bit_cast(bf16x8, vv), pf, o[db]);
           }
         }
     };
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 v = {pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                   pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+        u32x2 v = {E16<F16>::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                   E16<F16>::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(op + d) = v;
       }
     if (lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 //   9 x 32 by 9 x 32 (1.26x).  Same online-softmax body, 64 keys per step.
 // =================================================================================================
 
-template <int DH>
+template <int DH, bool F16 = false>
 __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t* __restrict__ qkv,
                                                                    bf16_t* __restrict__ out,
                                                                    float* __restrict__ lse, int S, int H, int ld,
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
           const bf16x8 kf = lds_frag128(smem, base + k_off[ks] + kvb + (unsigned)(kb * 32) * ROWB);
-          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
+          sc[kb] = E16<F16>::mfma32(kf, qf[ks], ks == 0 ? zero16 : sc[kb]);
         }
       if constexpr (MASK) {
 #pragma unroll
@@ -420,10 +421,10 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
           float pv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) pv[j] = sc[kb][8 * sp + j];
-          const bf16x8 pf = pack8(pv);
+          const bf16x8 pf = pack8<F16>(pv);
 #pragma unroll
           for (int db = 0; db < DH / 32; ++db)
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db], 0, 0, 0);
+            o[db] = E16<F16>::mfma32(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db]);
         }
     };
     {
@@ -447,8 +448,8 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = db * 32 + 8 * g + 4 * hi;
-          u32x2 v = {pack_bf2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                     pack_bf2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
+          u32x2 v = {E16<F16>::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                     E16<F16>::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
           *reinterpret_cast<u32x2*>(op + d) = v;
         }
       if (lse && hi == 0) lse[((long)b * H + h) * S + qi] = m * LN2 + logf(ltot);
@@ -869,7 +870,7 @@ static int launch_head_transpose(const bf16_t* src, bf16_t* dst, int B, int S, i
   return check_launch("head_transpose");
 }
 
-template <int DH, bool CAUSAL>
+template <int DH, bool CAUSAL, bool F16 = false>
 static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int B, int S, int H, int ld,
                     float scale, hipStream_t st, const int32_t* cu = nullptr) {
   int rc;
@@ -878,7 +879,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
     const int nkb = (S + 31) / 32;
     if (nkb <= 9 && !getenv("HVLM_ATTN_NO_RESIDENT")) {
       const int lds = 2 * 2 * nkb * 32 * DH * 2;       // two (K + V) buffers
-      rc = set_lds(attn_fwd_resident_kernel<DH>, lds, "attn_fwd_resident");
+      rc = set_lds(attn_fwd_resident_kernel<DH, F16>, lds, "attn_fwd_resident");
       if (rc) return rc;
       static int cus = 0;
       if (!cus) {
@@ -886,7 +887,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
       }
       const int nitems = B * H;
-      hipLaunchKernelGGL((attn_fwd_resident_kernel<DH>), dim3(nitems < cus ? nitems : cus), dim3(64 * (nkb + 1)), lds, st, qkv, out, lse,
+      hipLaunchKernelGGL((attn_fwd_resident_kernel<DH, F16>), dim3(nitems < cus ? nitems : cus), dim3(64 * (nkb + 1)), lds, st, qkv, out, lse,
                          S, H, ld, nkb, nitems, scale * LOG2E);
       return check_launch("attn_fwd_resident");
     }
@@ -895,16 +896,16 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   // rows per workgroup: 128 (4 waves) or 96 (3 waves) — whichever wastes fewer query rows (S=257 -> 96)
   const int waste4 = (S + 127) / 128 * 128 - S, waste3 = (S + 95) / 96 * 96 - S;
   if (false && waste3 < waste4) {   // 96-row workgroups measured slower in situ (649 vs 593 us per CLIP layer): kept for A/B only
-    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 3>, LDS, "attn_fwd");
+    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 3, F16>, LDS, "attn_fwd");
     if (rc) return rc;
     dim3 grid((S + 95) / 96, H, B);
-    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 3>), grid, dim3(192), LDS, st, qkv, (const bf16_t*)ws, out,
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 3, F16>), grid, dim3(192), LDS, st, qkv, (const bf16_t*)ws, out,
                        lse, S, H, ld, spad(S), scale * LOG2E, cu);
   } else {
-    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4>, LDS, "attn_fwd");
+    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4, F16>, LDS, "attn_fwd");
     if (rc) return rc;
     dim3 grid((S + 127) / 128, H, B);
-    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 4>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)ws, out,
+    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 4, F16>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)ws, out,
                        lse, S, H, ld, spad(S), scale * LOG2E, cu);
   }
   return check_launch("attn_fwd");
@@ -1022,4 +1023,15 @@ extern "C" int hvlm_attn_bwd_varlen(const void* qkv, const void* out, const void
                                : bwd_impl<128, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens);
   return causal ? bwd_impl<64, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens)
                 : bwd_impl<64, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens);
+}
+
+
+// fp16 instantiation (IEEE half q/k/v/out, v_mfma_f32_32x32x16_f16; P is rounded to fp16 for the PV product): the CLIP
+// tower's attention in the reference's own dtype (handsonvlm/train/train.py:316).  Non-causal, dh = 64 (CLIPAttention).
+extern "C" int hvlm_attn_fwd_f16(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh, int ld,
+                                 int causal, float scale, void* stream) {
+  HVLM_REQUIRE(qkv && out && ws, "attn_fwd_f16: null pointer");
+  HVLM_REQUIRE(B > 0 && S > 0 && H > 0 && ld >= 3 * H * dh && ld % 8 == 0, "attn_fwd_f16: bad shape");
+  HVLM_REQUIRE(dh == 64 && !causal, "attn_fwd_f16: the fp16 instantiation is the CLIP attention (dh = 64, non-causal)");
+  return fwd_impl<64, false, true>((const bf16_t*)qkv, (bf16_t*)out, lse, (bf16_t*)ws, B, S, H, ld, scale, as_stream(stream));
 }

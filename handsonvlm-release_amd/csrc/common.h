@@ -40,6 +40,32 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(unsigned int p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
 
+// ---- fp16 <-> f32 (the CLIP tower runs in fp16 like the reference: handsonvlm/train/train.py:316) -------------------
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ float h2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f2h(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }     // round-to-nearest-even
+__device__ __forceinline__ unsigned int pack_h2(float lo, float hi) {
+  const f16x2 r = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(unsigned int, r);
+}
+__device__ __forceinline__ float h_lo(unsigned int p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float h_hi(unsigned int p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+
+// 16-bit element type selected at compile time: F16 = false -> bfloat16, true -> IEEE half.  Storage is always uint16.
+template <bool F16>
+struct E16 {
+  static __device__ __forceinline__ float to_f(bf16_t h) { if constexpr (F16) return h2f(h); else return bf2f(h); }
+  static __device__ __forceinline__ bf16_t from_f(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+  static __device__ __forceinline__ unsigned int pack2(float lo, float hi) { if constexpr (F16) return pack_h2(lo, hi); else return pack_bf2(lo, hi); }
+  static __device__ __forceinline__ float lo(unsigned int p) { if constexpr (F16) return h_lo(p); else return bf_lo(p); }
+  static __device__ __forceinline__ float hi(unsigned int p) { if constexpr (F16) return h_hi(p); else return bf_hi(p); }
+  static __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
 // ---- wave / block reductions (wave = 64) -----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

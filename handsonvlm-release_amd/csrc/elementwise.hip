@@ -164,6 +164,20 @@ __global__ __launch_bounds__(EW_THREADS) void cast_b2f_kernel(const bf16_t* __re
   }
 }
 
+// 16-bit <-> 16-bit: bf16 -> fp16 (TO_F16) or fp16 -> bf16, 8 elements per thread, n % 8 == 0.  The reference casts the
+// frames to the tower's dtype (clip_encoder.py:44,48: images.to(dtype=self.dtype)) and the features back (.to(images.dtype)).
+template <bool TO_F16>
+__global__ __launch_bounds__(EW_THREADS) void cast16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long n8) {
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < n8; i += (long)gridDim.x * EW_THREADS) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(in)[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = TO_F16 ? pack_h2(bf_lo(v[e]), bf_hi(v[e])) : pack_bf2(h_lo(v[e]), h_hi(v[e]));
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+}
+
 // ---- transpose: out[C, R_pad] = in[R, C]^T, 64x64 tiles through LDS ----------------------------
 // LDS tile: 64 rows x 128 B, the 16-B chunk c of row r stored at chunk position c ^ ((r>>3)&7): one conflict-free
 // ds_write_b128 per loaded chunk; the gather reads one dword (TWO adjacent columns) from 8 consecutive rows and splits
@@ -303,6 +317,20 @@ extern "C" int hvlm_cast_bf16_to_f32(const void* in, float* out, long n, void* s
   hipLaunchKernelGGL(cast_b2f_kernel, dim3(ew_grid(n / 4 + 1)), dim3(EW_THREADS), 0, as_stream(stream),
                      (const bf16_t*)in, out, n);
   return check_launch("cast_bf16_to_f32");
+}
+
+extern "C" int hvlm_cast_bf16_to_f16(const void* in, void* out, long n, void* stream) {
+  HVLM_REQUIRE(in && out && n > 0 && n % 8 == 0, "cast_bf16_to_f16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(cast16_kernel<true>, dim3(ew_grid(n / 8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)in,
+                     (bf16_t*)out, n / 8);
+  return check_launch("cast_bf16_to_f16");
+}
+
+extern "C" int hvlm_cast_f16_to_bf16(const void* in, void* out, long n, void* stream) {
+  HVLM_REQUIRE(in && out && n > 0 && n % 8 == 0, "cast_f16_to_bf16: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(cast16_kernel<false>, dim3(ew_grid(n / 8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)in,
+                     (bf16_t*)out, n / 8);
+  return check_launch("cast_f16_to_bf16");
 }
 
 extern "C" int hvlm_transpose_bf16(const void* in, void* out, int R, int C, int ld_in, int R_pad,

@@ -27,6 +27,8 @@ int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream);
 int pp_sched_slot(hipStream_t stream);
 // same kernel, both operands K-strided (A is [K, M], B is [K, N]; lda / ldb = row strides of those): dW = dY^T X
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream);
+// same kernel on IEEE fp16 operands / output (v_mfma_f32_32x32x16_f16): the CLIP tower in the reference's dtype
+int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream);
 // same kernel on OCP e4m3 operands (A, B point at bytes; lda / ldb in bytes = elements), C = alpha * A B^T (+ epilogue)
 int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream);
 

@@ -89,10 +89,11 @@ __device__ PPSched g_pp_all[PP_NSCHED];
 // LDS image, the DMA pieces, the swizzle and the whole 8-phase schedule are unchanged; a fragment is two ds_read_b128
 // (32 k-bytes per lane), 4 MFMAs of 64 cycles per phase instead of 8 of 32.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false>
+template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
-  static_assert(!(TN && SEG4), "the 4-segment schedule is for K-contiguous operands");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
+  static_assert(!(F16 && (TN || FP8)), "the fp16 instantiation (CLIP tower) is K-contiguous, 16-bit");
+  using EL = E16<F16>;                      // 16-bit element type of A / B / C / bias / residual: bfloat16 or IEEE half
   constexpr int ES = FP8 ? 1 : 2;          // operand element size in bytes
   constexpr int NKS = FP8 ? 2 : 4;         // MFMA k-steps per K-tile
   using frag_t = std::conditional_t<FP8, i32x8, bf16x8>;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
           const bool full = (nb + 3 < p.N);
           if (p.bias) {
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(p.bias[nb + e]);
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += EL::to_f(p.bias[nb + e]);
           }
           if (p.act == HVLM_ACT_QUICK_GELU) {
 #pragma unroll
@@ -337,7 +338,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           }
           if (p.res) {
             const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
-            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += bf2f(rp[e]);
+            for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += EL::to_f(rp[e]);
           }
           if (p.out_f32) {
             float* cp = reinterpret_cast<float*>(p.C) + c_slab + (size_t)m * p.ldc + nb;
@@ -350,10 +351,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           } else {
             bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
             if (full) {
-              u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+              u32x2 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3])};
               *reinterpret_cast<u32x2*>(cp) = o;
             } else {
-              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = f2bf(v[e]);
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = EL::from_f(v[e]);
             }
           }
         }
@@ -403,13 +404,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
             if (p.bias) {
               const u32x2 bb = bias_q[j][g];
-              v[0] += bf_lo(bb[0]); v[1] += bf_hi(bb[0]); v[2] += bf_lo(bb[1]); v[3] += bf_hi(bb[1]);
+              v[0] += EL::lo(bb[0]); v[1] += EL::hi(bb[0]); v[2] += EL::lo(bb[1]); v[3] += EL::hi(bb[1]);
             }
             if (p.act == HVLM_ACT_QUICK_GELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
             }
-            const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            const u32x2 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(epi + (f & 1) * 2048 + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = o;
           }
         }
@@ -438,7 +439,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       for (int j = 0; j < 2; ++j) {
         const u32x4 bb = *reinterpret_cast<const u32x4*>(p.bias + ncol0 + j * 32);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { bias_f[j][2 * e] = bf_lo(bb[e]); bias_f[j][2 * e + 1] = bf_hi(bb[e]); }
+        for (int e = 0; e < 4; ++e) { bias_f[j][2 * e] = EL::lo(bb[e]); bias_f[j][2 * e + 1] = EL::hi(bb[e]); }
       }
     }
 #pragma unroll
@@ -478,11 +479,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             u32x4 rr = res_r[j][q];
             asm volatile("" : "+v"(rr));   // consume the load outside the `m < M` branch: nothing stays pending on any path
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rr[e]); v[2 * e + 1] += bf_hi(rr[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += EL::lo(rr[e]); v[2 * e + 1] += EL::hi(rr[e]); }
           }
           const int m = mrow0 + 16 * q;
           if (m < p.M) {
-            const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+            const u32x4 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3]), EL::pack2(v[4], v[5]), EL::pack2(v[6], v[7])};
             store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
           }
         }
@@ -540,8 +541,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         acc[J][I0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0, SCALE1, 0, SCALE1); \
         acc[J][I0 + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0, SCALE1, 0, SCALE1); \
       } else {                                                                                            \
-        acc[J][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF0[KS], acc[J][I0], 0, 0, 0);       \
-        acc[J][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF[KS], AF1[KS], acc[J][I0 + 1], 0, 0, 0); \
+        acc[J][I0] = EL::mfma32(BF[KS], AF0[KS], acc[J][I0]);       \
+        acc[J][I0 + 1] = EL::mfma32(BF[KS], AF1[KS], acc[J][I0 + 1]); \
       }                                                                                                   \
     }                                                                                                     \
   } while (0)
@@ -567,10 +568,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         acc[1][I0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb1[KS], AF0[KS], acc[1][I0], 0, 0, 0, SCALE1, 0, SCALE1); \
         acc[1][I0 + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb1[KS], AF1[KS], acc[1][I0 + 1], 0, 0, 0, SCALE1, 0, SCALE1); \
       } else {                                                                                            \
-        acc[0][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[KS], AF0[KS], acc[0][I0], 0, 0, 0);      \
-        acc[0][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[KS], AF1[KS], acc[0][I0 + 1], 0, 0, 0); \
-        acc[1][I0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[KS], AF0[KS], acc[1][I0], 0, 0, 0);      \
-        acc[1][I0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[KS], AF1[KS], acc[1][I0 + 1], 0, 0, 0); \
+        acc[0][I0] = EL::mfma32(fb0[KS], AF0[KS], acc[0][I0]);      \
+        acc[0][I0 + 1] = EL::mfma32(fb0[KS], AF1[KS], acc[0][I0 + 1]); \
+        acc[1][I0] = EL::mfma32(fb1[KS], AF0[KS], acc[1][I0]);      \
+        acc[1][I0 + 1] = EL::mfma32(fb1[KS], AF1[KS], acc[1][I0 + 1]); \
       }                                                                                                   \
     }                                                                                                     \
   } while (0)
@@ -619,6 +620,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         read_a(sb, T1{}, fa1);
         if (!(DBG && (p.dbg & 2))) stage_a(ob, 1, c1);
         HVLM_PHASE_SYNC();
+        if constexpr (TN) {   // the transpose reads are inline asm (untracked): retire them here, fragments as operands
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3]), "+v"(fb1[0]), "+v"(fb1[1]),
+                       "+v"(fb1[2]), "+v"(fb1[3]), "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
+                       "+v"(fa1[2]), "+v"(fa1[3]));
+        }
         HVLM_MFMA_OCT(0, fa0, fa1);
         __builtin_amdgcn_s_barrier();
         if (!(DBG && (p.dbg & 8))) {           // dbg 8: a third of the fragment reads gone (stale A fragments of half 0)
@@ -631,6 +637,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           stage_b(cb, 1, c2);
         }
         HVLM_PHASE_SYNC();
+        if constexpr (TN) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
+                       "+v"(fa1[2]), "+v"(fa1[3]));
+        }
         HVLM_MFMA_OCT(2, fa0, fa1);
       } else {
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
@@ -758,11 +768,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_
 // the same kernel with the K-loop ablation switches of GemmArgs::dbg compiled in (HVLM_GEMM_DBG != 0 only)
 __global__ __launch_bounds__(512, 2) void gemm_pp4_dbg_kernel(GemmArgs p) { gemm_pp_body<false, false, true, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_tn_kernel(GemmArgs p) { gemm_pp_body<true, false, true>(p); }
+// IEEE-half operands / output on v_mfma_f32_32x32x16_f16 (same rate): the CLIP tower in the reference's own dtype
+__global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true>(p); }
 
-template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4 = NT bf16, NT fp8 on the 4-segment schedule; 5 = 3 + ablation switches
+template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4, 6 = NT bf16, NT fp8, TN bf16 on the 4-segment schedule; 5 = 3 + ablation switches
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -771,7 +784,9 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
     }
     attr_done = true;
   }
-  if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  if (KIND == 7) hipLaunchKernelGGL(gemm_pp4_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 6) hipLaunchKernelGGL(gemm_pp4_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 4) hipLaunchKernelGGL(gemm_pp4_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 5) hipLaunchKernelGGL(gemm_pp4_dbg_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 3) hipLaunchKernelGGL(gemm_pp4_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
@@ -797,11 +812,16 @@ static bool use_seg4() {
   static const bool v = !(getenv("HVLM_GEMM_SEG4") && atoi(getenv("HVLM_GEMM_SEG4")) == 0);
   return v;
 }
+int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<7>(p, grid, stream); }
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   if (p.dbg) return launch_pp<5>(p, grid, stream);
   return use_seg4() ? launch_pp<3>(p, grid, stream) : launch_pp<0>(p, grid, stream);
 }
-int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<1>(p, grid, stream); }
+// HVLM_GEMM_TN_SEG4=0 keeps the K-strided (TN) kernel on the 8-phase schedule (A/B switch; default = 4-segment)
+int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) {
+  static const bool seg4 = !(getenv("HVLM_GEMM_TN_SEG4") && atoi(getenv("HVLM_GEMM_TN_SEG4")) == 0);
+  return seg4 ? launch_pp<6>(p, grid, stream) : launch_pp<1>(p, grid, stream);
+}
 int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
   return use_seg4() ? launch_pp<4>(p, grid, stream) : launch_pp<2>(p, grid, stream);
 }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   }
 }
 
-template <int TPR>
+template <int TPR, bool F16>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ b,
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
       const u32x4 xv = *reinterpret_cast<const u32x4*>(xr + i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[c][2 * e] = bf_lo(xv[e]); v[c][2 * e + 1] = bf_hi(xv[e]);
+        v[c][2 * e] = E16<F16>::lo(xv[e]); v[c][2 * e + 1] = E16<F16>::hi(xv[e]);
         s += v[c][2 * e] + v[c][2 * e + 1];
       }
     }
@@ -224,9 +224,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float r0 = (v[c][2 * e] - mean) * rstd * bf_lo(wv[e]) + bf_lo(bv[e]);
-        const float r1 = (v[c][2 * e + 1] - mean) * rstd * bf_hi(wv[e]) + bf_hi(bv[e]);
-        o[e] = pack_bf2(r0, r1);
+        const float r0 = (v[c][2 * e] - mean) * rstd * E16<F16>::lo(wv[e]) + E16<F16>::lo(bv[e]);
+        const float r1 = (v[c][2 * e + 1] - mean) * rstd * E16<F16>::hi(wv[e]) + E16<F16>::hi(bv[e]);
+        o[e] = E16<F16>::pack2(r0, r1);
       }
       *reinterpret_cast<u32x4*>(yr + i) = o;
     }
@@ -271,16 +271,25 @@ extern "C" int hvlm_reduce_rows_f32(const float* in, void* out, int rows, int D,
   return check_launch("reduce_rows_f32");
 }
 
-extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows,
-                                  int D, float eps, void* stream) {
+static int layernorm_impl(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, bool f16,
+                          void* stream) {
   HVLM_REQUIRE(x && w && b && y, "layernorm_fwd: null pointer");
   HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "layernorm_fwd: bad D=%d", D);
-  if (D <= 2048) {
-    hipLaunchKernelGGL((layernorm_fwd_kernel<64>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, D, eps);
-  } else {
-    hipLaunchKernelGGL((layernorm_fwd_kernel<256>), dim3(rows), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, D, eps);
-  }
+#define HVLM_LN(TPR, F, GRID)                                                                                         \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<TPR, F>), dim3(GRID), dim3(256), 0, as_stream(stream), (const bf16_t*)x,   \
+                     (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, rows, D, eps)
+  if (D <= 2048) { if (f16) HVLM_LN(64, true, cdiv(rows, 4)); else HVLM_LN(64, false, cdiv(rows, 4)); }
+  else { if (f16) HVLM_LN(256, true, rows); else HVLM_LN(256, false, rows); }
+#undef HVLM_LN
   return check_launch("layernorm_fwd");
+}
+
+extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps,
+                                  void* stream) {
+  return layernorm_impl(x, w, b, y, rows, D, eps, false, stream);
+}
+
+extern "C" int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps,
+                                      void* stream) {
+  return layernorm_impl(x, w, b, y, rows, D, eps, true, stream);
 }

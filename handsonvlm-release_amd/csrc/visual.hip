@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 }
 
 // tokens[n, 0] = cls + pos[0]; tokens[n, 1+p] = patch_out[n*NP+p] + pos[1+p]
+template <bool F16>
 __global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restrict__ patch_out,
                                                          const bf16_t* __restrict__ cls,
                                                          const bf16_t* __restrict__ pos,
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const bf16_t* __restric
     const u32x4 b = *reinterpret_cast<const u32x4*>(pos + (long)t * D + c);
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(bf_lo(a[e]) + bf_lo(b[e]), bf_hi(a[e]) + bf_hi(b[e]));
+    for (int e = 0; e < 4; ++e) o[e] = E16<F16>::pack2(E16<F16>::lo(a[e]) + E16<F16>::lo(b[e]), E16<F16>::hi(a[e]) + E16<F16>::hi(b[e]));
     *reinterpret_cast<u32x4*>(tokens + tokrow * (long)D + c) = o;
   }
 }
@@ -277,10 +278,20 @@ extern "C" int hvlm_clip_embed(const void* patch_out, const void* cls, const voi
                                int N, int NP, int D, void* stream) {
   HVLM_REQUIRE(patch_out && cls && pos && tokens && N > 0 && NP > 0 && D % 8 == 0, "clip_embed: bad args");
   const long total = (long)N * (NP + 1) * (D / 8);
-  hipLaunchKernelGGL(clip_embed_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(clip_embed_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                      (const bf16_t*)patch_out, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)tokens,
                      (long)N, NP, D);
   return check_launch("clip_embed");
+}
+
+extern "C" int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens,
+                                   int N, int NP, int D, void* stream) {
+  HVLM_REQUIRE(patch_out && cls && pos && tokens && N > 0 && NP > 0 && D % 8 == 0, "clip_embed_f16: bad args");
+  const long total = (long)N * (NP + 1) * (D / 8);
+  hipLaunchKernelGGL(clip_embed_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)patch_out, (const bf16_t*)cls, (const bf16_t*)pos, (bf16_t*)tokens,
+                     (long)N, NP, D);
+  return check_launch("clip_embed_f16");
 }
 
 extern "C" int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,

@@ -24,7 +24,14 @@ BF16 = torch.bfloat16
 
 
 class CLIPVisionTower:
-    def __init__(self, cfg: CLIPVisionConfig, device, select_layer: int = -2, select_feature: str = "patch"):
+    def __init__(self, cfg: CLIPVisionConfig, device, select_layer: int = -2, select_feature: str = "patch",
+                 dtype: torch.dtype = BF16):
+        """dtype = torch.float16 runs the tower in the reference's own dtype (handsonvlm/train/train.py:316,
+        handsonvlm/model/builder.py:108: `vision_tower.to(dtype=torch.float16)`): fp16 weights, activations and MFMA
+        operands, frames cast bf16 -> fp16 on the way in and features fp16 -> bf16 on the way out exactly like
+        clip_encoder.py:44-48.  bf16 (the default) keeps one dtype through the whole step."""
+        assert dtype in (BF16, torch.float16)
+        self.wdtype = dtype
         self.cfg = cfg
         self.device = torch.device(device)
         self.select_layer = select_layer
@@ -46,7 +53,7 @@ class CLIPVisionTower:
 
     @property
     def dtype(self):
-        return BF16
+        return self.wdtype
 
     @property
     def dummy_feature(self):
@@ -59,11 +66,12 @@ class CLIPVisionTower:
         d = cfg.hidden_size
         if prefix + "embeddings.class_embedding" not in sd and "embeddings.class_embedding" in sd:
             prefix = ""                  # transformers >= 5 writes CLIPVisionModel keys without the `vision_model.` level
-        g = lambda k: sd[prefix + k].to(device=dev, dtype=BF16).contiguous()  # noqa: E731
+        WD = self.wdtype
+        g = lambda k: sd[prefix + k].to(device=dev, dtype=WD).contiguous()  # noqa: E731
         p = {}
         w = sd[prefix + "embeddings.patch_embedding.weight"].reshape(d, -1)
-        wp = torch.zeros(d, self.kpad, dtype=BF16, device=dev)
-        wp[:, : w.shape[1]] = w.to(device=dev, dtype=BF16)
+        wp = torch.zeros(d, self.kpad, dtype=WD, device=dev)
+        wp[:, : w.shape[1]] = w.to(device=dev, dtype=WD)
         p["patch_w"] = wp
         p["cls"] = g("embeddings.class_embedding")
         p["pos"] = g("embeddings.position_embedding.weight")
@@ -86,14 +94,15 @@ class CLIPVisionTower:
         cfg, dev = self.cfg, self.device
         d, m = cfg.hidden_size, cfg.intermediate_size
         gen = torch.Generator(device=dev).manual_seed(seed)
-        rn = lambda *s, sc=std: (torch.randn(*s, device=dev, generator=gen) * sc).to(BF16)  # noqa: E731
+        WD = self.wdtype
+        rn = lambda *s, sc=std: (torch.randn(*s, device=dev, generator=gen) * sc).to(WD)  # noqa: E731
         p = {"patch_w": rn(d, self.kpad), "cls": rn(d), "pos": rn(cfg.num_patches + 1, d),
-             "pre_ln_w": torch.ones(d, device=dev, dtype=BF16), "pre_ln_b": torch.zeros(d, device=dev, dtype=BF16)}
+             "pre_ln_w": torch.ones(d, device=dev, dtype=WD), "pre_ln_b": torch.zeros(d, device=dev, dtype=WD)}
         p["patch_w"][:, 3 * cfg.patch_size ** 2:] = 0
         for i in range(self.n_run):
             for n in ("ln1", "ln2"):
-                p[f"{i}.{n}_w"] = torch.ones(d, device=dev, dtype=BF16)
-                p[f"{i}.{n}_b"] = torch.zeros(d, device=dev, dtype=BF16)
+                p[f"{i}.{n}_w"] = torch.ones(d, device=dev, dtype=WD)
+                p[f"{i}.{n}_b"] = torch.zeros(d, device=dev, dtype=WD)
             p[f"{i}.qkv_w"], p[f"{i}.qkv_b"] = rn(3 * d, d), rn(3 * d)
             p[f"{i}.o_w"], p[f"{i}.o_b"] = rn(d, d), rn(d)
             p[f"{i}.fc1_w"], p[f"{i}.fc1_b"] = rn(m, d), rn(m)
@@ -114,23 +123,35 @@ class CLIPVisionTower:
         NP = cfg.num_patches
         T = NP + 1
         x_img = images.to(device=self.device, dtype=BF16).contiguous()
-        patches = ops.patch_im2col(x_img, cfg.patch_size, self.kpad)
-        pe = ops.gemm_nt(patches, p["patch_w"])
+        f16 = self.wdtype == torch.float16
+        if f16:
+            x_img = ops.cast16(x_img, torch.float16)               # images.to(dtype=self.dtype), clip_encoder.py:48
+        mm = ops.gemm_f16_nt if f16 else ops.gemm_nt
+        ln = ops.layernorm_fwd_f16 if f16 else ops.layernorm_fwd
+        patches = ops.patch_im2col(x_img.view(BF16) if f16 else x_img, cfg.patch_size, self.kpad)    # 2-byte moves: dtype-agnostic
+        if f16:
+            patches = patches.view(torch.float16)
+        pe = mm(patches, p["patch_w"])
         del patches
-        x = ops.clip_embed(pe, p["cls"], p["pos"], N, NP, d).view(N * T, d)
+        x = (ops.clip_embed_f16 if f16 else ops.clip_embed)(pe, p["cls"], p["pos"], N, NP, d).view(N * T, d)
         del pe
-        x = ops.layernorm_fwd(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
+        x = ln(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
         scale = dh ** -0.5
         for i in range(self.n_run):
-            y = ops.layernorm_fwd(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
-            qkv = ops.gemm_nt(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
-            a, _ = ops.attn_fwd(qkv, N, T, heads, dh, False, scale, need_lse=False)
+            y = ln(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
+            qkv = mm(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
+            if f16:
+                a = ops.attn_fwd_f16(qkv, N, T, heads, dh, scale)
+            else:
+                a, _ = ops.attn_fwd(qkv, N, T, heads, dh, False, scale, need_lse=False)
             del qkv
-            x = ops.gemm_nt(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x)
-            y = ops.layernorm_fwd(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps, out=y)
-            hmid = ops.gemm_nt(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
-            x = ops.gemm_nt(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x)
+            x = mm(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x)
+            y = ln(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps, out=y)
+            hmid = mm(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+            x = mm(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x)
             del hmid
+        if f16:
+            x = ops.cast16(x, BF16)                                # image_features.to(images.dtype), clip_encoder.py:48
         return x.view(N, T, d)
 
     @torch.no_grad()

@@ -30,6 +30,7 @@ from . import ops
 from .config import HandsOnVLMConfig
 
 BF16 = torch.bfloat16
+_DW_TN = os.environ.get("HVLM_DW_TN", "0") == "1"      # weight-gradient GEMMs on K-strided operands (A/B switch, see _dw)
 
 
 def _round_up(x: int, m: int) -> int:
@@ -392,6 +393,11 @@ class LlamaStack:
         its last, partial round of tiles (880 tiles on 256 CUs = 3.44 rounds).  Measured: 0 - 0.7 % on the SFT step (two
         persistent one-workgroup-per-CU kernels mostly just take turns), so it is OFF by default."""
         side = self._side_stream()
+        if _DW_TN and dy.stride(1) == 1 and xin.stride(1) == 1:
+            # dW = dY^T X straight from the token-major activations: the K-strided (TN) instantiation of the ping-pong GEMM
+            # gathers its fragments with LDS transpose reads — no transposed copies, no HBM-bound transpose kernels
+            ops.gemm(dy, xin, trans_a=True, trans_b=True, out=out)
+            return
         if side is None:
             dyT = ops.transpose(dy, r_pad=mpad)
             xT = ops.transpose(xin, r_pad=mpad)

@@ -99,7 +99,8 @@ class HandsOnVLMForCausalLM:
         D, V, Vp = config.hidden_size, config.vocab_size, config.vocab_padded
         dev = self.device
         self.traj_decoder_name = kwargs.get("traj_decoder_name", config.traj_decoder_name)
-        self.tower = CLIPVisionTower(config.vision, dev, config.mm_vision_select_layer, config.mm_vision_select_feature)
+        self.tower = CLIPVisionTower(config.vision, dev, config.mm_vision_select_layer, config.mm_vision_select_feature,
+                                     dtype=torch.float16 if config.vision_dtype == "fp16" else BF16)
         self.stack = LlamaStack(config, dev, training)
         self.embed = torch.zeros(V, D, dtype=BF16, device=dev)
         self.lm_head = torch.zeros(Vp, D, dtype=BF16, device=dev)          # rows >= V stay zero

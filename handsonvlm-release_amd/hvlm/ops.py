@@ -522,3 +522,68 @@ def cast_f32_to_bf16(x, out=None):
     y = torch.empty(x.shape, dtype=BF16, device=x.device) if out is None else out
     check(_lib.load().hvlm_cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "cast")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# fp16 instantiations (CLIP tower in the reference's dtype, handsonvlm/train/train.py:316)
+# ------------------------------------------------------------------------------------------------
+F16 = torch.float16
+
+
+def gemm_f16_nt(a, b, bias=None, residual=None, act: int = ACT_NONE, out=None):
+    """fp16 operands / output: out[M,N] = act(a[M,K] @ b[N,K]^T + bias) + residual."""
+    _chk(a, F16, "gemm_f16.a"); _chk(b, F16, "gemm_f16.b")
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F16, device=a.device)
+    assert out.dtype == F16 and out.shape == (M, N)
+    ldr = 0
+    if residual is not None:
+        _chk(residual, F16, "gemm_f16.residual")
+        ldr = residual.stride(0)
+    if bias is not None:
+        _chk(bias, F16, "gemm_f16.bias")
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_f16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), _p(bias),
+                                       _p(residual), ldr, act, 0, _stream()), "gemm_f16_nt")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
+def layernorm_fwd_f16(x, w, b, eps: float, out=None):
+    _chk(x, F16, "layernorm_f16.x")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().hvlm_layernorm_fwd_f16(_p(x), _p(w), _p(b), _p(y), x.numel() // D, D, eps, _stream()), "layernorm_fwd_f16")
+    return y
+
+
+def clip_embed_f16(patch_out, cls, pos, N: int, NP: int, D: int):
+    tokens = torch.empty((N, NP + 1, D), dtype=F16, device=patch_out.device)
+    check(_lib.load().hvlm_clip_embed_f16(_p(patch_out), _p(cls), _p(pos), _p(tokens), N, NP, D, _stream()), "clip_embed_f16")
+    return tokens
+
+
+def attn_fwd_f16(qkv, B: int, S: int, H: int, dh: int, scale: float):
+    _chk(qkv, F16, "attn_f16.qkv")
+    assert qkv.dim() == 2 and qkv.shape[0] == B * S and qkv.stride(1) == 1
+    lib = _lib.load()
+    o = torch.empty((B * S, H * dh), dtype=F16, device=qkv.device)
+    ws = torch.empty((lib.hvlm_attn_fwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
+    check(lib.hvlm_attn_fwd_f16(_p(qkv), _p(o), None, _p(ws), B, S, H, dh, qkv.stride(0), 0, scale, _stream()), "attn_fwd_f16")
+    return o
+
+
+def cast16(x, to_dtype):
+    """bf16 <-> fp16 (round-to-nearest-even), the casts of clip_encoder.py:44-48."""
+    assert x.is_contiguous() and x.numel() % 8 == 0 and {x.dtype, to_dtype} == {BF16, F16}
+    out = torch.empty(x.shape, dtype=to_dtype, device=x.device)
+    fn = _lib.load().hvlm_cast_bf16_to_f16 if to_dtype == F16 else _lib.load().hvlm_cast_f16_to_bf16
+    check(fn(_p(x), _p(out), x.numel(), _stream()), "cast16")
+    return out

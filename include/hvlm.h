@@ -298,6 +298,24 @@ int hvlm_hand_gather_bwd(const void* dout, const int32_t* rows, void* dhidden, i
                          int dout_f32, void* stream);
 
 /* ------------------------------------------------------------------------------------------ *
+ * fp16 instantiations for the CLIP tower.  The reference runs the frozen tower in IEEE half
+ * (handsonvlm/train/train.py:316 `vision_tower.to(dtype=torch.float16)`, handsonvlm/model/builder.py:108) and casts the
+ * frames to it and the features back (llava/model/multimodal_encoder/clip_encoder.py:44-48); these entry points are the
+ * same kernels as their bf16 namesakes with 16-bit IEEE-half storage and v_mfma_f32_32x32x16_f16 (same MFMA rate):
+ *   gemm_f16_nt (A, B, C, bias, residual all fp16), layernorm_fwd_f16, clip_embed_f16, attn_fwd_f16 (non-causal, dh = 64:
+ *   CLIPAttention; lse / ws as in hvlm_attn_fwd), and the two 16-bit casts (n % 8 == 0).
+ * ------------------------------------------------------------------------------------------ */
+int hvlm_gemm_f16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                     const void* bias, const void* residual, int ldr, int act, int out_f32, void* stream);
+int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, void* stream);
+int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,
+                        void* stream);
+int hvlm_attn_fwd_f16(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh, int ld, int causal,
+                      float scale, void* stream);
+int hvlm_cast_bf16_to_f16(const void* in, void* out, long n, void* stream);
+int hvlm_cast_f16_to_bf16(const void* in, void* out, long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------ *
  * Optimizer / elementwise
  * ------------------------------------------------------------------------------------------ */
 /* AdamW on fp32 master weights with bf16 gradients (scripts/finetune.sh:30-33: lr 2e-5, wd 0),

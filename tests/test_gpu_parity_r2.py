@@ -328,3 +328,60 @@ def test_packed_batch_matches_padded_batch_on_hip():
         assert rel(g1[n], g0[n]) < 1e-2, (n, rel(g1[n], g0[n]))
     l2, g2, _ = _step(_tiny_engine(pack_sequences=True, activation_recompute=True), batch)
     assert l2 == l1 and all(torch.equal(g1[n], g2[n]) for n in g1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp16 CLIP tower (the reference's dtype: handsonvlm/train/train.py:316, handsonvlm/model/builder.py:108)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_f16_ops_vs_oracle(ops):
+    """The fp16 instantiations (same kernels, IEEE-half storage, v_mfma_f32_32x32x16_f16) against fp32 restatements on the
+    same fp16-rounded inputs: GEMM with every epilogue, LayerNorm, CLIP embedding assembly, non-causal dh=64 attention
+    (resident and streaming kernels), the two casts (bit-exact against torch)."""
+    F16 = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).to(F16)  # noqa: E731
+    M, N, K = 1000, 520, 192
+    a, b, bias, res = rn(M, K), rn(N, K), rn(N), rn(M, N)
+    lin = torch.nn.functional.linear(a.float(), b.float(), bias.float())
+    assert rel(ops.gemm_f16_nt(a, b), (a.float() @ b.float().t()).to(F16)) <= 2e-4
+    assert rel(ops.gemm_f16_nt(a, b, bias=bias, residual=res, act=ops.ACT_QUICK_GELU), (R.quick_gelu(lin) + res.float()).to(F16)) <= 2e-4
+    assert rel(ops.gemm_f16_nt(a, b, bias=bias, act=ops.ACT_QUICK_GELU), R.quick_gelu(lin).to(F16)) <= 2e-4
+    x, w, bb = rn(300, 1024), (1 + 0.1 * rn(1024).float()).to(F16), rn(1024, sc=0.1)
+    ref = torch.nn.functional.layer_norm(x.float(), (1024,), w.float(), bb.float(), 1e-5)
+    assert rel(ops.layernorm_fwd_f16(x, w, bb, 1e-5), ref.to(F16)) <= 2e-4
+    pe, cls, pos = rn(3 * 256, 64), rn(64), rn(257, 64)
+    tok = ops.clip_embed_f16(pe, cls, pos, 3, 256, 64)
+    want = torch.cat([(cls.float() + pos[0].float()).expand(3, 1, 64), pe.float().view(3, 256, 64) + pos[1:].float()], 1)
+    assert torch.equal(tok, want.to(F16))
+    for B, S, H in ((70, 257, 16), (3, 577, 2)):                      # resident (4.4 items per workgroup) / streaming kernel
+        qkv = rn(B * S, 3 * H * 64, sc=0.8)
+        o = ops.attn_fwd_f16(qkv, B, S, H, 64, 64 ** -0.5)
+        xx = qkv.float().cpu().view(B, S, 3, H, 64).permute(2, 0, 3, 1, 4)
+        r = R.softmax_attention(xx[0], xx[1], xx[2], False, 64 ** -0.5)
+        assert rel(o.cpu().view(B, S, H, 64).permute(0, 2, 1, 3), r) <= 8e-4          # P rounded to fp16 (11 bits), not bf16
+    v = (torch.randn(4096, device="cuda", generator=g) * 3).to(BF)
+    assert torch.equal(ops.cast16(v, F16), v.to(F16)) and torch.equal(ops.cast16(v.to(F16), BF), v.to(F16).to(BF))
+
+
+def test_clip_tower_fp16_vit_l14_vs_oracle():
+    """The ViT-L/14-dimension tower in fp16 against the fp32 oracle, with the oracle's own fp16-eager run (= what the
+    reference executes: CLIPVisionModel in half precision) as the envelope."""
+    from hvlm.clip import CLIPVisionTower
+    from hvlm.config import CLIPVisionConfig
+    c = dict(clip_d=1024, clip_mlp=4096, clip_layers=24, clip_heads=16, patch=14, image=224)
+    pnp = synth.clip_params(c, seed=77)
+    p = synth.to_torch(pnp)
+    img = synth.make_images(1, 3, 3, 224, seed=31)[0].to(BF)               # frames arrive in bf16 (training dtype)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = R.clip_features(img.float(), p, 24, 16)                      # fp32
+        ph = synth.to_torch(pnp, torch.float16)
+        env = R.clip_features(img.to(torch.float16), ph, 24, 16).float()   # fp16 eager (the reference's tower)
+    tower = CLIPVisionTower(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                             num_attention_heads=16), "cuda:0", dtype=torch.float16)
+    tower.load_state_dict(p)
+    got = tower(img.cuda())
+    assert got.dtype == BF and got.shape == (3, 256, 1024)                 # features cast back to the frames' dtype
+    e_env, e_hip = rel(env.to(BF), ref), rel(got, ref)
+    print(f"ViT-L/14 tower fp16: HIP vs fp32 oracle {e_hip:.3e}; fp16-eager oracle (cast to bf16) vs fp32 oracle {e_env:.3e}")
+    assert e_hip <= 1.25 * e_env and e_hip <= 6e-3, (e_hip, e_env)
