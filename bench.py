@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
-    ap.add_argument("--clip-dtype", default="bf16", choices=["bf16", "fp16"],
+    ap.add_argument("--clip-dtype", default="fp16", choices=["bf16", "fp16"],
                     help="CLIP tower dtype: fp16 = the reference's (handsonvlm/train/train.py:316), same MFMA rate")
     ap.add_argument("--recompute", nargs="?", const=-1, default=0, type=int, metavar="N",
                     help="activation recompute (scripts/finetune.sh:36): keep only the layer input and re-run the layer forward in "

@@ -57,7 +57,7 @@ class HandsOnVLMConfig:
     project_after_pool: bool = True    # mm_projector commutes with the mean/avg pooling: 356 rows instead of 25 600
     dedup_frames: bool = False         # run CLIP once per unique frame (EK100 tiles 10 frames x10)
     clip_chunk_frames: int = 400       # frames per CLIP pass (bounds activation memory)
-    vision_dtype: str = "bf16"         # "fp16" = the CLIP tower in the reference's dtype (train.py:316, builder.py:108)
+    vision_dtype: str = "fp16"         # the CLIP tower in the reference's dtype (train.py:316, builder.py:108); "bf16" for A/B
     activation_recompute: bool = False  # keep only each decoder layer's input, re-run its forward in backward
                                         # (scripts/finetune.sh:36 `--gradient_checkpointing True`); off: 288 GB hold them
     pack_sequences: bool = False       # training batches without padding rows (cu_seqlens through the whole decoder: the

@@ -381,6 +381,40 @@ def cast_f32_to_bf16(x, out=None):
     return x.to(BF16)
 
 
+# ---- fp16 instantiations (CLIP tower in the reference's dtype) ----
+F16 = torch.float16
+
+
+def gemm_f16_nt(a, b, bias=None, residual=None, act=ACT_NONE, out=None):
+    y = gemm_nt(a, b, bias, residual, act, None, out_dtype=F16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def layernorm_fwd_f16(x, w, b, eps, out=None):
+    y = F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(F16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def clip_embed_f16(patch_out, cls, pos, N, NP, D):
+    return clip_embed(patch_out.float(), cls.float(), pos.float(), N, NP, D).to(F16) if False else \
+        torch.cat([(cls.float() + pos[0].float()).expand(N, 1, D), patch_out.float().view(N, NP, D) + pos[1:].float()], 1).to(F16)
+
+
+def attn_fwd_f16(qkv, B, S, H, dh, scale):
+    o, _ = _attn_padded(qkv.float(), B, S, H, dh, False, scale)
+    return o.to(F16)
+
+
+def cast16(x, to_dtype):
+    return x.to(to_dtype)
+
+
 def set_gemm_hook(hook):
     pass
 
