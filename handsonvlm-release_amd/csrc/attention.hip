@@ -678,8 +678,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 // =================================================================================================
 // backward, dK / dV  (one key per lane)
 // =================================================================================================
-template <int DH, bool CAUSAL>
-__global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
+// MODE 0: dK and dV in one pass (one wave per SIMD at dh = 128: 412 registers).  MODE 1: dV only (S -> P -> dV^T += dO^T P),
+// MODE 2: dK only (S, dP -> dS -> dK^T += Q^T dS): half the accumulators each, so TWO waves per SIMD fit at dh = 128 and the
+// softmax VALU of one wave overlaps the MFMAs of the other; S (and the exponentials) are computed in both passes.
+template <int DH, bool CAUSAL, int MODE = 0>
+__global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt_g /*Q^T*/,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ dot_g /*dO^T*/,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S_max,
@@ -698,21 +701,25 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
   const int kc = min(ki, S - 1);
   const float scale_log2 = scale * LOG2E;
 
-  bf16x8 kf[DH / 16], vf[DH / 16];
+  constexpr bool DO_DV = MODE != 2, DO_DK = MODE != 1;
+  bf16x8 kf[DH / 16], vf[DO_DK ? DH / 16 : 1];
   {
     const bf16_t* kp = qkv + (tok0 + kc) * ld + (long)H * DH + h * DH + hi * 8;
     const bf16_t* vp = qkv + (tok0 + kc) * ld + 2L * H * DH + h * DH + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < DH / 16; ++ks) {
       kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
-      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
+      if constexpr (DO_DK) vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
     }
   }
-  f32x16 dk[DH / 32], dv[DH / 32];
+  f32x16 dk[DO_DK ? DH / 32 : 1], dv[DO_DV ? DH / 32 : 1];
 #pragma unroll
   for (int db = 0; db < DH / 32; ++db)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (DO_DK) dk[db][r] = 0.f;
+      if constexpr (DO_DV) dv[db][r] = 0.f;
+    }
 
   const int nqt = (S + 63) / 64;
   const int qt_begin = CAUSAL ? (k0 / 64) : 0;
@@ -770,8 +777,10 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
         const unsigned a = tile_addr<DH>(qb * 32 + l31, ks * 2 + hi);
         const bf16x8 qfr = lds_frag128(smem, sQ + a);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[ks], s, 0, 0, 0);
-        const bf16x8 dofr = lds_frag128(smem, sDO + a);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], dp, 0, 0, 0);
+        if constexpr (DO_DK) {
+          const bf16x8 dofr = lds_frag128(smem, sDO + a);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dofr, vf[ks], dp, 0, 0, 0);
+        }
       }
       // dS = P o (dP - delta); the softmax scale is applied once to dK at the end.
       // The Q^T / dO^T fragments (4 transpose reads per d block) are software-pipelined one set ahead of the two MFMAs that
@@ -793,11 +802,20 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
 #define HVLM_DKV_ISSUE(SET, SP, DB)                                                                                    \
       do {                                                                                                              \
         const unsigned qbytes_ = (unsigned)(qb * 32 + 16 * (SP)) * (DH * 2);                                           \
-        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7" \
-                     : "=&v"(d0[SET]), "=&v"(d1[SET]), "=&v"(q0r[SET]), "=&v"(q1r[SET])                                 \
-                     : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_),                         \
-                       "v"(tr_off[DB][0] + sQ + qbytes_), "v"(tr_off[DB][1] + sQ + qbytes_)                            \
-                     : "memory");                                                                                       \
+        if constexpr (MODE == 0)                                                                                        \
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7" \
+                       : "=&v"(d0[SET]), "=&v"(d1[SET]), "=&v"(q0r[SET]), "=&v"(q1r[SET])                               \
+                       : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_),                       \
+                         "v"(tr_off[DB][0] + sQ + qbytes_), "v"(tr_off[DB][1] + sQ + qbytes_)                          \
+                       : "memory");                                                                                     \
+        else if constexpr (MODE == 1)                                                                                   \
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                        \
+                       : "=&v"(d0[SET]), "=&v"(d1[SET])                                                                 \
+                       : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_) : "memory");           \
+        else                                                                                                            \
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                        \
+                       : "=&v"(q0r[SET]), "=&v"(q1r[SET])                                                               \
+                       : "v"(tr_off[DB][0] + sQ + qbytes_), "v"(tr_off[DB][1] + sQ + qbytes_) : "memory");             \
       } while (0)
       HVLM_DKV_ISSUE(0, 0, 0);
       bf16x8 pf, dsf;
@@ -824,14 +842,22 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
         if (idx + 1 < 2 * (DH / 32)) {
           if (cur == 0) HVLM_DKV_ISSUE(1, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
           else HVLM_DKV_ISSUE(0, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
-          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+          if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+          else if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(d0[cur]), "+v"(d1[cur]));
+          else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0r[cur]), "+v"(q1r[cur]));
         } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+          if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
+          else if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0r[cur]), "+v"(q1r[cur]));
         }
-        const s16x8_t dotv = {d0[cur][0], d0[cur][1], d0[cur][2], d0[cur][3], d1[cur][0], d1[cur][1], d1[cur][2], d1[cur][3]};
-        const s16x8_t qtv = {q0r[cur][0], q0r[cur][1], q0r[cur][2], q0r[cur][3], q1r[cur][0], q1r[cur][1], q1r[cur][2], q1r[cur][3]};
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dotv), pf, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qtv), dsf, dk[db], 0, 0, 0);
+        if constexpr (DO_DV) {
+          const s16x8_t dotv = {d0[cur][0], d0[cur][1], d0[cur][2], d0[cur][3], d1[cur][0], d1[cur][1], d1[cur][2], d1[cur][3]};
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dotv), pf, dv[db], 0, 0, 0);
+        }
+        if constexpr (DO_DK) {
+          const s16x8_t qtv = {q0r[cur][0], q0r[cur][1], q0r[cur][2], q0r[cur][3], q1r[cur][0], q1r[cur][1], q1r[cur][2], q1r[cur][3]};
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qtv), dsf, dk[db], 0, 0, 0);
+        }
       }
 #undef HVLM_DKV_ISSUE
     }
@@ -844,11 +870,15 @@ __global__ __launch_bounds__(256, DH == 128 ? 1 : 2) void attn_bwd_dkv_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 a = {pack_bf2(dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale),
-                   pack_bf2(dk[db][4 * g + 2] * scale, dk[db][4 * g + 3] * scale)};
-        u32x2 c = {pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3])};
-        *reinterpret_cast<u32x2*>(kp + d) = a;
-        *reinterpret_cast<u32x2*>(vp + d) = c;
+        if constexpr (DO_DK) {
+          u32x2 a = {pack_bf2(dk[db][4 * g] * scale, dk[db][4 * g + 1] * scale),
+                     pack_bf2(dk[db][4 * g + 2] * scale, dk[db][4 * g + 3] * scale)};
+          *reinterpret_cast<u32x2*>(kp + d) = a;
+        }
+        if constexpr (DO_DV) {
+          u32x2 c = {pack_bf2(dv[db][4 * g], dv[db][4 * g + 1]), pack_bf2(dv[db][4 * g + 2], dv[db][4 * g + 3])};
+          *reinterpret_cast<u32x2*>(vp + d) = c;
+        }
       }
   }
 }
@@ -935,11 +965,24 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   }
   {
     constexpr int LDS = 2 * (2 * 64 * DH * 2 + 512);    // two stages of (Q, dO, lse, delta)
-    if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
-                       dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
-    if ((rc = check_launch("attn_bwd_dkv"))) return rc;
+    static const int split = getenv("HVLM_ATTN_DKV_SPLIT") ? atoi(getenv("HVLM_ATTN_DKV_SPLIT")) : (DH == 128 ? 1 : 0);
+    if (split) {
+      // dh = 128: dV and dK as two passes with two waves per SIMD each instead of one pass at one wave per SIMD
+      if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL, 1>, LDS, "attn_bwd_dv"))) return rc;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 1>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
+                         dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
+      if ((rc = check_launch("attn_bwd_dv"))) return rc;
+      if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL, 2>, LDS, "attn_bwd_dk"))) return rc;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 2>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
+                         dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
+      if ((rc = check_launch("attn_bwd_dk"))) return rc;
+    } else {
+      if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
+                         dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
+      if ((rc = check_launch("attn_bwd_dkv"))) return rc;
+    }
   }
   return HVLM_OK;
 }
