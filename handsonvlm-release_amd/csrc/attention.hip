@@ -13,10 +13,12 @@
 //   backward : two kernels. dQ (one query per lane):  S^T = K Q^T, dP^T = V dO^T,
 //              dS^T = P^T o (dP^T - delta), dQ^T = K^T dS^T.   dK/dV (one key per lane):
 //              S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS.  No atomics, deterministic.
-//   The k-contiguous "transposed" operand tiles (V^T, K^T, Q^T, dO^T: [dh][tokens]) come from a
-//   cheap HBM-bound head-transpose pre-pass into a caller-provided workspace.
-//   K/V/Q/dO tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4) with the XOR swizzle
+//   The "transposed" operand fragments (V^T, K^T, Q^T, dO^T) are gathered from the row-major K / V / Q / dO tiles in
+//   LDS with transpose reads (ds_read_b64_tr_b16): no transposed tiles, no pre-passes, no workspace beyond delta.
+//   K/V/Q/dO tiles go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) with the XOR swizzle
 //   applied to the per-lane source address (conflict-free ds_read_b128 fragment reads).
+//   Sequences are padded [B*S] or packed (cu_seqlens: the reference's flash_attn_varlen contract); the forward also has
+//   an fp16 instantiation for the CLIP tower and a resident-K/V persistent variant for S <= 288 (CLIP, S = 257).
 //
 // Reference arithmetic replaced: LlamaAttention softmax(QK^T/sqrt(dh) + causal mask) V
 // (transformers modeling_llama; flash path llava/train/llama_flash_attn_monkey_patch.py:81-94) and
@@ -457,38 +459,6 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
   }
 }
 
-// =================================================================================================
-// head transpose: src[(b*S+s)*ld + col0 + h*DH + d] -> dst[((b*H+h)*DH + d)*S_pad + s], zero for
-// s in [S, S_pad).  One block per (64-token tile, h, b).
-// =================================================================================================
-template <int DH>
-__global__ __launch_bounds__(256) void head_transpose_kernel(const bf16_t* __restrict__ src,
-                                                             bf16_t* __restrict__ dst, int S, int H,
-                                                             int ld, int col0, int S_pad) {
-  __shared__ bf16_t tile[64][DH + 2];
-  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int t = threadIdx.x;
-  constexpr int CPR = DH / 8;
-  for (int idx = t; idx < 64 * CPR; idx += 256) {
-    const int r = idx / CPR, c = (idx % CPR) * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (s0 + r < S)
-      v = *reinterpret_cast<const u32x4*>(src + ((long)b * S + s0 + r) * ld + col0 + h * DH + c);
-    unsigned* d = reinterpret_cast<unsigned*>(&tile[r][c]);
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-  }
-  __syncthreads();
-  for (int idx = t; idx < DH * 8; idx += 256) {
-    const int d = idx >> 3, r = (idx & 7) * 8;
-    bf16_t e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = tile[r + j][d];
-    u32x4 o = {e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
-               e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
-    *reinterpret_cast<u32x4*>(dst + (((long)b * H + h) * DH + d) * S_pad + s0 + r) = o;
-  }
-}
-
 // delta[b,h,s] = sum_d O[b,s,h,d] * dO[b,s,h,d]   (one thread per 8 elements, dh/8-lane reduce).  Rows are token-major
 // [tokens, H*DH]; `row_b` / `row_s` (varlen: sample and position of every packed row) may be NULL (b = row / S, s = row % S).
 template <int DH>
@@ -890,14 +860,6 @@ static int set_lds(K kernel, int bytes, const char* what) {
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
   return HVLM_OK;
-}
-
-template <int DH>
-static int launch_head_transpose(const bf16_t* src, bf16_t* dst, int B, int S, int H, int ld, int col0,
-                                 hipStream_t st) {
-  dim3 grid(spad(S) / 64, H, B);
-  hipLaunchKernelGGL((head_transpose_kernel<DH>), grid, dim3(256), 0, st, src, dst, S, H, ld, col0, spad(S));
-  return check_launch("head_transpose");
 }
 
 template <int DH, bool CAUSAL, bool F16 = false>
