@@ -1,0 +1,103 @@
+// MFMA-only throughput under the package power cap (gfx950): registers only, RANDOM bf16 operands, every CU busy.
+// Compares v_mfma_f32_32x32x16_bf16 with v_mfma_f32_16x16x32_bf16 (same peak flops per cycle) and the fp16 forms.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o tools/build/mfma_power_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int KIND>
+__global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict__ src, float* __restrict__ out, int iters) {
+  const int t = blockIdx.x * 512 + threadIdx.x;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const bf16x8*>(src + ((size_t)(t * 8 + i) * 8) % (1 << 24));
+    b[i] = *reinterpret_cast<const bf16x8*>(src + ((size_t)(t * 8 + 4 + i) * 8) % (1 << 24));
+  }
+  float sum = 0.f;
+  if constexpr (KIND == 0 || KIND == 2) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + k) & 3], b[k], acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[(i + k) & 3]), __builtin_bit_cast(f16x8, b[k]), acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[i][r];
+  } else {
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if constexpr (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(i + k) & 3]), __builtin_bit_cast(f16x8, b[(i >> 2) & 3]), acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += acc[i][r];
+  }
+  out[t] = sum;
+}
+
+template <int KIND>
+static void run(const char* name, const unsigned short* src, float* out, int grid, int iters, double flops_per_iter_per_wave) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  probe<KIND><<<grid, 512>>>(src, out, iters / 10);
+  hipDeviceSynchronize();
+  // long enough for the power management to settle (~1 s), timed over the last launches
+  for (int rep = 0; rep < 3; ++rep) probe<KIND><<<grid, 512>>>(src, out, iters);
+  hipEventRecord(e0);
+  for (int rep = 0; rep < 3; ++rep) probe<KIND><<<grid, 512>>>(src, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double fl = 3.0 * (double)grid * 8 * iters * flops_per_iter_per_wave;
+  printf("%-28s %8.1f TFLOP/s  (%.1f ms per launch)\n", name, fl / (ms * 1e-3) / 1e12, ms / 3);
+}
+
+int main(int argc, char** argv) {
+  const int zero = argc > 1 && atoi(argv[1]) == 1;
+  const size_t n = 1 << 24;
+  std::vector<unsigned short> h(n);
+  srand(1);
+  for (size_t i = 0; i < n; ++i) {
+    // random bf16 / fp16-safe values in (-2, 2): sign, exponent 0x3f..0x3f+-1, random mantissa
+    const unsigned short mant = rand() & 0x7f, sign = (rand() & 1) << 15, ex = (0x7e + (rand() & 1)) << 7;
+    h[i] = zero ? 0 : (unsigned short)(sign | ex | mant);
+  }
+  unsigned short* d; float* out;
+  hipMalloc(&d, n * 2); hipMalloc(&out, 512 * 512 * 4);
+  hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice);
+  const int grid = 512, iters = 40000;       // 2 workgroups of 8 waves per CU = 4 waves per SIMD
+  printf("operands: %s\n", zero ? "zeros" : "random");
+  run<0>("mfma_f32_32x32x16_bf16", d, out, grid, iters, 16.0 * 2 * 32 * 32 * 16);
+  run<1>("mfma_f32_16x16x32_bf16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
+  run<2>("mfma_f32_32x32x16_f16", d, out, grid, iters, 16.0 * 2 * 32 * 32 * 16);
+  run<3>("mfma_f32_16x16x32_f16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
+  return 0;
+}
