@@ -89,8 +89,16 @@ __device__ PPSched g_pp_all[PP_NSCHED];
 // LDS image, the DMA pieces, the swizzle and the whole 8-phase schedule are unchanged; a fragment is two ds_read_b128
 // (32 k-bytes per lane), 4 MFMAs of 64 cycles per phase instead of 8 of 32.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false>
+// M16: the MFMAs of the K loop are v_mfma_f32_16x16x32 (16 output rows x 16 columns x 32 k) instead of 32x32x16 — the same
+// flops per cycle, but half the accumulator traffic per flop: under the package power cap the matrix pipe alone sustains
+// 2140 TFLOP/s on random bf16 data with 16x16x32 against 1854 with 32x32x16 (tools/mfma_power_probe.hip; 2480 either way on
+// zeros), and this kernel is power-limited.  Same LDS image, same 24 ds_read_b128 per K-tile and wave, same
+// register count: a 32x32 accumulator fragment is simply held as four 16x16 quadrants (registers 4t..4t+3 = quadrant
+// t = 2*(column half) + (row half)), so only the fragment lane mapping, the MFMA calls and the (row, column) a register
+// stands for in the epilogue change.
+template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false, bool M16 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
+  static_assert(!M16 || (SEG4 && !TN && !FP8), "the 16x16x32 form exists for the K-contiguous 16-bit 4-segment kernel");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
   static_assert(!(F16 && (TN || FP8)), "the fp16 instantiation (CLIP tower) is K-contiguous, 16-bit");
   using EL = E16<F16>;                      // 16-bit element type of A / B / C / bias / residual: bfloat16 or IEEE half
@@ -234,6 +242,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   for (int ks = 0; ks < 4; ++ks) koffl[ks] = (unsigned)(((ks * 2 + hi) ^ sw) << 4);
   const unsigned a_base = (unsigned)(grp * 64 + l31) * 128u;
   const unsigned b_base = TILE_BYTES + (unsigned)(wn * 32 + l31) * 128u;
+  // M16: a 16-row fragment: lane -> row (l & 15) of its 16-row block, k = 32*ks2 + 8*(l >> 4) .. +7 (one 16-B chunk); the
+  // row swizzle only sees (l & 15) >> 1 (block bases are multiples of 16 rows).  f[s*2 + ks2] = 16-row block s, k half ks2.
+  const int l15 = l & 15, q4 = l >> 4;
+  unsigned koff16[2];
+#pragma unroll
+  for (int ks2 = 0; ks2 < 2; ++ks2) koff16[ks2] = (unsigned)(((q4 + 4 * ks2) ^ ((l15 >> 1) & 7)) << 4);
+  const unsigned a_base16 = (unsigned)(grp * 64 + l15) * 128u;
+  const unsigned b_base16 = TILE_BYTES + (unsigned)(wn * 32 + l15) * 128u;
   // TN: lane p of a 16-lane group addresses k-row (p>>2) [+ 8*hi + 4*rr + 16*ks], columns (p&3)*4.. of its 16-column
   // block and receives column l31 of the fragment; the 16-B chunk index is XOR-ed with ((k&3)<<2)
   const int p16 = l & 15, g16 = l31 >> 4;
@@ -277,6 +293,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     if constexpr (FP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u, ks);
+    } else if constexpr (M16) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+          f[sx * 2 + ks2] = *reinterpret_cast<const bf16x8*>(smem + sb + a_base16 + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + (unsigned)sx * 2048u + koff16[ks2]);
     } else if constexpr (!TN) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -294,6 +316,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     if constexpr (FP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + b_base + (unsigned)j * HALF_BYTES, ks);
+    } else if constexpr (M16) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2)
+          f[sx * 2 + ks2] = *reinterpret_cast<const bf16x8*>(smem + sb + b_base16 + (unsigned)j * HALF_BYTES + (unsigned)sx * 2048u + koff16[ks2]);
     } else if constexpr (!TN) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -311,18 +339,22 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 
   f32x16 acc[2][4];                       // [column half j][row fragment i]
 
-  // ---- epilogues: lane holds row m, 4 consecutive columns per register quad -------------------
-  auto row_of = [&](int m0, int i) { return m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + l31; };
-  auto col_of = [&](int n0, int j, int g) { return n0 + wn * 64 + j * 32 + 8 * g + 4 * hi; };
+  // ---- epilogues: register quad g (registers 4g..4g+3) of a 32x32 fragment = 4 consecutive columns of ONE row:
+  //   32x32x16: row l31 of the fragment, columns 8g + 4hi ..;   16x16x32 (M16): quadrant g = 2*(column half) + (row half):
+  //   row (g & 1)*16 + (l & 15), columns (g >> 1)*16 + 4*(l >> 4) ..
+  auto qrow = [&](int g) { return M16 ? ((g & 1) * 16 + l15) : l31; };
+  auto qcol = [&](int g) { return M16 ? ((g >> 1) * 16 + 4 * q4) : (8 * g + 4 * hi); };
+  auto row_of = [&](int m0, int i) { return m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + l31; };        // (32x32 form: fp8 scales)
+  auto col_of = [&](int n0, int j, int g) { return n0 + wn * 64 + j * 32 + qcol(g); };
   auto epilogue_generic = [&](int m0, int n0, size_t c_slab) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = row_of(m0, i);
-      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+          const int m = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + qrow(g);
+          if (m >= p.M) continue;
           const int nb = col_of(n0, j, g);
           if (nb >= p.N) continue;
           float v[4];
@@ -411,7 +443,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
               for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
             }
             const u32x2 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(epi + (f & 1) * 2048 + l31 * 64 + ((g ^ ((l31 >> 1) & 3)) << 4) + hi * 8) = o;
+            const int qr = qrow(g), qc = qcol(g);   // row qr, bf16 columns qc..qc+3 of the 32x32 fragment (64-B rows)
+            *reinterpret_cast<u32x2*>(epi + (f & 1) * 2048 + qr * 64 + (((qc >> 3) ^ ((qr >> 1) & 3)) << 4) + ((qc >> 2) & 1) * 8) = o;
           }
         }
         if (f > 0) {
@@ -459,7 +492,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 o = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-          *reinterpret_cast<f32x4*>(epi + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) << 4)) = o;
+          const int qr = qrow(g), qc = qcol(g);     // row qr, fp32 columns qc..qc+3: 16-B chunk qc/4 of a 128-B row
+          *reinterpret_cast<f32x4*>(epi + qr * 128 + ((((qc >> 2)) ^ (qr & 7)) << 4)) = o;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -588,6 +622,34 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
   } while (0)
+  // 16x16x32 form of the 16-MFMA segment: 4 (j, i) fragments x 4 quadrants x 2 k-halves = 32 MFMAs of 16 cycles.  A
+  // quadrant t = 2*sb + sa of acc[j][i] (registers 4t..4t+3) += W-block sb (16 output columns, MFMA A) x X-block sa (16 rows, B).
+  auto mfma16 = [&](f32x16& c, int t, const frag_t& wf, const frag_t& xf) {
+    if constexpr (M16) {
+      f32x4 q = {c[4 * t], c[4 * t + 1], c[4 * t + 2], c[4 * t + 3]};
+      if constexpr (F16) q = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), q, 0, 0, 0);
+      else q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, q, 0, 0, 0);
+      c[4 * t] = q[0]; c[4 * t + 1] = q[1]; c[4 * t + 2] = q[2]; c[4 * t + 3] = q[3];
+    }
+  };
+#define HVLM_MFMA_OCT16(I0, AF0, AF1)                                                                     \
+  do {                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int ks2_ = 0; ks2_ < 2; ++ks2_) {                                              \
+      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
+        const int sb_ = t_ >> 1, sa_ = t_ & 1;                                                            \
+        mfma16(acc[0][I0], t_, fb0[sb_ * 2 + ks2_], AF0[sa_ * 2 + ks2_]);                                 \
+        mfma16(acc[0][I0 + 1], t_, fb0[sb_ * 2 + ks2_], AF1[sa_ * 2 + ks2_]);                             \
+        mfma16(acc[1][I0], t_, fb1[sb_ * 2 + ks2_], AF0[sa_ * 2 + ks2_]);                                 \
+        mfma16(acc[1][I0 + 1], t_, fb1[sb_ * 2 + ks2_], AF1[sa_ * 2 + ks2_]);                             \
+      }                                                                                                   \
+    }                                                                                                     \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+    asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+  } while (0)
 #define HVLM_PHASE_SYNC()                 \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -625,7 +687,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
                        "+v"(fb1[2]), "+v"(fb1[3]), "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
                        "+v"(fa1[2]), "+v"(fa1[3]));
         }
-        HVLM_MFMA_OCT(0, fa0, fa1);
+        if constexpr (M16) HVLM_MFMA_OCT16(0, fa0, fa1); else HVLM_MFMA_OCT(0, fa0, fa1);
         __builtin_amdgcn_s_barrier();
         if (!(DBG && (p.dbg & 8))) {           // dbg 8: a third of the fragment reads gone (stale A fragments of half 0)
           read_a(sb, T2{}, fa0);
@@ -641,7 +703,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
                        "+v"(fa1[2]), "+v"(fa1[3]));
         }
-        HVLM_MFMA_OCT(2, fa0, fa1);
+        if constexpr (M16) HVLM_MFMA_OCT16(2, fa0, fa1); else HVLM_MFMA_OCT(2, fa0, fa1);
       } else {
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
       const unsigned adb = lds0 + sb + tb_off, ada0 = lds0 + sb + ta_off[0], ada1 = lds0 + sb + ta_off[1];   // TN
@@ -755,6 +817,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   HVLM_VMCNT(0);
 #undef HVLM_MFMA_QUAD
 #undef HVLM_MFMA_OCT
+#undef HVLM_MFMA_OCT16
 #undef HVLM_MFMA_OCT_STEP
 #undef HVLM_MFMA_STEP
 #undef HVLM_TR2
@@ -771,11 +834,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm
 __global__ __launch_bounds__(512, 2) void gemm_pp4_tn_kernel(GemmArgs p) { gemm_pp_body<true, false, true>(p); }
 // IEEE-half operands / output on v_mfma_f32_32x32x16_f16 (same rate): the CLIP tower in the reference's own dtype
 __global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true>(p); }
+// the 16x16x32 forms (default; HVLM_GEMM_M16=0 selects the 32x32x16 kernels above for A/B)
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, false, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true, true>(p); }
 
 template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4, 6 = NT bf16, NT fp8, TN bf16 on the 4-segment schedule; 5 = 3 + ablation switches
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 9 ? (const void*)gemm_pp4m_f16_kernel : KIND == 8 ? (const void*)gemm_pp4m_kernel : KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -784,7 +850,9 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
     }
     attr_done = true;
   }
-  if (KIND == 7) hipLaunchKernelGGL(gemm_pp4_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  if (KIND == 9) hipLaunchKernelGGL(gemm_pp4m_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 8) hipLaunchKernelGGL(gemm_pp4m_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 7) hipLaunchKernelGGL(gemm_pp4_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 6) hipLaunchKernelGGL(gemm_pp4_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 4) hipLaunchKernelGGL(gemm_pp4_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
@@ -812,10 +880,18 @@ static bool use_seg4() {
   static const bool v = !(getenv("HVLM_GEMM_SEG4") && atoi(getenv("HVLM_GEMM_SEG4")) == 0);
   return v;
 }
-int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream) { return launch_pp<7>(p, grid, stream); }
+// HVLM_GEMM_M16=0 selects the 32x32x16 kernels (A/B switch; default = the 16x16x32 form)
+static bool use_m16() {
+  static const bool v = !(getenv("HVLM_GEMM_M16") && atoi(getenv("HVLM_GEMM_M16")) == 0);
+  return v;
+}
+int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream) {
+  return use_m16() ? launch_pp<9>(p, grid, stream) : launch_pp<7>(p, grid, stream);
+}
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   if (p.dbg) return launch_pp<5>(p, grid, stream);
-  return use_seg4() ? launch_pp<3>(p, grid, stream) : launch_pp<0>(p, grid, stream);
+  if (!use_seg4()) return launch_pp<0>(p, grid, stream);
+  return use_m16() ? launch_pp<8>(p, grid, stream) : launch_pp<3>(p, grid, stream);
 }
 // HVLM_GEMM_TN_SEG4=0 keeps the K-strided (TN) kernel on the 8-phase schedule (A/B switch; default = 4-segment)
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) {

@@ -21,6 +21,7 @@ for (M, N, K) in [(13872, 12288, 4096), (13872, 4096, 4096), (13872, 22016, 4096
     del a, b, c
 print(out)
 ''' % ROOT
-for env in [{}, {"HVLM_GEMM_GROUP_M": "2"}, {"HVLM_GEMM_GROUP_M": "8"}, {"HVLM_GEMM_GROUP_M": "16"}, {"HVLM_GEMM_STATIC": "1"}, {}]:
+ENVS = [{}, {"HVLM_GEMM_M16": "0"}, {}, {"HVLM_GEMM_M16": "0"}] if len(sys.argv) < 2 else [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[1:]]
+for env in ENVS:
     r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, **env), capture_output=True, text=True)
     print(env, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], flush=True)
