@@ -98,7 +98,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // stands for in the epilogue change.
 template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false, bool M16 = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
-  static_assert(!M16 || (SEG4 && !TN && !FP8), "the 16x16x32 form exists for the K-contiguous 16-bit 4-segment kernel");
+  static_assert(!M16 || (SEG4 && !TN), "the 16x16 form exists for the K-contiguous 4-segment kernels (16-bit: 16x16x32, fp8: 16x16x128)");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
   static_assert(!(F16 && (TN || FP8)), "the fp16 instantiation (CLIP tower) is K-contiguous, 16-bit");
   using EL = E16<F16>;                      // 16-bit element type of A / B / C / bias / residual: bfloat16 or IEEE half
@@ -248,6 +248,15 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   unsigned koff16[2];
 #pragma unroll
   for (int ks2 = 0; ks2 < 2; ++ks2) koff16[ks2] = (unsigned)(((q4 + 4 * ks2) ^ ((l15 >> 1) & 7)) << 4);
+  unsigned koff816[2];      // fp8, 16x16x128: the 32 k-bytes of a lane = 16-B chunks 2*q4, 2*q4 + 1 of its row (the whole K-tile)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) koff816[e] = (unsigned)(((2 * q4 + e) ^ ((l15 >> 1) & 7)) << 4);
+  auto read816 = [&](unsigned base) -> i32x8 {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base + koff816[0]);
+    const u32x4 hi4 = *reinterpret_cast<const u32x4*>(smem + base + koff816[1]);
+    const i32x8 v = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+    return v;
+  };
   const unsigned a_base16 = (unsigned)(grp * 64 + l15) * 128u;
   const unsigned b_base16 = TILE_BYTES + (unsigned)(wn * 32 + l15) * 128u;
   // TN: lane p of a 16-lane group addresses k-row (p>>2) [+ 8*hi + 4*rr + 16*ks], columns (p&3)*4.. of its 16-column
@@ -290,7 +299,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   };
   auto read_a = [&](unsigned sb, auto i_tag, frag_t (&f)[NKS]) {
     constexpr int i = decltype(i_tag)::value;
-    if constexpr (FP8) {
+    if constexpr (FP8 && M16) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) f[sx] = read816(sb + a_base16 + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u + (unsigned)sx * 2048u);
+    } else if constexpr (FP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + a_base + (unsigned)(i >> 1) * HALF_BYTES + (unsigned)(i & 1) * 4096u, ks);
     } else if constexpr (M16) {
@@ -313,7 +325,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   };
   auto read_b = [&](unsigned sb, auto j_tag, frag_t (&f)[NKS]) {
     constexpr int j = decltype(j_tag)::value;
-    if constexpr (FP8) {
+    if constexpr (FP8 && M16) {
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) f[sx] = read816(sb + b_base16 + (unsigned)j * HALF_BYTES + (unsigned)sx * 2048u);
+    } else if constexpr (FP8) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) f[ks] = read8(sb + b_base + (unsigned)j * HALF_BYTES, ks);
     } else if constexpr (M16) {
@@ -344,7 +359,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   //   row (g & 1)*16 + (l & 15), columns (g >> 1)*16 + 4*(l >> 4) ..
   auto qrow = [&](int g) { return M16 ? ((g & 1) * 16 + l15) : l31; };
   auto qcol = [&](int g) { return M16 ? ((g >> 1) * 16 + 4 * q4) : (8 * g + 4 * hi); };
-  auto row_of = [&](int m0, int i) { return m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + l31; };        // (32x32 form: fp8 scales)
   auto col_of = [&](int n0, int j, int g) { return n0 + wn * 64 + j * 32 + qcol(g); };
   auto epilogue_generic = [&](int m0, int n0, size_t c_slab) {
 #pragma unroll
@@ -624,10 +638,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   } while (0)
   // 16x16x32 form of the 16-MFMA segment: 4 (j, i) fragments x 4 quadrants x 2 k-halves = 32 MFMAs of 16 cycles.  A
   // quadrant t = 2*sb + sa of acc[j][i] (registers 4t..4t+3) += W-block sb (16 output columns, MFMA A) x X-block sa (16 rows, B).
+  constexpr int NKH16 = FP8 ? 1 : 2;      // MFMA k-steps per K-tile in the 16x16 form (fp8: one 16x16x128; 16-bit: two 16x16x32)
   auto mfma16 = [&](f32x16& c, int t, const frag_t& wf, const frag_t& xf) {
     if constexpr (M16) {
       f32x4 q = {c[4 * t], c[4 * t + 1], c[4 * t + 2], c[4 * t + 3]};
-      if constexpr (F16) q = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), q, 0, 0, 0);
+      if constexpr (FP8) q = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, q, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      else if constexpr (F16) q = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), q, 0, 0, 0);
       else q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, q, 0, 0, 0);
       c[4 * t] = q[0]; c[4 * t + 1] = q[1]; c[4 * t + 2] = q[2]; c[4 * t + 3] = q[3];
     }
@@ -637,13 +653,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     __builtin_amdgcn_sched_barrier(0);                                                                    \
     asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int ks2_ = 0; ks2_ < 2; ++ks2_) {                                              \
+    _Pragma("unroll") for (int ks2_ = 0; ks2_ < NKH16; ++ks2_) {                                          \
       _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
         const int sb_ = t_ >> 1, sa_ = t_ & 1;                                                            \
-        mfma16(acc[0][I0], t_, fb0[sb_ * 2 + ks2_], AF0[sa_ * 2 + ks2_]);                                 \
-        mfma16(acc[0][I0 + 1], t_, fb0[sb_ * 2 + ks2_], AF1[sa_ * 2 + ks2_]);                             \
-        mfma16(acc[1][I0], t_, fb1[sb_ * 2 + ks2_], AF0[sa_ * 2 + ks2_]);                                 \
-        mfma16(acc[1][I0 + 1], t_, fb1[sb_ * 2 + ks2_], AF1[sa_ * 2 + ks2_]);                             \
+        mfma16(acc[0][I0], t_, fb0[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_]);                         \
+        mfma16(acc[0][I0 + 1], t_, fb0[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_]);                     \
+        mfma16(acc[1][I0], t_, fb1[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_]);                         \
+        mfma16(acc[1][I0 + 1], t_, fb1[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_]);                     \
       }                                                                                                   \
     }                                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                        \
@@ -764,11 +780,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     }
     if constexpr (FP8) {
       // de-quantisation: tensor scale (alpha) x per-token scale of the row x per-output-channel scale of the column
-      float rs[4] = {p.alpha, p.alpha, p.alpha, p.alpha};
-      if (p.row_scale) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rs[i] *= p.row_scale[min(row_of(m0, i), p.M - 1)];
-      }
+      // (register quad g4 of fragment (j, i) holds row qrow(g4), columns qcol(g4).. — see the epilogue mapping above)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -780,9 +792,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             for (int e = 0; e < 4; ++e) cs[e] = p.col_scale[min(nb + e, p.N - 1)];
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i) {
+            float rs = p.alpha;
+            if (p.row_scale) rs *= p.row_scale[min(m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + qrow(g4), p.M - 1)];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j][i][4 * g4 + e] *= rs[i] * cs[e];
+            for (int e = 0; e < 4; ++e) acc[j][i][4 * g4 + e] *= rs * cs[e];
+          }
         }
     }
     epilogue(m0, n0, (size_t)ksl * p.slab);
@@ -837,11 +852,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm
 // the 16x16x32 forms (default; HVLM_GEMM_M16=0 selects the 32x32x16 kernels above for A/B)
 __global__ __launch_bounds__(512, 2) void gemm_pp4m_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, false, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4m_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true, false, false, true>(p); }
 
 template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4, 6 = NT bf16, NT fp8, TN bf16 on the 4-segment schedule; 5 = 3 + ablation switches
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  const void* kfn = KIND == 9 ? (const void*)gemm_pp4m_f16_kernel : KIND == 8 ? (const void*)gemm_pp4m_kernel : KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  const void* kfn = KIND == 10 ? (const void*)gemm_pp4m_fp8_kernel : KIND == 9 ? (const void*)gemm_pp4m_f16_kernel : KIND == 8 ? (const void*)gemm_pp4m_kernel : KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
@@ -850,7 +866,8 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
     }
     attr_done = true;
   }
-  if (KIND == 9) hipLaunchKernelGGL(gemm_pp4m_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  if (KIND == 10) hipLaunchKernelGGL(gemm_pp4m_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  else if (KIND == 9) hipLaunchKernelGGL(gemm_pp4m_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 8) hipLaunchKernelGGL(gemm_pp4m_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 7) hipLaunchKernelGGL(gemm_pp4_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   else if (KIND == 6) hipLaunchKernelGGL(gemm_pp4_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
@@ -899,7 +916,12 @@ int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) {
   return seg4 ? launch_pp<6>(p, grid, stream) : launch_pp<1>(p, grid, stream);
 }
 int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
-  return use_seg4() ? launch_pp<4>(p, grid, stream) : launch_pp<2>(p, grid, stream);
+  if (!use_seg4()) return launch_pp<2>(p, grid, stream);
+  // fp8: the 16x16x128 form is NOT the default — the matrix pipe alone gains 5 % from it under the power cap (4605 vs 4369
+  // TFLOP/s), but this kernel is not matrix-power-bound at fp8 (operand traffic per unit time doubles): measured 2471 vs 2506
+  // TFLOP/s on 13872x12288x4096, 2875 vs 2859 on 8192^3.  HVLM_GEMM_FP8_M16=1 selects it.
+  static const bool m16 = getenv("HVLM_GEMM_FP8_M16") && atoi(getenv("HVLM_GEMM_FP8_M16")) == 1;
+  return m16 ? launch_pp<10>(p, grid, stream) : launch_pp<4>(p, grid, stream);
 }
 
 }  // namespace hvlm

@@ -9,6 +9,55 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// fp8 (e4m3) scaled MFMA: 32x32x64 vs 16x16x128 (block scales 2^0)
+template <int KIND>
+__global__ __launch_bounds__(512, 2) void probe8(const unsigned short* __restrict__ src, float* __restrict__ out, int iters) {
+  const int t = blockIdx.x * 512 + threadIdx.x;
+  i32x8 a[2], b[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a[i] = *reinterpret_cast<const i32x8*>(src + ((size_t)(t * 4 + i) * 16) % (1 << 24));
+    b[i] = *reinterpret_cast<const i32x8*>(src + ((size_t)(t * 4 + 2 + i) * 16) % (1 << 24));
+  }
+  constexpr int S1 = 0x7f7f7f7f;
+  float sum = 0.f;
+  if constexpr (KIND == 0) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[(i + k) & 1], b[k], acc[i], 0, 0, 0, S1, 0, S1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[i][r];
+  } else {
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i & 1], b[(i >> 1) & 1], acc[i], 0, 0, 0, S1, 0, S1);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += acc[i][r];
+  }
+  out[t] = sum;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict__ src, float* __restrict__ out, int iters) {
@@ -63,6 +112,23 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
 }
 
 template <int KIND>
+static void run8(const char* name, const unsigned short* src, float* out, int grid, int iters, double flops_per_iter_per_wave) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  probe8<KIND><<<grid, 512>>>(src, out, iters / 10);
+  hipDeviceSynchronize();
+  for (int rep = 0; rep < 3; ++rep) probe8<KIND><<<grid, 512>>>(src, out, iters);
+  hipEventRecord(e0);
+  for (int rep = 0; rep < 3; ++rep) probe8<KIND><<<grid, 512>>>(src, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double fl = 3.0 * (double)grid * 8 * iters * flops_per_iter_per_wave;
+  printf("%-28s %8.1f TFLOP/s  (%.1f ms per launch)\n", name, fl / (ms * 1e-3) / 1e12, ms / 3);
+}
+
+template <int KIND>
 static void run(const char* name, const unsigned short* src, float* out, int grid, int iters, double flops_per_iter_per_wave) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -99,5 +165,8 @@ int main(int argc, char** argv) {
   run<1>("mfma_f32_16x16x32_bf16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
   run<2>("mfma_f32_32x32x16_f16", d, out, grid, iters, 16.0 * 2 * 32 * 32 * 16);
   run<3>("mfma_f32_16x16x32_f16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
+  // fp8: every byte a random e4m3 value in (-2, 2)-ish (the same bit patterns read as bytes)
+  run8<0>("mfma_scale_32x32x64_fp8", d, out, grid, iters, 8.0 * 2 * 32 * 32 * 64);
+  run8<1>("mfma_scale_16x16x128_fp8", d, out, grid, iters, 16.0 * 2 * 16 * 16 * 128);
   return 0;
 }
