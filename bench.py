@@ -165,20 +165,20 @@ def pmc_traffic(ev, args):
     """roofline.traffic: L2-miss (fabric / HBM side) bytes per GEMM launch from PMC counters.  A `--pmc` pass cannot wrap
     the ~3000-dispatch step on this pool, so the counters were collected per distinct GEMM shape in isolation
     (tools/gemm_traffic.py: FETCH_SIZE and WRITE_SIZE alone in their passes, FETCH_SIZE x2 on gfx950) and are committed in
-    profiles/r01s_gemm_traffic.json; here they are weighted by the launches of THIS run.  null when the run contains a
+    profiles/r02i_gemm_traffic.json; here they are weighted by the launches of THIS run.  null when the run contains a
     shape that was not measured (other model / batch)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01s_gemm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02i_gemm_traffic.json")
     if not ev.pairs or not os.path.exists(path):
-        return None, "no PMC table (profiles/r01s_gemm_traffic.json)"
+        return None, "no PMC table (profiles/r02i_gemm_traffic.json)"
     table = {(r["M"], r["N"], r["K"]): r["fetch_bytes"] + r["write_bytes"] for r in json.load(open(path))["per_shape"]}
     tot = algo = 0.0
     for _, _, _, shp in ev.pairs:
         if shp not in table:
-            return None, f"GEMM shape {shp} of this run is not in profiles/r01s_gemm_traffic.json"
+            return None, f"GEMM shape {shp} of this run is not in profiles/r02i_gemm_traffic.json"
         tot += table[shp]
         algo += 2.0 * (shp[0] * shp[2] + shp[1] * shp[2] + shp[0] * shp[1])
     return tot / ev.kernels, ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, collected per GEMM shape in isolation, all kernel launches of a "
-                              "call summed (tools/gemm_traffic.py -> profiles/r01s_gemm_traffic.json), weighted by this run's calls and "
+                              "call summed (tools/gemm_traffic.py -> profiles/r02i_gemm_traffic.json), weighted by this run's calls and "
                               f"divided by its kernel launches; algorithmic operand+output bytes per launch: {algo / ev.kernels / 1e9:.2f} GB")
 
 
@@ -584,7 +584,7 @@ def main():
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)
         if gs is not None:
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4_kernel", "achieved": gs["tflops"],
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4m_kernel (v_mfma_f32_16x16x32; the CLIP tower runs its fp16 twin gemm_pp4m_f16_kernel)", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
                                "launches": gs["launches"], "gemm_calls": gs["calls"], "avg_launch_us": gs["avg_us"],
