@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW after the whole backward instead of per bucket (A/B)")
     ap.add_argument("--clip-dtype", default="fp16", choices=["bf16", "fp16"],
                     help="CLIP tower dtype: fp16 = the reference's (handsonvlm/train/train.py:316), same MFMA rate")
+    ap.add_argument("--clip-chunk", type=int, default=None, help="frames per CLIP pass (default: config.clip_chunk_frames)")
     ap.add_argument("--recompute", nargs="?", const=-1, default=0, type=int, metavar="N",
                     help="activation recompute (scripts/finetune.sh:36): keep only the layer input and re-run the layer forward in "
                          "backward, for the first N layers (no value: all layers)")
@@ -80,6 +81,8 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
+    if args.clip_chunk:
+        cfg.clip_chunk_frames = args.clip_chunk
     cfg.vision_dtype = args.clip_dtype
     cfg.activation_recompute = True if args.recompute < 0 else args.recompute
     cfg.pack_sequences = args.pack

@@ -44,16 +44,27 @@ __device__ __forceinline__ void glds16(const bf16_t* base, unsigned byte_off, un
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + lds_off), 16, byte_off, 0, 0, 0);
 }
 
+// LDS tile image: row-major [rows][COLS] bf16, the 16-byte chunk c of row r stored at chunk position c ^ swz(r).  The
+// permutation has to serve TWO read patterns of the same tile without bank conflicts:
+//   * ds_read_b128 fragment reads: a 16-lane service group = 16 rows (distinct mod 16), one chunk each -> swz must be a
+//     bijection of the row bits it looks at (any bit permutation is);
+//   * ds_read_b64_tr_b16 transpose reads: a 32-lane group = rows r0..r0+3 (r0 % 4 == 0) x one aligned group of four chunks
+//     (64 B) x two 8-B halves -> the FOUR ROWS must land in four different 64-B bank quarters.
+// Round 1 used swz = r & 15 (256-B rows) / (r >> 1) & 7 (128-B rows): conflict-free for the first pattern, but the four
+// rows of a transpose read only permuted chunks INSIDE one quarter — 4-way (2-way) conflicts, 46-60 % of the LDS cycles of
+// the attention kernels (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Now the low row bits select the quarter:
+//   256-B rows (dh = 128): swz = ((r & 3) << 2) | ((r >> 2) & 3)          (rows r0..r0+3 -> quarters 0..3)
+//   128-B rows (dh = 64):  swz = (((r >> 1) & 1) << 2) | ((r >> 2) & 3)   (with the bank half r & 1: four distinct 64-B groups)
+template <int COLS>
+__device__ __forceinline__ int swz_bits(int r) {
+  if constexpr (COLS == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+  else return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+}
 // byte offset of 16-byte chunk `c` (logical) of row `r` inside a swizzled [rows][COLS] bf16 tile
 template <int COLS>
 __device__ __forceinline__ unsigned tile_addr(int r, int c) {
-  if constexpr (COLS == 128) return (unsigned)r * 256u + (unsigned)((c ^ (r & 15)) << 4);
-  else return (unsigned)r * 128u + (unsigned)((c ^ ((r >> 1) & 7)) << 4);
-}
-template <int COLS>
-__device__ __forceinline__ int swz_bits(int r) {
-  if constexpr (COLS == 128) return r & 15;
-  else return (r >> 1) & 7;
+  if constexpr (COLS == 128) return (unsigned)r * 256u + (unsigned)((c ^ swz_bits<128>(r)) << 4);
+  else return (unsigned)r * 128u + (unsigned)((c ^ swz_bits<64>(r)) << 4);
 }
 
 // LDS-DMA a [ROWS][COLS] tile (4 waves).  Row r of the tile is global row min(row0 + r, row_lim-1)

@@ -100,7 +100,11 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if constexpr (KIND == 1) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
-          else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(i + k) & 3]), __builtin_bit_cast(f16x8, b[(i >> 2) & 3]), acc[i], 0, 0, 0);
+          else if constexpr (KIND == 3) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[(i + k) & 3]), __builtin_bit_cast(f16x8, b[(i >> 2) & 3]), acc[i], 0, 0, 0);
+          else if (k == 0) {   // KIND 4: the two k-halves of one accumulator BACK TO BACK (dependent pair), 16 accumulators
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + 1) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+          }
         }
     }
 #pragma unroll
@@ -165,6 +169,7 @@ int main(int argc, char** argv) {
   run<1>("mfma_f32_16x16x32_bf16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
   run<2>("mfma_f32_32x32x16_f16", d, out, grid, iters, 16.0 * 2 * 32 * 32 * 16);
   run<3>("mfma_f32_16x16x32_f16", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
+  run<4>("16x16x32_bf16 dependent pairs", d, out, grid, iters, 32.0 * 2 * 16 * 16 * 32);
   // fp8: every byte a random e4m3 value in (-2, 2)-ish (the same bit patterns read as bytes)
   run8<0>("mfma_scale_32x32x64_fp8", d, out, grid, iters, 8.0 * 2 * 32 * 32 * 64);
   run8<1>("mfma_scale_16x16x128_fp8", d, out, grid, iters, 16.0 * 2 * 16 * 16 * 128);
