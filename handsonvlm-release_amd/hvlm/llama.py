@@ -30,6 +30,7 @@ from . import ops
 from .config import HandsOnVLMConfig
 
 BF16 = torch.bfloat16
+_FUSED_T = os.environ.get("HVLM_FUSED_T", "1") == "1"   # SwiGLU kernels also write the token-contiguous copies the dW GEMMs need
 _DW_TN = os.environ.get("HVLM_DW_TN", "0") == "1"      # weight-gradient GEMMs on K-strided operands (A/B switch, see _dw)
 
 
@@ -260,11 +261,18 @@ class LlamaStack:
         h = mm(ao, "o", residual=x)
         hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
         gu = mm(hn, "gu")
-        act = ops.swiglu_fwd(gu)
+        actT = None
+        if save and _FUSED_T and self.F % 64 == 0:
+            # the token-contiguous copy of act (operand of dW_down) is written by the SwiGLU kernel itself; the row-major
+            # act is only needed by down_proj right below and is not kept
+            act, actT = ops.swiglu_fwd_t(gu, _round_up(seq.M, 64))
+        else:
+            act = ops.swiglu_fwd(gu)
         if probe is not None:
             probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
         xo = mm(act, "down", residual=h)
-        sv = dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn, gu=gu, act=act) if save else None
+        sv = dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn, gu=gu,
+                  act=None if actT is not None else act, actT=actT) if save else None
         return xo, sv
 
     def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
@@ -385,7 +393,7 @@ class LlamaStack:
         return hidden
 
     # -- backward -------------------------------------------------------------------------------
-    def _dw(self, dy: torch.Tensor, xin: torch.Tensor, out: torch.Tensor, mpad: int):
+    def _dw(self, dy: torch.Tensor, xin: torch.Tensor, out: torch.Tensor, mpad: int, dyT=None, xT=None):
         """out[N,K] = dy[M,N]^T @ xin[M,K]  via K-contiguous transposed copies (zero-padded to mpad).
 
         HVLM_DW_SIDE_STREAM=1 issues it on a side stream: the weight gradient is independent of the activation-gradient
@@ -393,23 +401,25 @@ class LlamaStack:
         its last, partial round of tiles (880 tiles on 256 CUs = 3.44 rounds).  Measured: 0 - 0.7 % on the SFT step (two
         persistent one-workgroup-per-CU kernels mostly just take turns), so it is OFF by default."""
         side = self._side_stream()
-        if _DW_TN and dy.stride(1) == 1 and xin.stride(1) == 1:
+        if _DW_TN and dyT is None and xT is None and dy.stride(1) == 1 and xin.stride(1) == 1:
             # dW = dY^T X straight from the token-major activations: the K-strided (TN) instantiation of the ping-pong GEMM
             # gathers its fragments with LDS transpose reads — no transposed copies, no HBM-bound transpose kernels
             ops.gemm(dy, xin, trans_a=True, trans_b=True, out=out)
             return
         if side is None:
-            dyT = ops.transpose(dy, r_pad=mpad)
-            xT = ops.transpose(xin, r_pad=mpad)
+            dyT = ops.transpose(dy, r_pad=mpad) if dyT is None else dyT      # (already written by the producing kernel)
+            xT = ops.transpose(xin, r_pad=mpad) if xT is None else xT
             ops.gemm_nt(dyT, xT, out=out)
             return
         main = torch.cuda.current_stream()
         side.wait_stream(main)                       # dy / xin are produced on the main stream
         with torch.cuda.stream(side):
-            dyT = ops.transpose(dy, r_pad=mpad)
-            xT = ops.transpose(xin, r_pad=mpad)
+            dyT = ops.transpose(dy, r_pad=mpad) if dyT is None else dyT
+            xT = ops.transpose(xin, r_pad=mpad) if xT is None else xT
             ops.gemm_nt(dyT, xT, out=out)
-        dy.record_stream(side); xin.record_stream(side)
+        for t_ in (dy, xin, dyT, xT):
+            if t_ is not None:
+                t_.record_stream(side)
 
     def _side_stream(self):
         if os.environ.get("HVLM_DW_SIDE_STREAM", "0") != "1":
@@ -441,12 +451,16 @@ class LlamaStack:
                 sv = self._layer_forward(i, sv["x"], seq, True)[1]
             # ---- MLP ----
             dact = ops.gemm_nt(dx, lp.wt["down"])                      # [M,F] = dx @ Wd
-            self._dw(dx, sv["act"], lp.g["down"], mpad)                 # dWd[D,F]
-            dgu = ops.swiglu_bwd(sv["gu"], dact)
+            self._dw(dx, sv["act"], lp.g["down"], mpad, xT=sv.get("actT"))   # dWd[D,F]
+            dguT = None
+            if _FUSED_T and self.F % 64 == 0:
+                dgu, dguT = ops.swiglu_bwd_t(sv["gu"], dact, mpad)
+            else:
+                dgu = ops.swiglu_bwd(sv["gu"], dact)
             del dact
             dhn = ops.gemm_nt(dgu, lp.wt["gu"])                        # [M,D]
-            self._dw(dgu, sv["hn"], lp.g["gu"], mpad)
-            del dgu
+            self._dw(dgu, sv["hn"], lp.g["gu"], mpad, dyT=dguT)
+            del dgu, dguT
             dh, dw2 = ops.rmsnorm_bwd(dhn, sv["h"], lp.w["ln2"], sv["rstd2"], add=dx)
             lp.g["ln2"].copy_(dw2)
             # ---- attention ----

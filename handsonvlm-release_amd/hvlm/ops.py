@@ -392,6 +392,26 @@ def swiglu_fwd(gu: torch.Tensor, out=None) -> torch.Tensor:
     return act
 
 
+def swiglu_fwd_t(gu: torch.Tensor, r_pad: int):
+    """(act [M, F], actT [F, r_pad]) — the transposed copy is the dW_down operand (columns M.. zero)."""
+    _chk(gu, BF16, "swiglu.gu")
+    assert gu.is_contiguous()
+    M, F2 = gu.shape
+    act = torch.empty((M, F2 // 2), dtype=BF16, device=gu.device)
+    actT = torch.empty((F2 // 2, r_pad), dtype=BF16, device=gu.device)
+    check(_lib.load().hvlm_swiglu_fwd_t(_p(gu), _p(act), _p(actT), M, F2 // 2, r_pad, _stream()), "swiglu_fwd_t")
+    return act, actT
+
+
+def swiglu_bwd_t(gu, dact, r_pad: int):
+    """(dgu [M, 2F], dguT [2F, r_pad])."""
+    M, F2 = gu.shape
+    dgu = torch.empty_like(gu)
+    dguT = torch.empty((F2, r_pad), dtype=BF16, device=gu.device)
+    check(_lib.load().hvlm_swiglu_bwd_t(_p(gu), _p(dact), _p(dgu), _p(dguT), M, F2 // 2, r_pad, _stream()), "swiglu_bwd_t")
+    return dgu, dguT
+
+
 def swiglu_bwd(gu, dact, out=None):
     M, F2 = gu.shape
     dgu = torch.empty_like(gu) if out is None else out

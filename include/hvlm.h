@@ -220,6 +220,12 @@ int hvlm_llama_decode_step_dev(const void* const* w_qkv, const void* const* w_o,
 int hvlm_swiglu_fwd(const void* gu, void* act, int M, int F, void* stream);
 int hvlm_swiglu_bwd(const void* gu, const void* dact, void* dgu, int M, int F, void* stream);
 
+/* The same two functions with a fused TRANSPOSED second output ([features, R_pad] with the token index contiguous, columns
+ * M..R_pad-1 zero) — the operand layout of the weight-gradient GEMMs dW = dY^T X: actT feeds dW_down, dguT feeds dW_gate|up;
+ * saves the read half of a separate hvlm_transpose_bf16 pass.  F % 64 == 0, R_pad % 64 == 0, R_pad >= M. */
+int hvlm_swiglu_fwd_t(const void* gu, void* act, void* actT, int M, int F, int R_pad, void* stream);
+int hvlm_swiglu_bwd_t(const void* gu, const void* dact, void* dgu, void* dguT, int M, int F, int R_pad, void* stream);
+
 /* ------------------------------------------------------------------------------------------ *
  * Visual-token pipeline
  * ------------------------------------------------------------------------------------------ */

@@ -222,6 +222,16 @@ def swiglu_bwd(gu, dact, out=None):
     return y
 
 
+def swiglu_fwd_t(gu, r_pad):
+    act = swiglu_fwd(gu)
+    return act, transpose(act, r_pad=r_pad)
+
+
+def swiglu_bwd_t(gu, dact, r_pad):
+    dgu = swiglu_bwd(gu, dact)
+    return dgu, transpose(dgu, r_pad=r_pad)
+
+
 def patch_im2col(images, P, kpad):
     N, _, HW, _ = images.shape
     G = HW // P

@@ -385,3 +385,17 @@ def test_clip_tower_fp16_vit_l14_vs_oracle():
     e_env, e_hip = rel(env.to(BF), ref), rel(got, ref)
     print(f"ViT-L/14 tower fp16: HIP vs fp32 oracle {e_hip:.3e}; fp16-eager oracle (cast to bf16) vs fp32 oracle {e_env:.3e}")
     assert e_hip <= 1.25 * e_env and e_hip <= 6e-3, (e_hip, e_env)
+
+
+def test_swiglu_fused_transposed_outputs(ops):
+    """hvlm_swiglu_fwd_t / hvlm_swiglu_bwd_t: the row-major output is bit-identical to the plain kernels and the second
+    output is exactly its transpose, zero-padded to R_pad (the token-contiguous operand of the dW GEMMs)."""
+    for M, F in ((13872 // 8, 11008), (77, 256), (64, 64)):
+        gu, da = grnd(M, 2 * F, seed=70), grnd(M, F, seed=71)
+        rp = (M + 63) // 64 * 64
+        act, actT = ops.swiglu_fwd_t(gu, rp)
+        assert torch.equal(act, ops.swiglu_fwd(gu))
+        assert torch.equal(actT[:, :M], act.t()) and float(actT[:, M:].abs().max() if rp > M else 0.0) == 0.0
+        dgu, dguT = ops.swiglu_bwd_t(gu, da, rp)
+        assert torch.equal(dgu, ops.swiglu_bwd(gu, da))
+        assert torch.equal(dguT[:, :M], dgu.t()) and float(dguT[:, M:].abs().max() if rp > M else 0.0) == 0.0
