@@ -25,17 +25,33 @@ def inference(model, sample: Dict, temperature=0.5, top_p=0.9, max_new_tokens=10
 
 
 @torch.no_grad()
-def evaluate_traj(model, samples: Iterable[Dict], reference_labels: bool = True, **gen_kw):
+def inference_batch(model, batch, temperature=0.5, top_p=0.9, max_new_tokens=100, do_sample=True, fp8=False, pad_token_id=0):
+    """A list of samples -> list of pred_hands ([1,2,n,2] or None), generated in lock step (model.generate_batch): prompts
+    are right-padded to the longest one, exactly like the reference's collator would."""
+    T = max(s["input_ids"].shape[1] for s in batch)
+    ids = torch.full((len(batch), T), pad_token_id, dtype=torch.long)
+    mask = torch.zeros((len(batch), T), dtype=torch.bool)
+    for b, s in enumerate(batch):
+        n = s["input_ids"].shape[1]
+        ids[b, :n] = s["input_ids"][0]
+        mask[b, :n] = True
+    image = torch.cat([s["image"] for s in batch], 0)
+    out = model.generate_batch(ids, image=image, attention_mask=mask, do_sample=do_sample, temperature=temperature, top_p=top_p,
+                               max_new_tokens=max_new_tokens, fp8=fp8)
+    return [out.pred_hands[b:b + 1, :, : out.num_hands[b]] if out.num_hands[b] > 0 else None for b in range(len(batch))]
+
+
+@torch.no_grad()
+def evaluate_traj(model, samples: Iterable[Dict], reference_labels: bool = True, batch_size: int = 1, **gen_kw):
     """samples yield dicts with input_ids, image, future_hands [1,2,5,2] (GT; first point dropped), future_valid [1,2].
     Samples whose generation does not contain exactly 4 <hand_traj> tokens are scored with zeros and valid=0, the
-    reference's handling of failed generations.  Returns {'ade','fde','wde','n'} with the reference's label convention."""
+    reference's handling of failed generations.  Returns {'ade','fde','wde','n'} with the reference's label convention.
+    batch_size > 1 generates that many samples in lock step (model.sample_batch) instead of the reference's one by one."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     preds, gts, valids = [], [], []
-    for i, s in enumerate(samples):
-        if i % world != rank:
-            continue
-        _, ph = inference(model, s, **gen_kw)
+
+    def score(s, ph):
         gt = s["future_hands"][:, :, 1:, :].float().cpu().numpy()[0]
         fv = s["future_valid"].float().cpu().numpy()[0]
         if ph is None or ph.shape[2] != 4:
@@ -43,6 +59,22 @@ def evaluate_traj(model, samples: Iterable[Dict], reference_labels: bool = True,
         else:
             preds.append(ph.float().cpu().numpy()); valids.append(fv)
         gts.append(gt)
+
+    pending = []
+    for i, s in enumerate(samples):
+        if i % world != rank:
+            continue
+        if batch_size <= 1:
+            score(s, inference(model, s, **gen_kw)[1])
+            continue
+        pending.append(s)
+        if len(pending) == batch_size:
+            for ss, ph in zip(pending, inference_batch(model, pending, **gen_kw)):
+                score(ss, ph)
+            pending = []
+    if pending:
+        for ss, ph in zip(pending, inference_batch(model, pending, **gen_kw)):
+            score(ss, ph)
     preds = np.stack(preds) if preds else np.zeros((0, 1, 2, 4, 2), np.float32)
     gts = np.stack(gts) if gts else np.zeros((0, 2, 4, 2), np.float32)
     valids = np.stack(valids) if valids else np.zeros((0, 2), np.float32)

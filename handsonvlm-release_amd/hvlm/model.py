@@ -732,15 +732,31 @@ class HandsOnVLMForCausalLM:
                  max_new_tokens=100, use_cache=False, output_hidden_states=True, return_dict_in_generate=True, **kw):
         """The call made by handsonvlm/evaluation/handsonvlm_inference.py:99-109."""
         assert num_beams == 1
-        procs = []
-        if do_sample and temperature != 1.0:
-            procs.append(lambda ids, s: s / temperature)
-        if do_sample and top_p < 1.0:
-            procs.append(lambda ids, s: _top_p_filter(s, top_p))
-        if not do_sample:
-            procs.append(lambda ids, s: torch.full_like(s, float("-inf")).scatter(1, s.argmax(-1, keepdim=True), 0.0))
+        procs = _generation_processors(do_sample, temperature, top_p)
         return self.sample(input_ids, logits_processor=procs, max_length=input_ids.shape[1] + max_new_tokens,
                            image=image, return_dict_in_generate=return_dict_in_generate, **kw)
+
+    @torch.no_grad()
+    def generate_batch(self, input_ids, image=None, attention_mask=None, do_sample=True, temperature=1.0, top_p=1.0,
+                       max_new_tokens=100, fp8: bool = False, **kw):
+        """generate() for a right-padded batch of prompts (input_ids [B, T], attention_mask [B, T]): the same decoding recipe,
+        B samples in lock step (sample_batch)."""
+        procs = _generation_processors(do_sample, temperature, top_p)
+        return self.sample_batch(input_ids, logits_processor=procs, max_length=input_ids.shape[1] + max_new_tokens,
+                                 attention_mask=attention_mask, image=image, fp8=fp8, **kw)
+
+
+def _generation_processors(do_sample: bool, temperature: float, top_p: float):
+    """Logits processors of the reference's generate() call (temperature, top-p; greedy when do_sample is False); every one
+    works on a [B, V] batch of scores."""
+    procs = []
+    if do_sample and temperature != 1.0:
+        procs.append(lambda ids, s: s / temperature)
+    if do_sample and top_p < 1.0:
+        procs.append(lambda ids, s: _top_p_filter(s, top_p))
+    if not do_sample:
+        procs.append(lambda ids, s: torch.full_like(s, float("-inf")).scatter(1, s.argmax(-1, keepdim=True), 0.0))
+    return procs
 
 
 def _top_p_filter(scores: torch.Tensor, top_p: float) -> torch.Tensor:

@@ -153,3 +153,82 @@ def test_sample_batch_equals_per_sample_sampling(monkeypatch):
             a, r = ob.pred_hands[b, :, : ob.num_hands[b]].float(), o1.pred_hands[0].float()
             assert float((a - r).abs().max()) <= 2e-2 * float(r.abs().max()), (b, a, r)
     assert ob.num_hands == [2, 3, 0] and ob.lengths == [21, 16, 17]
+
+
+def test_batched_generation_with_model_chosen_tokens(monkeypatch):
+    """Greedy decoding where the MODEL picks the tokens (only <hand_traj> is boosted at two steps so that hands get decoded):
+    sample_batch on right-padded prompts == the reference-shaped one-by-one loop, token for token and hand for hand."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from test_train_resume_cpu import _tiny
+    m, cfg = _tiny(training=False)
+    m.config.dedup_frames = False
+    c = synth.TINY
+    lens = (12, 9, 14)
+    prompts, imgs = [], []
+    for i, T in enumerate(lens):
+        ids, _, _ = synth.make_text_batch(1, T, seed=20 + i, n_hand=(0,))
+        prompts.append(ids[0])
+        imgs.append(synth.make_images(1, c["frames"], 2, c["image"], seed=30 + i).to(torch.bfloat16))
+    g = torch.Generator().manual_seed(1)
+    noise = [[2.0 * torch.randn(2, 256, generator=g) for _ in range(8)] for _ in range(3)]
+    ids_b = torch.nn.utils.rnn.pad_sequence(prompts, batch_first=True)
+    mask = torch.nn.utils.rnn.pad_sequence([torch.ones(n, dtype=torch.bool) for n in lens], batch_first=True)
+    T = ids_b.shape[1]
+    greedy = lambda ids, s: torch.full_like(s, float("-inf")).scatter(1, s.argmax(-1, keepdim=True), 0.0)  # noqa: E731
+
+    def boost_batch(cur, scores):
+        if cur.shape[1] - T in (1, 3):
+            scores = scores.clone(); scores[:, 32100] += 1e4
+        return scores
+
+    ob = m.sample_batch(ids_b, logits_processor=[boost_batch, greedy], max_length=T + 6, eos_token_id=2, attention_mask=mask,
+                        image=torch.cat(imgs), hand_noise=noise)
+    assert ob.num_hands == [2, 2, 2]
+    for b in range(3):
+        def boost_one(cur, scores, n0=lens[b]):
+            if cur.shape[1] - n0 in (1, 3):
+                scores = scores.clone(); scores[:, 32100] += 1e4
+            return scores
+        o1 = m.sample(prompts[b][None], logits_processor=[boost_one, greedy], max_length=lens[b] + 6, eos_token_id=2, image=imgs[b],
+                      hand_noise=noise[b], use_kv_cache=False)
+        assert ob.sequences[b, : ob.lengths[b]].tolist() == o1.sequences[0].tolist(), b
+        assert torch.allclose(ob.pred_hands[b, :, :2].float(), o1.pred_hands[0].float(), atol=2e-2)
+
+
+def test_evaluate_traj_batched_plumbing(monkeypatch):
+    """evaluate_traj(batch_size=2): samples are right-padded into batches of two (last batch partial), generate_batch is
+    called per batch and its hands are scored exactly as the one-by-one path scores them."""
+    from hvlm import evaluate as E
+    from hvlm.model import SampleDecoderOnlyOutput
+    r = np.random.RandomState(0)
+    samples = [dict(input_ids=torch.arange(3 + i)[None], image=torch.zeros(1, 1), future_hands=torch.from_numpy(r.rand(1, 2, 5, 2).astype(np.float32)),
+                    future_valid=torch.ones(1, 2)) for i in range(5)]
+    preds = [torch.from_numpy(r.rand(1, 2, 4, 2).astype(np.float32)) for _ in range(5)]
+    calls = []
+
+    class Fake:
+        def generate(self, input_ids, image=None, **kw):
+            i = input_ids.shape[1] - 3
+            ph = preds[i] if i != 3 else torch.empty(1, 2, 0, 2)
+            return SampleDecoderOnlyOutput(sequences=input_ids, pred_hands=ph)
+
+        def generate_batch(self, input_ids, image=None, attention_mask=None, **kw):
+            n = attention_mask.sum(1).tolist()
+            calls.append(n)
+            B = len(n)
+            ph = torch.zeros(B, 2, 4, 2)
+            nh = []
+            for b in range(B):
+                i = n[b] - 3
+                assert input_ids[b, : n[b]].tolist() == list(range(n[b])) and (input_ids[b, n[b]:] == 0).all()
+                if i != 3:
+                    ph[b] = preds[i][0]
+                nh.append(0 if i == 3 else 4)
+            o = SampleDecoderOnlyOutput(sequences=input_ids, pred_hands=ph)
+            o.num_hands = nh
+            return o
+
+    a = E.evaluate_traj(Fake(), samples)
+    b = E.evaluate_traj(Fake(), samples, batch_size=2)
+    assert calls == [[3, 4], [5, 6], [7]] and a == b and a["n"] == 5 and np.isfinite(a["ade"])
