@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""GEMM micro-benchmark + correctness (GPU box).  HVLM_GEMM_VARIANT selects the kernel variant."""
+"""GEMM micro-benchmark + correctness (GPU box).  The variant list on the command line is kept for the round-1 logs only:
+HVLM_GEMM_VARIANT is no longer read by the library (the first-generation kernels were removed in round 2); use
+tools/gemm_knobs.py to A/B the switches that exist (HVLM_GEMM_M16, HVLM_GEMM_SEG4, HVLM_GEMM_GROUP_M, HVLM_GEMM_STATIC)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
