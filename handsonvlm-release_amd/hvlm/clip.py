@@ -113,8 +113,9 @@ class CLIPVisionTower:
 
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_tokens(self, images: torch.Tensor) -> torch.Tensor:
-        """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d]."""
+    def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d] (bf16).  `out`: an
+        optional [N, NP+1, d] bf16 destination (a slice of the caller's buffer: no concatenation of chunks afterwards)."""
         cfg, p = self.cfg, self.p
         assert self.is_loaded
         N = images.shape[0]
@@ -151,7 +152,10 @@ class CLIPVisionTower:
             x = mm(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x)
             del hmid
         if f16:
-            x = ops.cast16(x, BF16)                                # image_features.to(images.dtype), clip_encoder.py:48
+            x = ops.cast16(x, BF16, out=None if out is None else out.view(N * T, d))   # image_features.to(images.dtype), clip_encoder.py:48
+        elif out is not None:
+            out.view(N * T, d).copy_(x)
+            x = out
         return x.view(N, T, d)
 
     @torch.no_grad()

@@ -214,10 +214,10 @@ class HandsOnVLMForCausalLM:
                 inv = inverse
                 frames = frames[first]
         n = frames.shape[0]
-        chunks = []
+        NT = cfg.vision.num_patches + 1
+        tok = torch.empty((n, NT, d), dtype=BF16, device=self.device)          # [n, 257, d]: every chunk writes its slice
         for s in range(0, n, cfg.clip_chunk_frames):
-            chunks.append(self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames]))
-        tok = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)          # [n, 257, d]
+            self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames], out=tok[s:s + cfg.clip_chunk_frames])
         if inv is not None:
             tok = tok[inv]
         tok = tok.contiguous()

@@ -600,10 +600,12 @@ def attn_fwd_f16(qkv, B: int, S: int, H: int, dh: int, scale: float):
     return o
 
 
-def cast16(x, to_dtype):
+def cast16(x, to_dtype, out=None):
     """bf16 <-> fp16 (round-to-nearest-even), the casts of clip_encoder.py:44-48."""
     assert x.is_contiguous() and x.numel() % 8 == 0 and {x.dtype, to_dtype} == {BF16, F16}
-    out = torch.empty(x.shape, dtype=to_dtype, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=to_dtype, device=x.device)
+    assert out.is_contiguous() and out.dtype == to_dtype and out.numel() == x.numel()
     fn = _lib.load().hvlm_cast_bf16_to_f16 if to_dtype == F16 else _lib.load().hvlm_cast_f16_to_bf16
     check(fn(_p(x), _p(out), x.numel(), _stream()), "cast16")
     return out

@@ -421,7 +421,10 @@ def attn_fwd_f16(qkv, B, S, H, dh, scale):
     return o.to(F16)
 
 
-def cast16(x, to_dtype):
+def cast16(x, to_dtype, out=None):
+    if out is not None:
+        out.copy_(x.to(to_dtype).view_as(out))
+        return out
     return x.to(to_dtype)
 
 
