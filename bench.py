@@ -490,6 +490,8 @@ def main():
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}\n")
         sys.exit(2)
+    if os.environ.get("HVLM_SHARE_DEVICE", "0") == "1":        # functional check on a box with fewer GPUs than ranks (gloo)
+        local = local % max(1, torch.cuda.device_count())
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     from hvlm import ops

@@ -86,3 +86,21 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 4
     assert np.isfinite(res["value"]) and res["value"] > 0
+
+
+def test_bench_under_torch_distributed_run(tmp_path):
+    """The launch line the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — on this 1-GPU box with both ranks on device 0 over
+    gloo (HVLM_SHARE_DEVICE=1, HVLM_DIST_BACKEND=gloo): rank 0 prints the single JSON line, value = both ranks' samples."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny", "--batch", "2",
+           "--text-len", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-eval"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HVLM_SHARE_DEVICE="1", HVLM_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 4 and res["value"] > 0
