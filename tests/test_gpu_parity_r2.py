@@ -363,25 +363,27 @@ def test_f16_ops_vs_oracle(ops):
     assert torch.equal(ops.cast16(v, F16), v.to(F16)) and torch.equal(ops.cast16(v.to(F16), BF), v.to(F16).to(BF))
 
 
-def test_clip_tower_fp16_vit_l14_vs_oracle():
+@pytest.mark.parametrize("px", [224, 336])
+def test_clip_tower_fp16_vit_l14_vs_oracle(px):
     """The ViT-L/14-dimension tower in fp16 against the fp32 oracle, with the oracle's own fp16-eager run (= what the
-    reference executes: CLIPVisionModel in half precision) as the envelope."""
+    reference executes: CLIPVisionModel in half precision) as the envelope.  224 px = the reference geometry (257 tokens,
+    resident-K/V attention kernel); 336 px = BASELINE config 2's frame size (577 tokens, streaming attention kernel)."""
     from hvlm.clip import CLIPVisionTower
     from hvlm.config import CLIPVisionConfig
-    c = dict(clip_d=1024, clip_mlp=4096, clip_layers=24, clip_heads=16, patch=14, image=224)
+    c = dict(clip_d=1024, clip_mlp=4096, clip_layers=24, clip_heads=16, patch=14, image=px)
     pnp = synth.clip_params(c, seed=77)
     p = synth.to_torch(pnp)
-    img = synth.make_images(1, 3, 3, 224, seed=31)[0].to(BF)               # frames arrive in bf16 (training dtype)
+    img = synth.make_images(1, 3, 3, px, seed=31)[0].to(BF)                # frames arrive in bf16 (training dtype)
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     with torch.no_grad():
         ref = R.clip_features(img.float(), p, 24, 16)                      # fp32
         ph = synth.to_torch(pnp, torch.float16)
         env = R.clip_features(img.to(torch.float16), ph, 24, 16).float()   # fp16 eager (the reference's tower)
     tower = CLIPVisionTower(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
-                                             num_attention_heads=16), "cuda:0", dtype=torch.float16)
+                                             num_attention_heads=16, image_size=px), "cuda:0", dtype=torch.float16)
     tower.load_state_dict(p)
     got = tower(img.cuda())
-    assert got.dtype == BF and got.shape == (3, 256, 1024)                 # features cast back to the frames' dtype
+    assert got.dtype == BF and got.shape == (3, (px // 14) ** 2, 1024)     # features cast back to the frames' dtype
     e_env, e_hip = rel(env.to(BF), ref), rel(got, ref)
     print(f"ViT-L/14 tower fp16: HIP vs fp32 oracle {e_hip:.3e}; fp16-eager oracle (cast to bf16) vs fp32 oracle {e_env:.3e}")
     assert e_hip <= 1.25 * e_env and e_hip <= 6e-3, (e_hip, e_env)
