@@ -489,6 +489,20 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         for (int e = 0; e < 4; ++e) { bias_f[j][2 * e] = EL::lo(bb[e]); bias_f[j][2 * e + 1] = EL::hi(bb[e]); }
       }
     }
+    // residual fragments are fetched ONE ROW-FRAGMENT AHEAD: the loads of fragment i+1 are in flight during the LDS round
+    // trips and stores of fragment i (issued at the top of iteration i, their ~1 us HBM latency was exposed four times per tile)
+    u32x4 res_n[2][2];
+    auto load_res = [&](int i, u32x4 (&dst)[2][2]) {
+      const int mr = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int mc = min(mr + 16 * q, p.M - 1);
+          dst[j][q] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + ncol0 + j * 32);
+        }
+    };
+    load_res(0, res_n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int mrow0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;   // + 16*q
@@ -496,10 +510,8 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int mc = min(mrow0 + 16 * q, p.M - 1);
-          res_r[j][q] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + ncol0 + j * 32);
-        }
+        for (int q = 0; q < 2; ++q) res_r[j][q] = res_n[j][q];
+      if (i + 1 < 4) load_res(i + 1, res_n);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // accumulator layout -> LDS: row l31, 16-B chunk (2g + hi) at chunk position (2g + hi) ^ (l31 & 7)

@@ -76,7 +76,8 @@ def load(path: os.PathLike | None = None) -> ctypes.CDLL:
     global _lib, _protos
     if _lib is not None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    # HVLM_LIB: development A/B of two builds on one box (e.g. lib/libhvlm_base.so); the default is the in-tree library
+    p = Path(path) if path else (Path(os.environ["HVLM_LIB"]) if os.environ.get("HVLM_LIB") else LIB_PATH)
     if not p.exists():
         raise HvlmError(
             f"{p} not found: build it with `make -C {_PKG_ROOT}` (or __graft_entry__.build()). "
