@@ -2,9 +2,11 @@
 // Two schedules of the same structure: 8 phases per K-tile (described first; used by the K-strided TN instantiation) and
 // 4 segments per K-tile (SEG4, the default for K-contiguous operands: see the comment at `if constexpr (SEG4)`).
 //
-// Same tile geometry and LDS image as gemm.hip (256x256 output tile, BK = 64, 8 waves, 128-B LDS rows with
-// the 16-B chunk permutation c ^ ((row>>1)&7), swapped-operand v_mfma_f32_32x32x16_bf16 so a lane owns one
-// output row and 4 consecutive columns), but a different schedule:
+// Tile geometry and LDS image: 256x256 output tile, BK = 64, 8 waves, 128-B LDS rows with the 16-B chunk permutation
+// c ^ ((row>>1)&7), swapped-operand MFMAs (weight rows as MFMA A) so a lane owns one output row and 4 consecutive columns.
+// The DEFAULT kernels (gemm_pp4m_kernel, gemm_pp4m_f16_kernel) issue v_mfma_f32_16x16x32 — 15 % more power-efficient than
+// 32x32x16 on this power-capped chip, see the M16 comment at gemm_pp_body; the 32x32x16 form described below is kept as
+// gemm_pp4_kernel (HVLM_GEMM_M16=0) and is what the TN and fp8 instantiations use.  The schedule:
 //
 //   * the two wave groups (waves 0-3 / 4-7 = one wave of each group on every SIMD) run ONE BARRIER APART:
 //     while one group issues its MFMA cluster the other issues its LDS reads and LDS-DMA, then they swap.
@@ -18,7 +20,7 @@
 //   * a half-tile is read one phase after the wait that retires it (both groups pass a barrier in between);
 //   * LDS-DMA uses buffer loads (`buffer_load_dwordx4 ... lds`): per-lane offsets are tile-independent 32-bit
 //     values, the tile base lives in the (scalar) descriptor, rows past M / N fall outside num_records;
-//   * persistent workgroups walk tiles in the XCD-aware grouped order of gemm.hip; the staging cursor runs across
+//   * persistent workgroups walk tiles in an XCD-aware grouped order (tile_coords); the staging cursor runs across
 //     tile boundaries, so the epilogue of tile i overlaps the loads of tile i+1.  The two groups re-align at the
 //     epilogue (group 1 skips its last barrier, re-staggers after it) so both epilogues run concurrently;
 //   * epilogue through a wave-private LDS transpose (16-B row-contiguous stores / residual loads), see `epilogue`;
@@ -27,7 +29,9 @@
 //     MFMA (v_mfma_scale_f32_32x32x64_f8f6f4), see gemm_pp_body;
 //   * SEG4: the four 8-MFMA phases become two 16-MFMA segments (output rows of half 0, then half 1, each x both column
 //     fragments), 4 barriers per K-tile instead of 8: MFMA busy 70.5 % -> 78.3 %, cycles -10 %, time -3..4 % (the kernel is
-//     clock/power-limited: profiles/r01p_gemm_pp4_pmc.txt).
+//     clock/power-limited: profiles/r01p_gemm_pp4_pmc.txt);
+//   * instantiations: bf16 / fp16 (CLIP tower) / e4m3 operands, K-contiguous (NT) or K-strided (TN), 8-phase or 4-segment
+//     schedule, 32x32x16 or 16x16x32 (fp8: 32x32x64 or 16x16x128) MFMAs — one body, template flags.
 #include "common.h"
 #include "gemm_args.h"
 #include <type_traits>
