@@ -412,8 +412,7 @@ def layernorm_fwd_f16(x, w, b, eps, out=None):
 
 
 def clip_embed_f16(patch_out, cls, pos, N, NP, D):
-    return clip_embed(patch_out.float(), cls.float(), pos.float(), N, NP, D).to(F16) if False else \
-        torch.cat([(cls.float() + pos[0].float()).expand(N, 1, D), patch_out.float().view(N, NP, D) + pos[1:].float()], 1).to(F16)
+    return torch.cat([(cls.float() + pos[0].float()).expand(N, 1, D), patch_out.float().view(N, NP, D) + pos[1:].float()], 1).to(F16)
 
 
 def attn_fwd_f16(qkv, B, S, H, dh, scale):
