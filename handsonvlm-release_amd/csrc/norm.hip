@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16_t* __restri
 
 // grid = HVLM_NORM_BWD_BLOCKS blocks of 256 threads; block b walks rows b, b+grid, ...
 // dx = add + rstd * (g - xhat * mean(g * xhat)),  g = dy * w ; dw_partial[b] = sum dy * xhat.
+// NC = register chunks of 8 elements per thread = ceil(D / 2048): D = 4096 (7B) needs 2, and with NC = NC = 4 for every D the
+// kernel held 240 VGPRs (2 waves per SIMD); templated, the 7B instantiation keeps 4 waves per SIMD in flight.
+template <int NC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
                                                           const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w,
@@ -79,10 +82,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
                                                           int D) {
   __shared__ float red[4];
   const int t = threadIdx.x;
-  float wreg[MAXC][8];
-  float dwacc[MAXC][8];
+  float wreg[NC][8];
+  float dwacc[NC][8];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int i = (c * 256 + t) * 8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { dwacc[c][e] = 0.f; wreg[c][e] = 0.f; }
@@ -92,17 +95,39 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
       for (int e = 0; e < 4; ++e) { wreg[c][2 * e] = bf_lo(wv[e]); wreg[c][2 * e + 1] = bf_hi(wv[e]); }
     }
   }
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+  // the x / dy (/ add) chunks of the NEXT row are fetched before the block-wide reduction of the current one: the row loop
+  // has two barriers per row and nothing else to hide the HBM latency behind (4.1 TB/s without the prefetch)
+  u32x4 nx[NC], ng[NC], na[NC];
+  float nrstd = 0.f;
+  auto fetch = [&](int row) {
     const size_t off = (size_t)row * D;
-    const float rstd = rstd_in[row];
-    float xh[MAXC][8], g[MAXC][8];
-    float dot = 0.f;
+    nrstd = rstd_in[row];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int i = (c * 256 + t) * 8;
       if (i < D) {
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off + i);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off + i);
+        nx[c] = *reinterpret_cast<const u32x4*>(x + off + i);
+        ng[c] = *reinterpret_cast<const u32x4*>(dy + off + i);
+        if (add) na[c] = *reinterpret_cast<const u32x4*>(add + off + i);
+      }
+    }
+  };
+  if ((int)blockIdx.x < rows) fetch(blockIdx.x);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const size_t off = (size_t)row * D;
+    const float rstd = nrstd;
+    u32x4 cx[NC], cg[NC], ca[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { cx[c] = nx[c]; cg[c] = ng[c]; ca[c] = na[c]; }
+    if (row + (int)gridDim.x < rows) fetch(row + gridDim.x);
+    float xh[NC][8], g[NC][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int i = (c * 256 + t) * 8;
+      if (i < D) {
+        const u32x4 xv = cx[c];
+        const u32x4 gv = cg[c];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float x0 = bf_lo(xv[e]) * rstd, x1 = bf_hi(xv[e]) * rstd;
@@ -117,11 +142,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     dot = block_sum<4>(dot, red);
     const float mean = dot / (float)D;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const int i = (c * 256 + t) * 8;
       if (i < D) {
         u32x4 av = {0u, 0u, 0u, 0u};
-        if (add) av = *reinterpret_cast<const u32x4*>(add + off + i);
+        if (add) av = ca[c];
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -135,7 +160,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
   }
   float* dwp = dw_partial + (size_t)blockIdx.x * D;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
+  for (int c = 0; c < NC; ++c) {
     const int i = (c * 256 + t) * 8;
     if (i < D) {
       f32x4 a = {dwacc[c][0], dwacc[c][1], dwacc[c][2], dwacc[c][3]};
@@ -257,9 +282,13 @@ extern "C" int hvlm_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
                                 void* stream) {
   HVLM_REQUIRE(dy && x && w && rstd && dx && dw_partial, "rmsnorm_bwd: null pointer");
   HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "rmsnorm_bwd: bad D=%d", D);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(HVLM_NORM_BWD_BLOCKS), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)add,
-                     (bf16_t*)dx, dw_partial, rows, D);
+#define HVLM_RB(NC_)                                                                                            \
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<NC_>, dim3(HVLM_NORM_BWD_BLOCKS), dim3(256), 0, as_stream(stream),     \
+                     (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)add,           \
+                     (bf16_t*)dx, dw_partial, rows, D)
+  const int nc = (D + 2047) / 2048;
+  if (nc <= 1) HVLM_RB(1); else if (nc == 2) HVLM_RB(2); else if (nc == 3) HVLM_RB(3); else HVLM_RB(4);
+#undef HVLM_RB
   return check_launch("rmsnorm_bwd");
 }
 
