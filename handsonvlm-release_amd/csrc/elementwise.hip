@@ -242,17 +242,21 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void swiglu_t_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
                                                        bf16_t* __restrict__ out, bf16_t* __restrict__ outT, int M, int F,
                                                        int R_pad) {
-  __shared__ __attribute__((aligned(16))) char tile[64 * 128];
+  // backward: ONE workgroup produces the gate AND the up gradient of its 64 x 64 (token, feature) tile — g, u, d are read
+  // and the sigmoid evaluated once (the first version ran one workgroup per output column block and read them twice)
+  constexpr int NT = BWD ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char tile[NT][64 * 128];
   const int C = BWD ? 2 * F : F;                  // columns of the row-major output
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int t = threadIdx.x;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int idx = t + k * 256;
-    const int r = idx >> 3, c = c0 + (idx & 7) * 8;
-    u32x4 o = {0u, 0u, 0u, 0u};
+    const int r = idx >> 3, f = c0 + (idx & 7) * 8;
+    u32x4 o[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) o[n] = u32x4{0u, 0u, 0u, 0u};
     if (r0 + r < M) {
-      const int f = (BWD && c >= F) ? c - F : c;
       const bf16_t* row = gu + (size_t)(r0 + r) * (2 * (size_t)F);
       const u32x4 g = *reinterpret_cast<const u32x4*>(row + f);
       const u32x4 u = *reinterpret_cast<const u32x4*>(row + F + f);
@@ -261,44 +265,52 @@ __global__ __launch_bounds__(256) void swiglu_t_kernel(const bf16_t* __restrict_
         for (int e = 0; e < 4; ++e) {
           const float g0 = bf_lo(g[e]), g1 = bf_hi(g[e]);
           const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
-          o[e] = pack_bf2(s0 * bf_lo(u[e]), s1 * bf_hi(u[e]));
+          o[0][e] = pack_bf2(s0 * bf_lo(u[e]), s1 * bf_hi(u[e]));
         }
+        *reinterpret_cast<u32x4*>(out + (size_t)(r0 + r) * C + f) = o[0];
       } else {
         const u32x4 d = *reinterpret_cast<const u32x4*>(dact + (size_t)(r0 + r) * F + f);
-        const bool is_gate = c < F;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float gg[2] = {bf_lo(g[e]), bf_hi(g[e])};
           float uu[2] = {bf_lo(u[e]), bf_hi(u[e])};
           float dd[2] = {bf_lo(d[e]), bf_hi(d[e])};
-          float rr[2];
+          float rg[2], ru[2];
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const float sg = sigmoidf_(gg[q]);
-            rr[q] = is_gate ? dd[q] * uu[q] * (sg * (1.f + gg[q] * (1.f - sg))) : dd[q] * (gg[q] * sg);
+            rg[q] = dd[q] * uu[q] * (sg * (1.f + gg[q] * (1.f - sg)));
+            ru[q] = dd[q] * (gg[q] * sg);
           }
-          o[e] = pack_bf2(rr[0], rr[1]);
+          o[0][e] = pack_bf2(rg[0], rg[1]);
+          o[NT - 1][e] = pack_bf2(ru[0], ru[1]);
         }
+        *reinterpret_cast<u32x4*>(out + (size_t)(r0 + r) * C + f) = o[0];
+        *reinterpret_cast<u32x4*>(out + (size_t)(r0 + r) * C + F + f) = o[NT - 1];
       }
-      *reinterpret_cast<u32x4*>(out + (size_t)(r0 + r) * C + c) = o;
     }
-    *reinterpret_cast<u32x4*>(tile + r * 128 + (((idx & 7) ^ ((r >> 3) & 7)) << 4)) = o;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      *reinterpret_cast<u32x4*>(tile[n] + r * 128 + (((idx & 7) ^ ((r >> 3) & 7)) << 4)) = o[n];
   }
   __syncthreads();
   const int c2 = t >> 3, rb = t & 7;           // column pair (2*c2, 2*c2+1), input rows rb*8 .. rb*8+7
   const int r = rb * 8;
   if (r0 + r >= R_pad) return;
-  unsigned w[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    w[j] = *reinterpret_cast<const unsigned*>(tile + (r + j) * 128 + ((((c2 >> 2) ^ rb)) << 4) + (c2 & 3) * 4);
+  for (int n = 0; n < NT; ++n) {
+    unsigned w[8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = 2 * c2 + h;
-    const unsigned sel = h ? 0x07060302u : 0x05040100u;
-    const u32x4 o = {__builtin_amdgcn_perm(w[1], w[0], sel), __builtin_amdgcn_perm(w[3], w[2], sel),
-                     __builtin_amdgcn_perm(w[5], w[4], sel), __builtin_amdgcn_perm(w[7], w[6], sel)};
-    *reinterpret_cast<u32x4*>(outT + (size_t)(c0 + c) * R_pad + r0 + r) = o;
+    for (int j = 0; j < 8; ++j)
+      w[j] = *reinterpret_cast<const unsigned*>(tile[n] + (r + j) * 128 + ((((c2 >> 2) ^ rb)) << 4) + (c2 & 3) * 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = 2 * c2 + h;
+      const unsigned sel = h ? 0x07060302u : 0x05040100u;
+      const u32x4 ov = {__builtin_amdgcn_perm(w[1], w[0], sel), __builtin_amdgcn_perm(w[3], w[2], sel),
+                        __builtin_amdgcn_perm(w[5], w[4], sel), __builtin_amdgcn_perm(w[7], w[6], sel)};
+      *reinterpret_cast<u32x4*>(outT + ((size_t)n * F + c0 + c) * R_pad + r0 + r) = ov;
+    }
   }
 }
 
@@ -364,7 +376,7 @@ extern "C" int hvlm_swiglu_bwd_t(const void* gu, const void* dact, void* dgu, vo
                                  void* stream) {
   HVLM_REQUIRE(gu && dact && dgu && dguT && M > 0 && F > 0 && F % 64 == 0 && R_pad >= M && R_pad % 64 == 0,
                "swiglu_bwd_t: bad args (F %% 64, R_pad %% 64, R_pad >= M)");
-  hipLaunchKernelGGL(swiglu_t_kernel<true>, dim3(2 * F / 64, R_pad / 64), dim3(256), 0, as_stream(stream), (const bf16_t*)gu,
+  hipLaunchKernelGGL(swiglu_t_kernel<true>, dim3(F / 64, R_pad / 64), dim3(256), 0, as_stream(stream), (const bf16_t*)gu,
                      (const bf16_t*)dact, (bf16_t*)dgu, (bf16_t*)dguT, M, F, R_pad);
   return check_launch("swiglu_bwd_t");
 }

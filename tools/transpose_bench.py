@@ -40,3 +40,15 @@ for name, env, ks in (("resident", None, "2"), ("streaming", "1", "1")):
     os.environ["HVLM_ATTN_KSTEP"] = ks
     ms = timeit(lambda: ops.attn_fwd(qkv, B, S, H, dh, False, dh ** -0.5))
     print(f"CLIP attention fwd {name} B={B} S={S} H={H}: {ms*1e3:.0f} us  {4*S*S*dh*H*B/ms/1e9:.0f} TF/s (algorithmic)")
+
+M, F = 13872, 11008
+gu = torch.randn(M, 2 * F, device=dev).to(BF); dact = torch.randn(M, F, device=dev).to(BF)
+rp = (M + 63) // 64 * 64
+ms = timeit(lambda: ops.swiglu_fwd(gu))
+print(f"swiglu_fwd {M}x{F}: {ms*1e3:.0f} us  {3*M*F*2/ms/1e6:.0f} GB/s")
+ms = timeit(lambda: ops.swiglu_fwd_t(gu, rp))
+print(f"swiglu_fwd_t {M}x{F}: {ms*1e3:.0f} us  {4*M*F*2/ms/1e6:.0f} GB/s")
+ms = timeit(lambda: ops.swiglu_bwd(gu, dact))
+print(f"swiglu_bwd {M}x{F}: {ms*1e3:.0f} us  {5*M*F*2/ms/1e6:.0f} GB/s")
+ms = timeit(lambda: ops.swiglu_bwd_t(gu, dact, rp))
+print(f"swiglu_bwd_t {M}x{F}: {ms*1e3:.0f} us  {7*M*F*2/ms/1e6:.0f} GB/s (algorithmic: 3 reads + 4 writes of M*F)")
