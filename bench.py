@@ -497,6 +497,7 @@ def main():
     from hvlm import ops
     from hvlm.model import HandsOnVLMForCausalLM
     from hvlm.optim import AdamW
+    torch.manual_seed(20240 + rank)            # the CVAE head's reparameterisation noise: runs are repeatable
 
     cfg = make_config(args)
     B, T = args.batch, args.text_len

@@ -104,3 +104,26 @@ def test_bench_under_torch_distributed_run(tmp_path):
     assert len(lines) == 1, r.stdout[-1000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 4 and res["value"] > 0
+
+
+def test_bench_rccl_backend_world1(tmp_path):
+    """The REAL collective backend ("nccl" = RCCL) on this 1-GPU box: HVLM_FORCE_DIST=1 makes the engine take the distributed
+    path at world size 1 — process-group init over 127.0.0.1, one asynchronous RCCL all-reduce per gradient bucket on RCCL's
+    stream, the overlapped optimizer ordered behind the work handles, the barrier and the MAX reduction of the timing — so
+    everything except the link traffic of N > 1 is exercised with the library the 8-GPU run uses.  Same loss as the
+    non-distributed run (a SUM over one rank with grad_scale 1 is the identity)."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--model", "tiny", "--batch", "2", "--text-len", "64",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-eval"]
+    res = {}
+    for tag, extra in (("plain", {}), ("rccl", dict(HVLM_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                                                     MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port()))):
+        env = {k: v for k, v in os.environ.items() if k not in ("HVLM_DIST_BACKEND", "HVLM_SHARE_DEVICE")}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[-1000:]
+        res[tag] = json.loads(lines[0])
+    assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
+    assert res["rccl"]["loss"] == res["plain"]["loss"], (res["rccl"]["loss"], res["plain"]["loss"])
