@@ -114,6 +114,23 @@ __device__ __forceinline__ float xlane32(float v) {
   return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// XCD-aware workgroup -> (tile, head, sample) mapping.  The hardware deals consecutive workgroups round-robin over the 8 XCDs
+// (each with its own 4 MiB L2), so with the plain (tile = blockIdx.x, head = .y, sample = .z) order the q-tiles of ONE
+// (sample, head) — which all stream the same K / V rows — land on 8 different XCDs and every XCD fetches that K / V from
+// the fabric itself.  Here XCD x takes a CONTIGUOUS chunk of the (sample, head, tile) order: the tiles of one (sample, head)
+// run on one XCD at about the same time and share its L2.
+__device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  const int total = gx * gy * (int)gridDim.z;
+  const int lin = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+  const int x = lin & 7, q = total >> 3, r = total & 7;
+  const int v = x * q + min(x, r) + (lin >> 3);
+  bx = v % gx;
+  const int rest = v / gx;
+  by = rest % gy;
+  bz = rest / gy;
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -134,14 +151,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
   constexpr int QB = NW * 32;            // query rows per workgroup
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;
+  xcd_block(bx, h, b);
   // varlen (cu_seqlens != NULL, llama_flash_attn_monkey_patch.py:81-94): sample b owns the packed rows
   // [cu[b], cu[b+1]); the grid covers max_seqlen and the workgroups past this sample's length leave at once.
   const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;
   const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
   const int nqt = (S + QB - 1) / QB;
-  if ((int)blockIdx.x >= nqt) return;
-  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;  // heavy tiles first
+  if (bx >= nqt) return;
+  const int qt = CAUSAL ? (nqt - 1 - bx) : bx;  // heavy tiles first
   const int q0 = qt * QB;
   const int qi = q0 + w * 32 + l31;
 
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     for (int hf = 0; hf < 2; ++hf)
       v_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
 
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,77 +209,90 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 
     // second 32-key block of the tile entirely past the sequence end (or above the diagonal): skip it
     const bool kb1 = (kv0 + 32 < S) && !(CAUSAL && kv0 + 32 > q0 + w * 32 + 31);
-    auto tile_body = [&](auto nkb_tag) {
-      constexpr int NKB = decltype(nkb_tag)::value;
-      f32x16 s[NKB];
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    // The softmax VALU work is kept as small as in the resident kernel below: the score scale is folded into the exponent
+    // (p = exp2(fma(s, scale, -m)), the running max is taken on raw scores), O and the row sum are rescaled only when some
+    // lane's maximum moved (wave-uniform branch), and the mask code exists only in the variant taken by boundary tiles
+    // (sequence tail / causal diagonal) — the first version masked per element behind 32 wave-uniform branches per tile.
+    // ONE body (separate instantiations per case make the O accumulators meet at a join and spill): the second key block
+    // and the mask are small wave-uniform branches that only touch the score registers.
+    f32x16 s[2];
+    if (kb1) {
 #pragma unroll
       for (int ks = 0; ks < DH / 16; ++ks)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
           const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
-          s[kb] = E16<F16>::mfma32(kf, qf[ks], s[kb]);
+          s[kb] = E16<F16>::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[kb]);
         }
-      const bool need_mask = (kv0 + 32 * NKB > S) || (CAUSAL && kv0 + 32 * NKB - 1 > q0 + w * 32);
-      float mx = -INFINITY;
+    } else {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int ks = 0; ks < DH / 16; ++ks) {
+        const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(l31, ks * 2 + hi));
+        s[0] = E16<F16>::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[0]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[1][r] = -INFINITY;
+    }
+    if ((kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32)) {       // boundary tile: sequence tail / causal diagonal
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float t = s[kb][r] * scale_log2;
-          if (need_mask) {
-            const int key = kv0 + kb * 32 + crow(r, hi);
-            if (key >= S || (CAUSAL && key > qi)) t = -INFINITY;
-          }
-          s[kb][r] = t;
-          mx = fmaxf(mx, t);
+          const int key = kv0 + kb * 32 + crow(r, hi);
+          if (key >= S || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
         }
-      mx = fmaxf(mx, xlane32(mx));
-      const float mnew = fmaxf(m, mx);
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, xlane32(mx));
+    const float mnew = fmaxf(m, mx * scale_log2);
+    if (__builtin_amdgcn_ballot_w64(mnew > m)) {      // some lane's maximum moved (first tile: m = -inf -> alpha = 0)
       const float alpha = fast_exp2(m - mnew);
-      m = mnew;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = fast_exp2(s[kb][r] - mnew);
-          s[kb][r] = p;
-          psum += p;
-        }
-      lsum = lsum * alpha + psum;
+      lsum *= alpha;
 #pragma unroll
       for (int db = 0; db < DH / 32; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m = mnew;
+    }
+    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          float pv[8];
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -m));
+        const float p1 = fast_exp2(__builtin_fmaf(s[kb][r + 1], scale_log2, -m));
+        s[kb][r] = p0; s[kb][r + 1] = p1;
+        psum0 += p0; psum1 += p1;
+      }
+    lsum += psum0 + psum1;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
-          const bf16x8 pf = pack8<F16>(pv);
-          const unsigned kbytes = sV + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
-          s16x4_t lo[DH / 32], hi4[DH / 32];
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && !kb1) break;
 #pragma unroll
-          for (int db = 0; db < DH / 32; ++db)
-            asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
-                         : "=&v"(lo[db]), "=&v"(hi4[db]) : "v"(v_off[db][0] + kbytes), "v"(v_off[db][1] + kbytes) : "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int sp = 0; sp < 2; ++sp) {
+        float pv[8];
 #pragma unroll
-          for (int db = 0; db < DH / 32; ++db) {
-            s16x8_t vv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
-            asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
-            o[db] = E16<F16>::mfma32(__builtin_bit_cast(bf16x8, vv), pf, o[db]);
-          }
+        for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
+        const bf16x8 pf = pack8<F16>(pv);
+        const unsigned kbytes = sV + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
+        s16x4_t lo[DH / 32], hi4[DH / 32];
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db)
+          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
+                       : "=&v"(lo[db]), "=&v"(hi4[db]) : "v"(v_off[db][0] + kbytes), "v"(v_off[db][1] + kbytes) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db) {
+          s16x8_t vv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
+          asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
+          o[db] = E16<F16>::mfma32(__builtin_bit_cast(bf16x8, vv), pf, o[db]);
         }
-    };
-    if (kb1) tile_body(std::integral_constant<int, 2>{});
-    else tile_body(std::integral_constant<int, 1>{});
+      }
+    }
   }
   const float ltot = lsum + xlane32(lsum);
   if (qi < S) {
@@ -520,12 +552,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx, h, b;
+  xcd_block(bx, h, b);
   const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;       // varlen: see attn_fwd_kernel
   const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
   const int nqt = (S + 127) / 128;
-  if ((int)blockIdx.x >= nqt) return;
-  const int qt = CAUSAL ? (nqt - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+  if (bx >= nqt) return;
+  const int qt = CAUSAL ? (nqt - 1 - bx) : bx;
   const int q0 = qt * 128;
   const int qi = q0 + w * 32 + l31;
   const int qc = min(qi, S - 1);
@@ -673,7 +706,8 @@ __global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bw
   const int tid = threadIdx.x, l = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = l & 31, hi = l >> 5;
-  const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int kblk, h, b;
+  xcd_block(kblk, h, b);
   const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;       // varlen: see attn_fwd_kernel
   const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
   const int k0 = kblk * 128;
