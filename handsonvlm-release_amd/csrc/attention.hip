@@ -631,26 +631,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         const bf16x8 vf = lds_frag128(smem, sV + a);
         dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[kb], 0, 0, 0);
       }
-    // dS^T = P o (dP - delta); the softmax scale is applied once to dQ at the end.  The mask code exists only in
-    // the variant taken by boundary tiles (sequence tail / causal diagonal): wave-uniform choice.
-    const bool need_mask = (kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32);
-    if (need_mask) {
+    // dS^T = P o (dP - delta); the softmax scale is applied once to dQ at the end.  Boundary tiles (sequence tail / causal
+    // diagonal) first overwrite the masked scores with -inf (p = exp2(-inf) = 0) in a small wave-uniform branch that only
+    // touches the score registers; ONE copy of the arithmetic follows (two copies — masked / unmasked — cost the causal
+    // kernel five spilled registers, and every scratch reload in the loop drained the LDS-DMA prefetch with its vmcnt(0)).
+    if ((kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32)) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + kb * 32 + crow(r, hi);
-          float p = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -lse2));
-          if (key >= S || (CAUSAL && key > qi)) p = 0.f;
-          s[kb][r] = p * (dp[kb][r] - dlt);
+          if (key >= S || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
         }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -lse2)) * (dp[kb][r] - dlt);
     }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -lse2)) * (dp[kb][r] - dlt);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
