@@ -88,6 +88,42 @@ __device__ __forceinline__ void load_tile(char* smem, unsigned tile_off, const b
   }
 }
 
+// LDS-DMA of 64-row x COLS tiles with everything tile-independent hoisted out of the loop: the per-lane byte offset of each
+// of the wave's pieces (row inside the tile, swizzled source chunk) is computed ONCE (`init`), the tile enters as one scalar
+// byte offset, and the sample's row range is enforced by the buffer descriptor (rows >= S read as zeros) instead of a
+// per-lane clamp.  The first version recomputed row, swizzle, clamp and a 64-bit address for every piece of every tile:
+// measured 580-920 cycles per 64-key step in the forward kernel, 11-17 % of the step (in-kernel cycle stamps).
+template <int COLS, int NW = 4>
+struct TileDma {
+  static constexpr int CPR = COLS / 8, RPI = 64 / CPR, NPIECE = 64 / RPI, PPW = (NPIECE + NW - 1) / NW;
+  unsigned voff[PPW];
+  int w_;
+  __device__ __forceinline__ void init(long stride, int w, int l) {
+    w_ = w;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pi = i * NW + w;
+      const int r = pi * RPI + l / CPR;
+      const int c = (l % CPR) ^ swz_bits<COLS>(r);
+      voff[i] = (unsigned)(((long)r * stride + c * 8) * 2);
+    }
+  }
+  // rs: descriptor over the sample's rows (base = row 0 of the sample, num_records = S * stride * 2 bytes); soff = byte
+  // offset of the tile's first row + the operand's column offset; tile_off = LDS byte offset of the tile
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned tile_off, char* smem) const {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pi = i * NW + w_;
+      if (NPIECE % NW != 0 && pi >= NPIECE) break;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + tile_off + (unsigned)pi * 1024u), 16, voff[i], soff, 0, 0);
+    }
+  }
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sample_rsrc(const bf16_t* row0, long rows, long stride) {
+  const unsigned long bytes = (unsigned long)rows * (unsigned long)stride * 2ul;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(row0), 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ bf16x8 lds_frag128(const char* smem, unsigned off) {
   return *reinterpret_cast<const bf16x8*>(smem + off);
 }
@@ -137,13 +173,13 @@ constexpr float LN2 = 0.6931471805599453f;
 // =================================================================================================
 // forward
 // =================================================================================================
-template <int DH, bool CAUSAL, int NW, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
-                                                       const bf16_t* __restrict__ vt,
-                                                       bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, int S_max, int H, int ld,
-                                                       int S_pad, float scale_log2,
-                                                       const int32_t* __restrict__ cu_seqlens) {
+// (the body lives in a __device__ template: a __global__ TEMPLATE whose body names device-only types — the buffer
+// resource — or holds inline asm with AMDGPU register constraints is dropped silently by the host pass, leaving its launch
+// stub undefined)
+template <int DH, bool CAUSAL, int NW, bool F16>
+__device__ __forceinline__ void attn_fwd_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
+                                              bf16_t* __restrict__ out, float* __restrict__ lse, int S_max, int H, int ld,
+                                              int S_pad, float scale_log2, const int32_t* __restrict__ cu_seqlens) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;   // K tile bytes ; V^T tile has the same size
   constexpr unsigned STAGE = 2 * KT;
@@ -178,15 +214,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 
   const int nkt_all = (S + 63) / 64;
   const int nkt = CAUSAL ? min(nkt_all, min(q0 + QB - 1, S - 1) / 64 + 1) : nkt_all;
-  const bf16_t* kbase = qkv + tok0 * ld + (long)H * DH + h * DH;
-  const bf16_t* vbase = kbase + (long)H * DH;
 
   // a stage = the K and V tiles of 64 keys, both row-major; the V^T fragments of O^T = V^T P^T are gathered from the V
   // tile with `ds_read_b64_tr_b16` (inline asm, see the backward kernels) — no V^T pre-pass, no workspace
+  TileDma<DH, NW> dma;
+  dma.init(ld, w, l);
+  const __amdgpu_buffer_rsrc_t rs_kv = sample_rsrc(qkv + tok0 * ld, S, ld);
+  const unsigned k_col = (unsigned)(((long)H * DH + h * DH) * 2), v_col = k_col + (unsigned)((long)H * DH * 2);
   auto stage = [&](int buf, int kt) {
     const unsigned base = (unsigned)buf * STAGE;
-    load_tile<64, DH, NW>(smem, base, kbase, ld, kt * 64, S, w, l);
-    load_tile<64, DH, NW>(smem, base + KT, vbase, ld, kt * 64, S, w, l);
+    const unsigned row_off = (unsigned)((long)kt * 64 * ld * 2);
+    dma.issue(rs_kv, row_off + k_col, base, smem);
+    dma.issue(rs_kv, row_off + v_col, base + KT, smem);
   };
   const int p16 = l & 15, g16 = l31 >> 4;
   const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
@@ -217,13 +256,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     // and the mask are small wave-uniform branches that only touch the score registers.
     f32x16 s[2];
     if (kb1) {
+      // every K fragment of the step is requested before the first MFMA (64 registers at dh = 128): the read -> wait ->
+      // MFMA chains of the first version exposed one LDS latency per MFMA (QK^T: 1250 cycles per step for 512 of matrix pipe)
+      bf16x8 kfr[DH / 16][2];
 #pragma unroll
       for (int ks = 0; ks < DH / 16; ++ks)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const bf16x8 kf = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
-          s[kb] = E16<F16>::mfma32(kf, qf[ks], ks == 0 ? zero16 : s[kb]);
-        }
+        for (int kb = 0; kb < 2; ++kb) kfr[ks][kb] = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, ks * 2 + hi));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < DH / 16; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) s[kb] = E16<F16>::mfma32(kfr[ks][kb], qf[ks], ks == 0 ? zero16 : s[kb]);
     } else {
 #pragma unroll
       for (int ks = 0; ks < DH / 16; ++ks) {
@@ -234,14 +278,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
       for (int r = 0; r < 16; ++r) s[1][r] = -INFINITY;
     }
     if ((kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32)) {       // boundary tile: sequence tail / causal diagonal
+      // key = kv0 + kb*32 + (r&3) + 8*(r>>2) + 4*hi is valid iff key <= min(S-1, qi): ONE per-lane limit compared with
+      // compile-time constants (the per-element form kept 32 loop-invariant thresholds alive: +60 registers in the causal kernel)
+      int lim = S - 1 - kv0 - 4 * hi;
+      if (CAUSAL) lim = min(lim, qi - kv0 - 4 * hi);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + crow(r, hi);
-          if (key >= S || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) s[kb][r] = -INFINITY;
     }
+    // V^T fragments (transpose reads) are requested one (key block, k half) group ahead of the MFMAs that consume them;
+    // the first group is in flight during the softmax arithmetic.  Explicit counted waits: nothing else uses LDS in between.
+    s16x4_t vlo[2][DH / 32], vhi[2][DH / 32];
+#define HVLM_FWD_VREADS(SET, KB, SP)                                                                                   \
+    do {                                                                                                                \
+      const unsigned kbytes_ = sV + (unsigned)((KB) * 32 + 16 * (SP)) * (DH * 2);                                      \
+      _Pragma("unroll") for (int db = 0; db < DH / 32; ++db)                                                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                         \
+                     : "=&v"(vlo[SET][db]), "=&v"(vhi[SET][db]) : "v"(v_off[db][0] + kbytes_), "v"(v_off[db][1] + kbytes_) : "memory"); \
+    } while (0)
+    HVLM_FWD_VREADS(0, 0, 0);
     float mx = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -269,30 +326,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         psum0 += p0; psum1 += p1;
       }
     lsum += psum0 + psum1;
+    const int ngrp = kb1 ? 4 : 2;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (kb == 1 && !kb1) break;
+    for (int gi = 0; gi < 4; ++gi) {
+      if (gi >= ngrp) break;
+      const int kb = gi >> 1, sp = gi & 1, cur = gi & 1;
+      float pv[8];
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
-        const bf16x8 pf = pack8<F16>(pv);
-        const unsigned kbytes = sV + (unsigned)(kb * 32 + 16 * sp) * (DH * 2);
-        s16x4_t lo[DH / 32], hi4[DH / 32];
-#pragma unroll
-        for (int db = 0; db < DH / 32; ++db)
-          asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"
-                       : "=&v"(lo[db]), "=&v"(hi4[db]) : "v"(v_off[db][0] + kbytes), "v"(v_off[db][1] + kbytes) : "memory");
+      for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
+      const bf16x8 pf = pack8<F16>(pv);
+      if (gi + 1 < ngrp) {
+        if (cur == 0) HVLM_FWD_VREADS(1, (gi + 1) >> 1, (gi + 1) & 1);
+        else HVLM_FWD_VREADS(0, (gi + 1) >> 1, (gi + 1) & 1);
+        if constexpr (DH == 128) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
 #pragma unroll
-        for (int db = 0; db < DH / 32; ++db) {
-          s16x8_t vv = {lo[db][0], lo[db][1], lo[db][2], lo[db][3], hi4[db][0], hi4[db][1], hi4[db][2], hi4[db][3]};
-          asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
-          o[db] = E16<F16>::mfma32(__builtin_bit_cast(bf16x8, vv), pf, o[db]);
-        }
+      for (int db = 0; db < DH / 32; ++db) {
+        s16x8_t vv = {vlo[cur][db][0], vlo[cur][db][1], vlo[cur][db][2], vlo[cur][db][3], vhi[cur][db][0], vhi[cur][db][1], vhi[cur][db][2], vhi[cur][db][3]};
+        asm volatile("" : "+v"(vv));       // the MFMA below must stay behind the lgkmcnt wait
+        o[db] = E16<F16>::mfma32(__builtin_bit_cast(bf16x8, vv), pf, o[db]);
       }
     }
+#undef HVLM_FWD_VREADS
   }
   const float ltot = lsum + xlane32(lsum);
   if (qi < S) {
@@ -309,6 +367,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
       }
     if (lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
   }
+}
+template <int DH, bool CAUSAL, int NW, bool F16 = false>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv,
+                                                       const bf16_t* __restrict__ vt,
+                                                       bf16_t* __restrict__ out,
+                                                       float* __restrict__ lse, int S_max, int H, int ld,
+                                                       int S_pad, float scale_log2,
+                                                       const int32_t* __restrict__ cu_seqlens) {
+  attn_fwd_body<DH, CAUSAL, NW, F16>(qkv, vt, out, lse, S_max, H, ld, S_pad, scale_log2, cu_seqlens);
 }
 
 // =================================================================================================
@@ -636,13 +703,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     // touches the score registers; ONE copy of the arithmetic follows (two copies — masked / unmasked — cost the causal
     // kernel five spilled registers, and every scratch reload in the loop drained the LDS-DMA prefetch with its vmcnt(0)).
     if ((kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32)) {
+      int lim = S - 1 - kv0 - 4 * hi;                 // one per-lane limit against compile-time constants (see the forward kernel)
+      if (CAUSAL) lim = min(lim, qi - kv0 - 4 * hi);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + kb * 32 + crow(r, hi);
-          if (key >= S || (CAUSAL && key > qi)) s[kb][r] = -INFINITY;
-        }
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) s[kb][r] = -INFINITY;
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
