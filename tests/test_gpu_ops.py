@@ -106,7 +106,9 @@ def test_rope_vs_oracle(ops):
 @pytest.mark.parametrize("B,S,H,dh,causal", [(2, 128, 2, 128, True), (1, 200, 3, 128, True), (2, 257, 4, 64, False),
                                               (1, 64, 1, 64, True), (1, 33, 2, 128, True), (1, 50, 2, 128, False),
                                               (2, 868, 2, 128, True), (1, 1, 1, 64, True), (3, 40, 2, 64, False), (1, 320, 2, 64, False),
-                                              (1, 321, 1, 64, False), (1, 1, 2, 64, False)])
+                                              (1, 321, 1, 64, False), (1, 1, 2, 64, False),
+                                              # workgroup counts that are not multiples of the 8 XCDs (27, 50): the XCD-aware order's remainder chunks
+                                              (3, 300, 3, 128, True), (5, 130, 5, 64, True)])
 def test_attention_fwd_bwd_vs_oracle(ops, B, S, H, dh, causal):
     qkv = rnd(B * S, 3 * H * dh, seed=16, scale=0.7)
     x = qkv.float().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
