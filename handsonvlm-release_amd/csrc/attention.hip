@@ -167,6 +167,34 @@ __device__ __forceinline__ void xcd_block(int& bx, int& by, int& bz) {
   bz = rest / gy;
 }
 
+// Epilogue helper: a wave's 32 x DH block in the "one row per lane" accumulator layout (registers = head-dim quads, see the
+// design comment at the top) goes through a wave-private LDS block and leaves with 16-byte row-contiguous stores: 8 (4 at
+// dh = 64) store instructions of 4 (8) full rows each instead of 16 (8) instructions that touch 32 rows with 16 bytes apiece.
+// `blk` = 32 * DH * 2 bytes of LDS nobody else uses; chunk c of row r sits at c ^ (r & (DH/8 - 1)).
+template <int DH, bool F16>
+__device__ __forceinline__ void store_block_rows(char* blk, const f32x16 (&o)[DH / 32], float mul, bf16_t* grow0, long gstride,
+                                                 int rows_valid, int l) {
+  constexpr int ROWB = DH * 2, CPR = DH / 8;
+  const int l31 = l & 31, hi = l >> 5;
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = db * 4 + g;
+      const u32x2 v = {E16<F16>::pack2(o[db][4 * g] * mul, o[db][4 * g + 1] * mul),
+                       E16<F16>::pack2(o[db][4 * g + 2] * mul, o[db][4 * g + 3] * mul)};
+      *reinterpret_cast<u32x2*>(blk + l31 * ROWB + ((c ^ (l31 & (CPR - 1))) << 4) + hi * 8) = v;
+    }
+  constexpr int RPI = 64 / CPR;            // rows per store instruction
+  const int c = l % CPR;
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int r = it * RPI + l / CPR;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(blk + r * ROWB + ((c ^ (r & (CPR - 1))) << 4));
+    if (r < rows_valid) *reinterpret_cast<u32x4*>(grow0 + (long)r * gstride + c * 8) = v;
+  }
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -353,19 +381,12 @@ __device__ __forceinline__ void attn_fwd_body(const bf16_t* __restrict__ qkv, co
 #undef HVLM_FWD_VREADS
   }
   const float ltot = lsum + xlane32(lsum);
-  if (qi < S) {
-    const float inv = 1.f / ltot;
-    bf16_t* op = out + (tok0 + qi) * (long)(H * DH) + h * DH;
-#pragma unroll
-    for (int db = 0; db < DH / 32; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 v = {E16<F16>::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                   E16<F16>::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + d) = v;
-      }
-    if (lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
+  __syncthreads();                         // everyone is done with the last K / V stage: the LDS is free for the output blocks
+  {
+    const int qw0 = q0 + w * 32;
+    store_block_rows<DH, F16>(smem + w * (32 * DH * 2), o, 1.f / ltot, out + (tok0 + qw0) * (long)(H * DH) + h * DH, (long)H * DH,
+                              S - qw0, l);
+    if (qi < S && lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
   }
 }
 template <int DH, bool CAUSAL, int NW, bool F16 = false>
