@@ -984,6 +984,276 @@ __global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bw
   }
 }
 
+// =================================================================================================
+// backward, dK AND dV in one pass by ROLE-SPLIT waves (8 waves, 128 keys per workgroup, one workgroup per CU)
+//   waves 0-3 ("A", keys 32w..): S = Q K^T -> P = exp2(S*scale - lse) -> P to LDS (fp32, lane-linear) -> dV^T += dO^T P
+//   waves 4-7 ("B", same keys):  dP = dO V^T -> P from LDS -> dS = P o (dP - delta) -> dK^T += Q^T dS
+// Against the two-pass form (attn_bwd_dkv_kernel MODE 1 + MODE 2): S and the exponentials once instead of twice (4 matmul units
+// instead of 5), the Q / dO tiles fetched once for eight waves, one launch — and with it one set of per-workgroup fixed costs —
+// less.  B runs ONE 32-query half-step ("slot") behind A, so a slot is: A works on (step, qb) | B on the previous (step, qb);
+// one barrier per slot hands P[slot & 1] over.  Q / dO stages: three buffers (A reads stage s, B stage s or s-1, the DMA of
+// stage s+1 / s+2 is in flight), each fetched 3 slots before A needs it; the counted vmcnt leaves the youngest DMA pending.
+// =================================================================================================
+template <int DH, bool CAUSAL>
+__device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        bf16_t* __restrict__ dqkv, int S_max, int H, int ld, float scale,
+                                                        const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr unsigned KT = 64 * DH * 2;
+  constexpr unsigned STAGE = 2 * KT + 512;            // Q tile, dO tile, lse*log2e [64], delta [64]
+  constexpr unsigned P_OFF = 3 * STAGE;               // P hand-off: [2 slots][4 key waves][4 register quads][64 lanes] x 16 B
+  constexpr unsigned P_SLOT = 4 * 4 * 1024;
+  constexpr unsigned NEXT_OFF = P_OFF + 2 * P_SLOT;   // one int: the entry this workgroup takes next
+  constexpr unsigned EPI_OFF = 2 * STAGE;             // output staging (8 waves x 32 rows): clear of stage buffers 0 and 1
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = l & 31, hi = l >> 5;
+  const bool roleB = w >= 4;                          // wave-uniform
+  const int wk = w & 3;
+  const float scale_log2 = scale * LOG2E;
+  const int p16 = l & 15, g16 = l31 >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  unsigned tr_off[DH / 32][2];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      tr_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
+
+  // ---- PERSISTENT workgroup (one per CU: the kernel needs 130 KiB of LDS, so no second workgroup hides the prologue and the
+  // epilogue of this one): the (sample, head, key block) entries of this XCD's contiguous chunk (see xcd_block) are drawn
+  // from a per-XCD counter in order — the key blocks of one (sample, head) run on one XCD at about the same time — and the
+  // first two stages and the operand rows of the NEXT entry are requested before the output of the current one is stored.
+  const int gx = (S_max + 127) / 128;
+  const int total = gx * H * B;
+  const int xcd = (int)blockIdx.x & 7;
+  const int cq = total >> 3, cr = total & 7;
+  const int c_start = xcd * cq + min(xcd, cr), c_len = cq + (xcd < cr ? 1 : 0);
+  int* const next_slot = reinterpret_cast<int*>(smem + NEXT_OFF);
+  struct Entry { int b, h, k0, S, nsteps, qt_begin; long tok0; };
+  auto decode = [&](int idx, Entry& e) -> bool {     // false: nothing to do (past the sample's length: varlen)
+    const int v = c_start + idx;
+    const int kblk = v % gx, rest = v / gx;
+    e.h = rest % H;
+    e.b = rest / H;
+    e.tok0 = cu_seqlens ? (long)cu_seqlens[e.b] : (long)e.b * S_max;       // varlen: see attn_fwd_kernel
+    e.S = cu_seqlens ? (cu_seqlens[e.b + 1] - cu_seqlens[e.b]) : S_max;
+    e.k0 = kblk * 128;
+    if (e.k0 >= e.S) return false;
+    e.qt_begin = CAUSAL ? (e.k0 / 64) : 0;
+    e.nsteps = (e.S + 63) / 64 - e.qt_begin;
+    return true;
+  };
+  auto draw = [&]() {                                 // thread 0: next entry of this XCD's chunk -> LDS (read after a barrier)
+    if (tid == 0) *next_slot = (int)__hip_atomic_fetch_add(&ctr[xcd], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  Entry cur;
+  bf16x8 own[DH / 16];                                // A: the wave's K rows; B: its V rows (one key per lane)
+  float lse_n = 0.f, dlt_n = 0.f;               // wave 0: lse*log2e / delta of query (stage's first query + tid), on their way to LDS
+  auto load_own = [&](const Entry& e) {
+    const int kc = min(e.k0 + wk * 32 + l31, e.S - 1);
+    const bf16_t* rp = qkv + (e.tok0 + kc) * ld + (long)(roleB ? 2 : 1) * H * DH + e.h * DH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) own[ks] = *reinterpret_cast<const bf16x8*>(rp + ks * 16);
+  };
+  float lse_0 = 0.f, dlt_0 = 0.f;               // the same for stage 0 of an entry (parked behind the previous entry's epilogue)
+  auto stage_issue = [&](const Entry& e, int st, float& ls, float& dl) {    // st = step index relative to qt_begin
+    const unsigned o = (unsigned)(st % 3) * STAGE;
+    const int qq0 = (e.qt_begin + st) * 64;
+    load_tile<64, DH, 8>(smem, o, qkv + e.tok0 * ld + e.h * DH, ld, qq0, e.S, w, l);
+    load_tile<64, DH, 8>(smem, o + KT, dout + e.tok0 * (long)(H * DH) + e.h * DH, (long)H * DH, qq0, e.S, w, l);
+    if (tid < 64) {
+      const int q = min(qq0 + tid, e.S - 1);
+      ls = lse[((long)e.b * H + e.h) * S_max + q] * LOG2E;
+      dl = delta[((long)e.b * H + e.h) * S_max + q];
+    }
+  };
+  auto park_scalars = [&](int st, float ls, float dl) {   // wave 0: the values fetched with stage `st` go to its LDS slot
+    if (tid < 64) {
+      float* sl_ = reinterpret_cast<float*>(smem + (unsigned)(st % 3) * STAGE + 2 * KT);
+      sl_[tid] = ls;
+      sl_[64 + tid] = dl;
+    }
+  };
+  auto entry_prologue = [&](const Entry& e) {   // operand rows + stages 0 and 1 in flight (their scalars: parked at the loop top)
+    load_own(e);
+    stage_issue(e, 0, lse_0, dlt_0);
+    if (e.nsteps > 1) stage_issue(e, 1, lse_n, dlt_n);
+  };
+
+  // first entry
+  draw();
+  __syncthreads();
+  int idx = *next_slot;
+  bool have = false;
+  while (idx < c_len && !(have = decode(idx, cur))) {
+    __syncthreads();
+    draw();
+    __syncthreads();
+    idx = *next_slot;
+  }
+  if (!have) return;
+  entry_prologue(cur);
+
+  for (;;) {
+    __syncthreads();                                  // everyone has read next_slot
+    draw();                                           // the entry after this one
+    park_scalars(0, lse_0, dlt_0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // stages 0 / 1 landed; the output staging of the previous entry is drained
+    const int nidx = *next_slot;
+    const int k0 = cur.k0, S = cur.S, nsteps = cur.nsteps, qt_begin = cur.qt_begin;
+    const int ki = k0 + wk * 32 + l31;
+    const int mk_base = CAUSAL ? ki : 0;                                             // valid iff (unsigned)(q - mk_base) < mk_lim
+    const unsigned mk_lim = ki < S ? (unsigned)(S - mk_base) : 0u;
+    f32x16 acc[DH / 32];                                // A: dV^T, B: dK^T
+#pragma unroll
+    for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+
+    // the transposed-operand MFMAs of a slot: acc[db] += T^T(sp, db) x bfrag[sp], T = the dO (A) / Q (B) tile at LDS offset `tbase`
+    auto tr_mfmas = [&](unsigned tbase, int qb, const bf16x8 (&bfrag)[2]) {
+      s16x4_t t0[2], t1[2];
+#define HVLM_FUSED_ISSUE(SET, SP, DB)                                                                                   \
+      do {                                                                                                              \
+        const unsigned qbytes_ = (unsigned)(qb * 32 + 16 * (SP)) * (DH * 2);                                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                          \
+                     : "=&v"(t0[SET]), "=&v"(t1[SET])                                                                   \
+                     : "v"(tr_off[DB][0] + tbase + qbytes_), "v"(tr_off[DB][1] + tbase + qbytes_) : "memory");          \
+      } while (0)
+      HVLM_FUSED_ISSUE(0, 0, 0);
+#pragma unroll
+      for (int ix = 0; ix < 2 * (DH / 32); ++ix) {
+        const int sp = ix / (DH / 32), db = ix % (DH / 32);
+        const int cu_ = ix & 1;
+        if (ix + 1 < 2 * (DH / 32)) {
+          if (cu_ == 0) HVLM_FUSED_ISSUE(1, (ix + 1) / (DH / 32), (ix + 1) % (DH / 32));
+          else HVLM_FUSED_ISSUE(0, (ix + 1) / (DH / 32), (ix + 1) % (DH / 32));
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(t0[cu_]), "+v"(t1[cu_]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[cu_]), "+v"(t1[cu_]));
+        }
+        const s16x8_t tv = {t0[cu_][0], t0[cu_][1], t0[cu_][2], t0[cu_][3], t1[cu_][0], t1[cu_][1], t1[cu_][2], t1[cu_][3]};
+        acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, tv), bfrag[sp], acc[db], 0, 0, 0);
+      }
+#undef HVLM_FUSED_ISSUE
+    };
+
+    const int nslots = 2 * nsteps + 1;
+    for (int sl = 0; sl < nslots; ++sl) {
+      // DMA of stage (sl + 3) / 2 in the odd slots: its buffer was last read by B one slot ago
+      bool issued = false;
+      if ((sl & 1) && (sl + 3) / 2 < nsteps) { stage_issue(cur, (sl + 3) / 2, lse_n, dlt_n); issued = true; }
+      const int mysl = roleB ? sl - 1 : sl;             // the (step, qb) this wave works on in this slot
+      if (mysl >= 0 && mysl < 2 * nsteps) {
+        const int st = mysl >> 1, qb = mysl & 1;
+        const int qq0 = (qt_begin + st) * 64;
+        const unsigned sQ = (unsigned)(st % 3) * STAGE, sDO = sQ + KT;
+        // step fully masked for this wave's keys (all its queries precede them): both roles skip it, nothing is handed over
+        if (!(CAUSAL && qq0 + 63 < k0 + wk * 32)) {
+          const float* s_sc = reinterpret_cast<const float*>(smem + sQ + 2 * KT) + (roleB ? 64 : 0);   // lse (A) / delta (B)
+          char* pbuf = smem + P_OFF + (unsigned)(mysl & 1) * P_SLOT + (unsigned)(wk * 4) * 1024u + (unsigned)l * 16u;
+          f32x16 x;                                       // A: S, then P;  B: dP, then dS
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = 0.f;
+          const unsigned opnd = roleB ? sDO : sQ;
+#pragma unroll
+          for (int ks = 0; ks < DH / 16; ++ks) {
+            const bf16x8 fr = lds_frag128(smem, opnd + tile_addr<DH>(qb * 32 + l31, ks * 2 + hi));
+            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, own[ks], x, 0, 0, 0);
+          }
+          float sc_r[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc_r[r] = s_sc[qb * 32 + crow(r, hi)];
+          bf16x8 bfrag[2];
+          if (!roleB) {
+            // mask (valid iff causal: key <= query, query < S, key < S) only in boundary slots — the causal diagonal, the
+            // sequence tail — as a pre-mask of the scores (exp2(-inf) = 0): a small wave-uniform branch that touches x only
+            const int q_lo = qq0 + qb * 32;
+            if ((CAUSAL && q_lo < k0 + wk * 32 + 32) || q_lo + 32 > S || k0 + wk * 32 + 32 > S) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if ((unsigned)(q_lo + crow(r, hi) - mk_base) >= mk_lim) x[r] = -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = fast_exp2(__builtin_fmaf(x[r], scale_log2, -sc_r[r]));
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 pv4 = {x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]};
+              *reinterpret_cast<f32x4*>(pbuf + g4 * 1024) = pv4;
+            }
+          } else {
+            float pr[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const f32x4 pv4 = *reinterpret_cast<const f32x4*>(pbuf + g4 * 1024);
+              pr[4 * g4] = pv4[0]; pr[4 * g4 + 1] = pv4[1]; pr[4 * g4 + 2] = pv4[2]; pr[4 * g4 + 3] = pv4[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = pr[r] * (x[r] - sc_r[r]);
+          }
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            float v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v8[j] = x[8 * sp + j];
+            bfrag[sp] = pack8(v8);
+          }
+          // every tracked LDS access of the slot is retired before the untracked transpose reads start
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfrag[0]), "+v"(bfrag[1]) :: "memory");
+          tr_mfmas(roleB ? sQ : sDO, qb, bfrag);
+        }
+      }
+      // end of slot: the stage A starts next (stage (sl + 1) / 2 at an even slot sl + 1) was fetched 3 slots ago and must have
+      // landed; the DMA issued in THIS slot (4 pieces per wave at dh = 128, + the two scalar loads of wave 0) stays in flight
+      if (!(sl & 1)) park_scalars(sl / 2 + 1, lse_n, dlt_n);   // (tracked loads: the compiler waits for them here)
+      if (sl & 1) {
+        if (issued) {
+          if constexpr (DH == 128) {
+            if (w == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else {
+            if (w == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          }
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __syncthreads();
+    }
+    // the next entry: its operand rows and first two stages travel while this entry's output is stored
+    Entry nxt;
+    bool more = false;
+    int ni = nidx;
+    while (ni < c_len && !(more = decode(ni, nxt))) {   // (entries past a short sample's length: draw again — rare, varlen only)
+      __syncthreads();
+      draw();
+      __syncthreads();
+      ni = *next_slot;
+    }
+    const Entry done = cur;
+    if (more) { cur = nxt; entry_prologue(cur); }
+    // epilogue through LDS (16-byte row-contiguous stores); the staging area does not touch stage buffers 0 / 1
+    {
+      const int kw0 = done.k0 + wk * 32;
+      bf16_t* g0 = dqkv + (done.tok0 + kw0) * (long)ld + (long)(roleB ? 1 : 2) * H * DH + done.h * DH;
+      store_block_rows<DH, false>(smem + EPI_OFF + w * (32 * DH * 2), acc, roleB ? scale : 1.f, g0, (long)ld, done.S - kw0, l);
+    }
+    if (!more) break;
+  }
+}
+template <int DH, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                    bf16_t* __restrict__ dqkv, int S_max, int H, int ld, float scale,
+                                                                    const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr) {
+  attn_bwd_dkv_fused_body<DH, CAUSAL>(qkv, dout, lse, delta, dqkv, S_max, H, ld, scale, cu_seqlens, B, ctr);
+}
+
 static inline int spad(int S) { return (S + 63) / 64 * 64; }
 
 template <typename K>
@@ -1060,7 +1330,25 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     constexpr int LDS = 2 * (2 * 64 * DH * 2 + 512);    // two stages of (Q, dO, lse, delta)
     dim3 grid((S + 127) / 128, H, B);
     static const int split = getenv("HVLM_ATTN_DKV_SPLIT") ? atoi(getenv("HVLM_ATTN_DKV_SPLIT")) : (DH == 128 ? 1 : 0);
-    if (split) {
+    static const int fused = getenv("HVLM_ATTN_DKV_FUSED") ? atoi(getenv("HVLM_ATTN_DKV_FUSED")) : 1;
+    if (fused) {
+      // dK and dV in one pass by role-split waves (see attn_bwd_dkv_fused_body)
+      constexpr int LDSF = 3 * (2 * 64 * DH * 2 + 512) + 2 * 4 * 4 * 1024 + 16;
+      if ((rc = set_lds(attn_bwd_dkv_fused_kernel<DH, CAUSAL>, LDSF, "attn_bwd_dkv_fused"))) return rc;
+      static int cusf = 0;
+      if (!cusf) {
+        int dev = 0; hipDeviceProp_t prop;
+        cusf = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        cusf = cusf / 8 * 8;
+      }
+      // per-XCD entry counters: the 256 spare bytes behind delta[B, H, S] in the workspace (hvlm_attn_bwd_ws_bytes)
+      int* ctr = reinterpret_cast<int*>(ws + (((size_t)B * H * S * 4 + 15) & ~(size_t)15));
+      if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) { set_error("attn_bwd: hipMemsetAsync failed"); return HVLM_ERR_LAUNCH; }
+      const long total = (long)((S + 127) / 128) * H * B;
+      hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<DH, CAUSAL>), dim3((unsigned)(total < cusf ? total : cusf)), dim3(512), LDSF, st,
+                         qkv, dout, lse, (const float*)delta, dqkv, S, H, ld, scale, cu, B, ctr);
+      if ((rc = check_launch("attn_bwd_dkv_fused"))) return rc;
+    } else if (split) {
       // dh = 128: dV and dK as two passes with two waves per SIMD each instead of one pass at one wave per SIMD
       if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL, 1>, LDS, "attn_bwd_dv"))) return rc;
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 1>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
