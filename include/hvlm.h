@@ -152,8 +152,10 @@ int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int3
  *   out: bf16 [B*S, H*dh]; lse: f32 [B, H, S] (log-sum-exp of scaled scores; NULL to skip)
  *   dh in {64, 128}.
  *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): the backward keeps
- *       delta = rowsum(dO*O) there; the forward needs none (the transposed operands V^T, K^T, Q^T, dO^T are
- *       gathered inside the kernels with LDS transpose reads — the parameter stays for ABI stability).
+ *       delta = rowsum(dO*O) there, followed by the eight per-XCD entry counters of the persistent dK/dV kernel (zeroed by
+ *       the call itself with a stream-ordered memset: no initialisation is asked of the caller); the forward needs none (the
+ *       transposed operands V^T, K^T, Q^T, dO^T are gathered inside the kernels with LDS transpose reads — the parameter
+ *       stays for ABI stability).
  * bwd: dqkv (same layout as qkv, fully written for rows < S) from dout [B*S, H*dh].
  * ------------------------------------------------------------------------------------------ */
 size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh);
