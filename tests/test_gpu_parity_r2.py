@@ -247,7 +247,10 @@ def test_llama_layer_13b_width_fwd_bwd_vs_oracle():
 # ---------------------------------------------------------------------------------------------------------------------
 # varlen (cu_seqlens) attention, packed batches, activation recompute
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("lens,H,dh", [([200, 1, 129, 64, 333], 3, 128), ([867, 420, 547, 100], 2, 128), ([257, 31], 2, 64)])
+@pytest.mark.parametrize("lens,H,dh", [([200, 1, 129, 64, 333], 3, 128), ([867, 420, 547, 100], 2, 128), ([257, 31], 2, 64),
+                                       # more (sample, head, key block) entries than CUs, many of them past a short sample's end: the
+                                       # persistent dK/dV kernel draws several entries per workgroup and skips the empty ones
+                                       ([867, 100, 500, 33, 700, 260, 129, 64], 12, 128)])
 def test_varlen_attention_fwd_bwd_vs_oracle(ops, lens, H, dh):
     """hvlm_attn_fwd/bwd_varlen — the reference's kernel-swap contract (llama_flash_attn_monkey_patch.py:81-96:
     flash_attn_varlen_qkvpacked_func(qkv [total,3,H,dh], cu_seqlens, max_seqlen, causal=True)): packed rows, every sample
