@@ -761,17 +761,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         }
       }
   }
-  if (qi < S) {
-    bf16_t* op = dqkv + (tok0 + qi) * (long)ld + h * DH;
-#pragma unroll
-    for (int db = 0; db < DH / 32; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hi;
-        u32x2 v = {pack_bf2(dq[db][4 * g] * scale, dq[db][4 * g + 1] * scale),
-                   pack_bf2(dq[db][4 * g + 2] * scale, dq[db][4 * g + 3] * scale)};
-        *reinterpret_cast<u32x2*>(op + d) = v;
-      }
+  __syncthreads();                         // everyone is done with the last K / V stage: the LDS is free for the output blocks
+  {
+    const int qw0 = q0 + w * 32;
+    store_block_rows<DH, false>(smem + w * (32 * DH * 2), dq, scale, dqkv + (tok0 + qw0) * (long)ld + h * DH, (long)ld, S - qw0, l);
   }
 }
 
