@@ -1158,9 +1158,12 @@ __device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict
             const bf16x8 fr = lds_frag128(smem, opnd + tile_addr<DH>(qb * 32 + l31, ks * 2 + hi));
             x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, own[ks], x, 0, 0, 0);
           }
-          float sc_r[16];
+          float sc_r[16];                                  // registers 4g..4g+3 = queries 8g + 4hi + 0..3: one 16-byte read each
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sc_r[r] = s_sc[qb * 32 + crow(r, hi)];
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(s_sc + qb * 32 + 8 * g4 + 4 * hi);
+            sc_r[4 * g4] = v4[0]; sc_r[4 * g4 + 1] = v4[1]; sc_r[4 * g4 + 2] = v4[2]; sc_r[4 * g4 + 3] = v4[3];
+          }
           bf16x8 bfrag[2];
           if (!roleB) {
             // mask (valid iff causal: key <= query, query < S, key < S) only in boundary slots — the causal diagonal, the
