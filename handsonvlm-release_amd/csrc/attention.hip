@@ -1153,10 +1153,14 @@ __device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict
 #pragma unroll
           for (int r = 0; r < 16; ++r) x[r] = 0.f;
           const unsigned opnd = roleB ? sDO : sQ;
+          {
+            // all operand fragments of the slot requested before the first MFMA of the (dependent) chain
+            bf16x8 fr[DH / 16];
 #pragma unroll
-          for (int ks = 0; ks < DH / 16; ++ks) {
-            const bf16x8 fr = lds_frag128(smem, opnd + tile_addr<DH>(qb * 32 + l31, ks * 2 + hi));
-            x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, own[ks], x, 0, 0, 0);
+            for (int ks = 0; ks < DH / 16; ++ks) fr[ks] = lds_frag128(smem, opnd + tile_addr<DH>(qb * 32 + l31, ks * 2 + hi));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < DH / 16; ++ks) x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks], own[ks], x, 0, 0, 0);
           }
           float sc_r[16];                                  // registers 4g..4g+3 = queries 8g + 4hi + 0..3: one 16-byte read each
 #pragma unroll
