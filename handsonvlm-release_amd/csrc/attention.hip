@@ -771,11 +771,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 // =================================================================================================
 // backward, dK / dV  (one key per lane)
 // =================================================================================================
-// MODE 0: dK and dV in one pass (one wave per SIMD at dh = 128: 412 registers).  MODE 1: dV only (S -> P -> dV^T += dO^T P),
-// MODE 2: dK only (S, dP -> dS -> dK^T += Q^T dS): half the accumulators each, so TWO waves per SIMD fit at dh = 128 and the
-// softmax VALU of one wave overlaps the MFMAs of the other; S (and the exponentials) are computed in both passes.
-template <int DH, bool CAUSAL, int MODE = 0>
-__global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bwd_dkv_kernel(
+// The TWO-PASS form (the A/B alternative of the role-split single pass further down, HVLM_ATTN_DKV_FUSED=0).  MODE 1: dV only
+// (S -> P -> dV^T += dO^T P), MODE 2: dK only (S, dP -> dS -> dK^T += Q^T dS): half the accumulators each, so two waves per
+// SIMD fit at dh = 128 (a single pass with both accumulators needs 412 registers = one wave per SIMD and ran at 608 us per layer
+// against 501 for the two passes); S and the exponentials are computed in both passes.
+template <int DH, bool CAUSAL, int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt_g /*Q^T*/,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ dot_g /*dO^T*/,
     const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int S_max,
@@ -896,13 +897,7 @@ __global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bw
 #define HVLM_DKV_ISSUE(SET, SP, DB)                                                                                    \
       do {                                                                                                              \
         const unsigned qbytes_ = (unsigned)(qb * 32 + 16 * (SP)) * (DH * 2);                                           \
-        if constexpr (MODE == 0)                                                                                        \
-          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\tds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7" \
-                       : "=&v"(d0[SET]), "=&v"(d1[SET]), "=&v"(q0r[SET]), "=&v"(q1r[SET])                               \
-                       : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_),                       \
-                         "v"(tr_off[DB][0] + sQ + qbytes_), "v"(tr_off[DB][1] + sQ + qbytes_)                          \
-                       : "memory");                                                                                     \
-        else if constexpr (MODE == 1)                                                                                   \
+        if constexpr (MODE == 1)                                                                                        \
           asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                        \
                        : "=&v"(d0[SET]), "=&v"(d1[SET])                                                                 \
                        : "v"(tr_off[DB][0] + sDO + qbytes_), "v"(tr_off[DB][1] + sDO + qbytes_) : "memory");           \
@@ -936,12 +931,10 @@ __global__ __launch_bounds__(256, (DH == 128 && MODE == 0) ? 1 : 2) void attn_bw
         if (idx + 1 < 2 * (DH / 32)) {
           if (cur == 0) HVLM_DKV_ISSUE(1, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
           else HVLM_DKV_ISSUE(0, (idx + 1) / (DH / 32), (idx + 1) % (DH / 32));
-          if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
-          else if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(d0[cur]), "+v"(d1[cur]));
+          if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(d0[cur]), "+v"(d1[cur]));
           else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(q0r[cur]), "+v"(q1r[cur]));
         } else {
-          if constexpr (MODE == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]), "+v"(q0r[cur]), "+v"(q1r[cur]));
-          else if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]));
+          if constexpr (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d0[cur]), "+v"(d1[cur]));
           else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0r[cur]), "+v"(q1r[cur]));
         }
         if constexpr (DO_DV) {
@@ -1329,7 +1322,6 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   {
     constexpr int LDS = 2 * (2 * 64 * DH * 2 + 512);    // two stages of (Q, dO, lse, delta)
     dim3 grid((S + 127) / 128, H, B);
-    static const int split = getenv("HVLM_ATTN_DKV_SPLIT") ? atoi(getenv("HVLM_ATTN_DKV_SPLIT")) : (DH == 128 ? 1 : 0);
     static const int fused = getenv("HVLM_ATTN_DKV_FUSED") ? atoi(getenv("HVLM_ATTN_DKV_FUSED")) : 1;
     if (fused) {
       // dK and dV in one pass by role-split waves (see attn_bwd_dkv_fused_body)
@@ -1348,8 +1340,8 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
       hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<DH, CAUSAL>), dim3((unsigned)(total < cusf ? total : cusf)), dim3(512), LDSF, st,
                          qkv, dout, lse, (const float*)delta, dqkv, S, H, ld, scale, cu, B, ctr);
       if ((rc = check_launch("attn_bwd_dkv_fused"))) return rc;
-    } else if (split) {
-      // dh = 128: dV and dK as two passes with two waves per SIMD each instead of one pass at one wave per SIMD
+    } else {
+      // the two-pass form: dV, then dK (two waves per SIMD each)
       if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL, 1>, LDS, "attn_bwd_dv"))) return rc;
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 1>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
                          dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
@@ -1358,11 +1350,6 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 2>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
                          dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
       if ((rc = check_launch("attn_bwd_dk"))) return rc;
-    } else {
-      if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL>, LDS, "attn_bwd_dkv"))) return rc;
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
-                         dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
-      if ((rc = check_launch("attn_bwd_dkv"))) return rc;
     }
   }
   return HVLM_OK;
