@@ -294,7 +294,7 @@ extern "C" int hvlm_gemm_bf16(const void* A, const void* B, void* C, int M, int 
   int grid = p.tiles_m * p.tiles_n;
   if (grid > pgrid) grid = pgrid;
   hipStream_t st = as_stream(stream);
-  if (trans_a && trans_b && !getenv("HVLM_GEMM_TN_OLD")) {
+  if (trans_a && trans_b) {
     // both operands K-strided (dW = dY^T X): the 8-phase ping-pong kernel with transpose reads (gemm_pp.hip)
     GemmArgs q;
     q.A = p.A; q.B = p.B; q.C = C; q.bias = p.bias; q.res = p.res;
@@ -306,7 +306,6 @@ extern "C" int hvlm_gemm_bf16(const void* A, const void* B, void* C, int M, int 
     if (rc) return rc;
     return check_launch("gemm_pp_tn");
   }
-  if (trans_a && trans_b) return launch<true, true>(p, grid, st);
   if (trans_a) return launch<true, false>(p, grid, st);
   return launch<false, true>(p, grid, st);
 }
