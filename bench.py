@@ -305,6 +305,9 @@ def eval_leg(model, cfg, T, device):
     100 frames + a T-token prompt + 12 generated tokens of which four are <hand_traj>, each decoded by the CVAE head),
     with this build's KV cache.  Tokens are forced so the amount of work is fixed."""
     from hvlm.synthetic import make_text_batch_np
+    # the training leg leaves most of the device in the caching allocator's free lists, cut to ITS block sizes; the evaluation's
+    # large CLIP / KV-cache blocks would be carved out by releasing and re-allocating device memory inside the timed batches
+    torch.cuda.empty_cache()
     ids, _ = make_text_batch_np(1, T, 7, n_hand=0)
     ids = torch.from_numpy(ids)
     g = torch.Generator(device=device).manual_seed(7)
