@@ -195,6 +195,37 @@ __device__ __forceinline__ void store_block_rows(char* blk, const f32x16 (&o)[DH
   }
 }
 
+// Inverse RoPE (the gradient of apply_rotary_pos_emb, half-split pairs (d, d + DH/2)) applied to a 32 x DH gradient block in
+// the "one row per lane" accumulator layout BEFORE it is stored — the separate rope pass over dqkv (hvlm_rope_qk, inverse)
+// re-read and re-wrote two thirds of the buffer.  Bit-identical to that pass: the values are first scaled and rounded to
+// bf16 exactly as they used to be stored, then rotated with rope_kernel's op-by-op bf16 arithmetic
+// (o1 = bf16(bf16(x1*c) + bf16(x2*s)), o2 = bf16(bf16(x2*c) + bf16(-x1*s)) for the inverse).
+// cos_tab / sin_tab: bf16 [max_pos, DH/2]; p = position of this lane's row.
+template <int DH>
+__device__ __forceinline__ void rope_inverse_block(f32x16 (&o)[DH / 32], float mul, const bf16_t* __restrict__ cos_tab,
+                                                   const bf16_t* __restrict__ sin_tab, int p, int hi) {
+  constexpr int HALF = DH / 2;
+  static_assert(DH / 32 % 2 == 0, "rope pairs (d, d + DH/2) sit in accumulator blocks db and db + DH/64");
+#pragma unroll
+  for (int db = 0; db < DH / 64; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = db * 32 + 8 * g + 4 * hi;            // 4 consecutive rotation pairs d .. d+3 (< DH/2)
+      const u32x2 cv = *reinterpret_cast<const u32x2*>(cos_tab + (long)p * HALF + d);
+      const u32x2 sv = *reinterpret_cast<const u32x2*>(sin_tab + (long)p * HALF + d);
+      const float cc[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
+      const float ss[4] = {bf_lo(sv[0]), bf_hi(sv[0]), bf_lo(sv[1]), bf_hi(sv[1])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = bf2f(f2bf(o[db][4 * g + e] * mul));
+        const float b = bf2f(f2bf(o[db + DH / 64][4 * g + e] * mul));
+        const float sneg = -ss[e];
+        o[db][4 * g + e] = bf2f(f2bf(a * cc[e])) + bf2f(f2bf(-b * sneg));
+        o[db + DH / 64][4 * g + e] = bf2f(f2bf(b * cc[e])) + bf2f(f2bf(a * sneg));
+      }
+    }
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -634,7 +665,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt_g /*K^T [B,H,DH,S_pad]*/,
     const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dqkv, int S_max, int H, int ld, int S_pad, float scale,
-    const int32_t* __restrict__ cu_seqlens) {
+    const int32_t* __restrict__ cu_seqlens, const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
+    const int32_t* __restrict__ rope_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
   const int tid = threadIdx.x, l = tid & 63;
@@ -764,7 +796,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
   __syncthreads();                         // everyone is done with the last K / V stage: the LDS is free for the output blocks
   {
     const int qw0 = q0 + w * 32;
-    store_block_rows<DH, false>(smem + w * (32 * DH * 2), dq, scale, dqkv + (tok0 + qw0) * (long)ld + h * DH, (long)ld, S - qw0, l);
+    float mul = scale;
+    if (rope_cos) {                          // dQ leaves already rotated back (see rope_inverse_block)
+      rope_inverse_block<DH>(dq, scale, rope_cos, rope_sin, rope_pos[tok0 + qc], hi);
+      mul = 1.f;
+    }
+    store_block_rows<DH, false>(smem + w * (32 * DH * 2), dq, mul, dqkv + (tok0 + qw0) * (long)ld + h * DH, (long)ld, S - qw0, l);
   }
 }
 
@@ -984,7 +1021,9 @@ template <int DH, bool CAUSAL>
 __device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         bf16_t* __restrict__ dqkv, int S_max, int H, int ld, float scale,
-                                                        const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr) {
+                                                        const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr,
+                                                        const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
+                                                        const int32_t* __restrict__ rope_pos) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr unsigned KT = 64 * DH * 2;
   constexpr unsigned STAGE = 2 * KT + 512;            // Q tile, dO tile, lse*log2e [64], delta [64]
@@ -1234,7 +1273,12 @@ __device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict
     {
       const int kw0 = done.k0 + wk * 32;
       bf16_t* g0 = dqkv + (done.tok0 + kw0) * (long)ld + (long)(roleB ? 1 : 2) * H * DH + done.h * DH;
-      store_block_rows<DH, false>(smem + EPI_OFF + w * (32 * DH * 2), acc, roleB ? scale : 1.f, g0, (long)ld, done.S - kw0, l);
+      float mul = roleB ? scale : 1.f;
+      if (roleB && rope_cos) {               // dK leaves already rotated back (see rope_inverse_block); dV has no rotation
+        rope_inverse_block<DH>(acc, scale, rope_cos, rope_sin, rope_pos[done.tok0 + min(kw0 + l31, done.S - 1)], hi);
+        mul = 1.f;
+      }
+      store_block_rows<DH, false>(smem + EPI_OFF + w * (32 * DH * 2), acc, mul, g0, (long)ld, done.S - kw0, l);
     }
     if (!more) break;
   }
@@ -1243,8 +1287,10 @@ template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_fused_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                     const float* __restrict__ lse, const float* __restrict__ delta,
                                                                     bf16_t* __restrict__ dqkv, int S_max, int H, int ld, float scale,
-                                                                    const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr) {
-  attn_bwd_dkv_fused_body<DH, CAUSAL>(qkv, dout, lse, delta, dqkv, S_max, H, ld, scale, cu_seqlens, B, ctr);
+                                                                    const int32_t* __restrict__ cu_seqlens, int B, int* __restrict__ ctr,
+                                                                    const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
+                                                                    const int32_t* __restrict__ rope_pos) {
+  attn_bwd_dkv_fused_body<DH, CAUSAL>(qkv, dout, lse, delta, dqkv, S_max, H, ld, scale, cu_seqlens, B, ctr, rope_cos, rope_sin, rope_pos);
 }
 
 static inline int spad(int S) { return (S + 63) / 64 * 64; }
@@ -1300,9 +1346,11 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
 template <int DH, bool CAUSAL>
 static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse,
                     bf16_t* dqkv, char* ws, int B, int S, int H, int ld, float scale, hipStream_t st,
-                    const int32_t* cu = nullptr, long total_tokens = 0) {
+                    const int32_t* cu = nullptr, long total_tokens = 0, const bf16_t* rope_cos = nullptr,
+                    const bf16_t* rope_sin = nullptr, const int32_t* rope_pos = nullptr) {
   bf16_t* qT = nullptr; bf16_t* kT = nullptr; bf16_t* doT = nullptr;     // (unused kernel arguments, kept for signature stability)
   float* delta = reinterpret_cast<float*>(ws);
+  static const int fused = getenv("HVLM_ATTN_DKV_FUSED") ? atoi(getenv("HVLM_ATTN_DKV_FUSED")) : 1;
   int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
   {
     const long tokens = cu ? total_tokens : (long)B * S;
@@ -1316,13 +1364,13 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
     if ((rc = set_lds(attn_bwd_dq_kernel<DH, CAUSAL>, LDS, "attn_bwd_dq"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)kT,
-                       dout, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
+                       dout, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu,
+                       fused ? rope_cos : (const bf16_t*)nullptr, rope_sin, rope_pos);
     if ((rc = check_launch("attn_bwd_dq"))) return rc;
   }
   {
     constexpr int LDS = 2 * (2 * 64 * DH * 2 + 512);    // two stages of (Q, dO, lse, delta)
     dim3 grid((S + 127) / 128, H, B);
-    static const int fused = getenv("HVLM_ATTN_DKV_FUSED") ? atoi(getenv("HVLM_ATTN_DKV_FUSED")) : 1;
     if (fused) {
       // dK and dV in one pass by role-split waves (see attn_bwd_dkv_fused_body)
       constexpr int LDSF = 3 * (2 * 64 * DH * 2 + 512) + 2 * 4 * 4 * 1024 + 16;
@@ -1338,7 +1386,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
       if (hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) { set_error("attn_bwd: hipMemsetAsync failed"); return HVLM_ERR_LAUNCH; }
       const long total = (long)((S + 127) / 128) * H * B;
       hipLaunchKernelGGL((attn_bwd_dkv_fused_kernel<DH, CAUSAL>), dim3((unsigned)(total < cusf ? total : cusf)), dim3(512), LDSF, st,
-                         qkv, dout, lse, (const float*)delta, dqkv, S, H, ld, scale, cu, B, ctr);
+                         qkv, dout, lse, (const float*)delta, dqkv, S, H, ld, scale, cu, B, ctr, rope_cos, rope_sin, rope_pos);
       if ((rc = check_launch("attn_bwd_dkv_fused"))) return rc;
     } else {
       // the two-pass form: dV, then dK (two waves per SIMD each)
@@ -1350,6 +1398,11 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 2>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
                          dout, (const bf16_t*)doT, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu);
       if ((rc = check_launch("attn_bwd_dk"))) return rc;
+      // the two-pass kernels do not rotate: the separate (inverse) rope pass over dq and dk, as before
+      if (rope_cos) {
+        const long tokens = cu ? total_tokens : (long)B * S;
+        if ((rc = hvlm_rope_qk(dqkv, rope_cos, rope_sin, rope_pos, (int)tokens, H, DH, ld, 1, st))) return rc;
+      }
     }
   }
   return HVLM_OK;
@@ -1436,6 +1489,31 @@ extern "C" int hvlm_attn_bwd_varlen(const void* qkv, const void* out, const void
                 : bwd_impl<64, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens);
 }
 
+
+// Attention backward with the gradient of apply_rotary_pos_emb folded into the dQ / dK epilogues: `dqkv` comes out as the
+// gradient with respect to the UN-rotated q / k (what the QKV projection's backward consumes), bit-identical to
+// hvlm_attn_bwd[_varlen] followed by hvlm_rope_qk(dqkv, ..., inverse = 1).  cu_seqlens may be NULL (padded batch; total_tokens
+// is then ignored).  cos_tab / sin_tab: bf16 [max_pos, dh/2]; pos: int32 per token row.
+extern "C" int hvlm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* ws,
+                                  const int32_t* cu_seqlens, int B, int max_seqlen, long total_tokens, int H, int dh, int ld,
+                                  int causal, float scale, const void* cos_tab, const void* sin_tab, const int32_t* pos,
+                                  void* stream) {
+  HVLM_REQUIRE(qkv && out && dout && lse && dqkv && ws && cos_tab && sin_tab && pos, "attn_bwd_rope: null pointer");
+  HVLM_REQUIRE(B > 0 && max_seqlen > 0 && H > 0 && ld >= 3 * H * dh && ld % 8 == 0, "attn_bwd_rope: bad shape");
+  HVLM_REQUIRE(!cu_seqlens || total_tokens > 0, "attn_bwd_rope: total_tokens must be given with cu_seqlens");
+  HVLM_REQUIRE(dh == 64 || dh == 128, "attn_bwd_rope: dh must be 64 or 128 (got %d)", dh);
+  HVLM_REQUIRE(((uintptr_t)ws & 15) == 0, "attn_bwd_rope: workspace must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const bf16_t* q = (const bf16_t*)qkv;
+  const bf16_t* o = (const bf16_t*)out;
+  const bf16_t* g = (const bf16_t*)dout;
+  const bf16_t* c = (const bf16_t*)cos_tab;
+  const bf16_t* sn = (const bf16_t*)sin_tab;
+  if (dh == 128) return causal ? bwd_impl<128, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens, c, sn, pos)
+                               : bwd_impl<128, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens, c, sn, pos);
+  return causal ? bwd_impl<64, true>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens, c, sn, pos)
+                : bwd_impl<64, false>(q, o, g, lse, (bf16_t*)dqkv, (char*)ws, B, max_seqlen, H, ld, scale, st, cu_seqlens, total_tokens, c, sn, pos);
+}
 
 // fp16 instantiation (IEEE half q/k/v/out, v_mfma_f32_32x32x16_f16; P is rounded to fp16 for the PV product): the CLIP
 // tower's attention in the reference's own dtype (handsonvlm/train/train.py:316).  Non-causal, dh = 64 (CLIPAttention).

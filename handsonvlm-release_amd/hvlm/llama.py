@@ -466,8 +466,9 @@ class LlamaStack:
             # ---- attention ----
             dao = ops.gemm_nt(dh, lp.wt["o"])
             self._dw(dh, sv["ao"], lp.g["o"], mpad)
-            dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale, cu_seqlens=seq.cu)
-            ops.rope_qk_(dqkv, self.cos, self.sin, pos, self.H, self.dh, inverse=True)
+            # (the inverse rotary of dq / dk rides in the attention backward's epilogues: no separate pass over dqkv)
+            dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale, cu_seqlens=seq.cu,
+                                rope=(self.cos, self.sin, pos))
             dxn = ops.gemm_nt(dqkv, lp.wt["qkv"])
             self._dw(dqkv, sv["xn"], lp.g["qkv"], mpad)
             del dqkv, dao

@@ -333,13 +333,23 @@ def attn_fwd(qkv: torch.Tensor, B: int, S: int, H: int, dh: int, causal: bool, s
     return o, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=None, cu_seqlens=None):
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal: bool, scale: float, dqkv=None, cu_seqlens=None, rope=None):
+    """rope = (cos, sin, pos): the gradient of the rotary embedding is applied inside the dQ / dK epilogues — dqkv is then
+    the gradient w.r.t. the un-rotated q / k, bit-identical to attn_bwd followed by rope_qk_(dqkv, ..., inverse=True)."""
     _chk(dout, BF16, "attn_bwd.dout")
     assert dout.is_contiguous() and out.is_contiguous()
     lib = _lib.load()
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     ws = torch.empty((lib.hvlm_attn_bwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
+    if rope is not None:
+        cos, sin, pos = rope
+        _chk(cos, BF16, "attn_bwd.cos"); _chk(sin, BF16, "attn_bwd.sin"); _chk(pos, torch.int32, "attn_bwd.pos")
+        assert pos.numel() == qkv.shape[0] and cos.shape[-1] == dh // 2
+        check(lib.hvlm_attn_bwd_rope(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), _p(cu_seqlens), B, S, qkv.shape[0],
+                                     H, dh, qkv.stride(0), 1 if causal else 0, scale, _p(cos), _p(sin), _p(pos), _stream()),
+              "attn_bwd_rope")
+        return dqkv
     if cu_seqlens is None:
         check(lib.hvlm_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(ws), B, S, H, dh, qkv.stride(0),
                                 1 if causal else 0, scale, _stream()), "attn_bwd")

@@ -166,6 +166,16 @@ int hvlm_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                   void* ws, int B, int S, int H, int dh, int ld, int causal, float scale,
                   void* stream);
 
+/* Attention backward with the gradient of apply_rotary_pos_emb (transformers modeling_llama, called from LlamaAttention.forward;
+ * flash path llava/train/llama_flash_attn_monkey_patch.py:48-52) folded into the dQ / dK epilogues: dqkv is the gradient with
+ * respect to the UN-rotated q / k, bit-identical to hvlm_attn_bwd[_varlen] followed by hvlm_rope_qk(dqkv, ..., inverse = 1).
+ *   cu_seqlens: int32 [B+1] for packed rows (then max_seqlen / total_tokens as in hvlm_attn_bwd_varlen) or NULL (padded batch).
+ *   cos_tab / sin_tab: bf16 [max_pos, dh/2]; pos: int32 position of every token row. */
+int hvlm_attn_bwd_rope(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, void* ws,
+                       const int32_t* cu_seqlens, int B, int max_seqlen, long total_tokens, int H, int dh, int ld,
+                       int causal, float scale, const void* cos_tab, const void* sin_tab, const int32_t* pos,
+                       void* stream);
+
 /* Variable-length (packed) form — the contract of the reference's kernel swap, llava/train/llama_flash_attn_monkey_patch.py:
  * 81-96 (unpad_input -> flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, causal=True) -> pad_input):
  *   qkv / out / dout / dqkv hold the tokens of all B samples PACKED end to end (total_tokens rows, no padding rows),

@@ -150,12 +150,14 @@ def attn_fwd(qkv, B, S, H, dh, causal, scale, need_lse=True, out=None, cu_seqlen
     return o, (lse.contiguous() if need_lse else None)
 
 
-def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None, cu_seqlens=None):
+def attn_bwd(qkv, out, dout, lse, B, S, H, dh, causal, scale, dqkv=None, cu_seqlens=None, rope=None):
     with torch.enable_grad():
         x = qkv.float().detach().requires_grad_(True)
         o, _ = _attn_any(x, B, S, H, dh, causal, scale, cu_seqlens)
         (g,) = torch.autograd.grad(o, x, dout.float())
     g = g.to(BF16)
+    if rope is not None:
+        g = rope_qk_(g.clone(), rope[0], rope[1], rope[2], H, dh, inverse=True)
     if dqkv is not None:
         dqkv.copy_(g)
         return dqkv

@@ -404,3 +404,25 @@ def test_swiglu_fused_transposed_outputs(ops):
         dgu, dguT = ops.swiglu_bwd_t(gu, da, rp)
         assert torch.equal(dgu, ops.swiglu_bwd(gu, da))
         assert torch.equal(dguT[:, :M], dgu.t()) and float(dguT[:, M:].abs().max() if rp > M else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("lens,H,dh,packed", [([300, 129, 64], 3, 128, True), ([200, 200], 2, 128, False), ([257, 31], 2, 64, True)])
+def test_attention_backward_with_fused_inverse_rope_is_bit_identical(ops, lens, H, dh, packed):
+    """hvlm_attn_bwd_rope: the gradient of the rotary embedding applied inside the dQ / dK epilogues == hvlm_attn_bwd[_varlen]
+    followed by the separate inverse rope pass over dqkv (hvlm_rope_qk, inverse = 1), bit for bit (padded and packed rows)."""
+    B, total, S = len(lens), sum(lens), max(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda") if packed else None
+    qkv = grnd(total, 3 * H * dh, seed=70, scale=0.7)
+    do = grnd(total, H * dh, seed=71)
+    half = dh // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    fr = torch.outer(torch.arange(512, dtype=torch.float32), inv)
+    cos, sin = fr.cos().to(torch.bfloat16).cuda().contiguous(), fr.sin().to(torch.bfloat16).cuda().contiguous()
+    assert cos.shape == (512, half)
+    pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).cuda()
+    o, lse = ops.attn_fwd(qkv, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)
+    ref = ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)
+    ops.rope_qk_(ref, cos, sin, pos, H, dh, inverse=True)
+    got = ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu, rope=(cos, sin, pos))
+    assert torch.equal(got, ref)
+    assert not torch.equal(got[:, : H * dh], ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)[:, : H * dh])
