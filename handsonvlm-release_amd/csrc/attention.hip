@@ -202,17 +202,27 @@ __device__ __forceinline__ void store_block_rows(char* blk, const f32x16 (&o)[DH
 // (o1 = bf16(bf16(x1*c) + bf16(x2*s)), o2 = bf16(bf16(x2*c) + bf16(-x1*s)) for the inverse).
 // cos_tab / sin_tab: bf16 [max_pos, DH/2]; p = position of this lane's row.
 template <int DH>
-__device__ __forceinline__ void rope_inverse_block(f32x16 (&o)[DH / 32], float mul, const bf16_t* __restrict__ cos_tab,
-                                                   const bf16_t* __restrict__ sin_tab, int p, int hi) {
-  constexpr int HALF = DH / 2;
+struct RopeRow {                       // cos / sin of this lane's row for its DH/4 rotation pairs (16 registers each at dh = 128)
+  u32x2 cv[DH / 64][4], sv[DH / 64][4];
+  __device__ __forceinline__ void load(const bf16_t* __restrict__ cos_tab, const bf16_t* __restrict__ sin_tab, int p, int hi) {
+#pragma unroll
+    for (int db = 0; db < DH / 64; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hi;          // 4 consecutive rotation pairs d .. d+3 (< DH/2)
+        cv[db][g] = *reinterpret_cast<const u32x2*>(cos_tab + (long)p * (DH / 2) + d);
+        sv[db][g] = *reinterpret_cast<const u32x2*>(sin_tab + (long)p * (DH / 2) + d);
+      }
+  }
+};
+template <int DH>
+__device__ __forceinline__ void rope_inverse_block(f32x16 (&o)[DH / 32], float mul, const RopeRow<DH>& rr) {
   static_assert(DH / 32 % 2 == 0, "rope pairs (d, d + DH/2) sit in accumulator blocks db and db + DH/64");
 #pragma unroll
   for (int db = 0; db < DH / 64; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int d = db * 32 + 8 * g + 4 * hi;            // 4 consecutive rotation pairs d .. d+3 (< DH/2)
-      const u32x2 cv = *reinterpret_cast<const u32x2*>(cos_tab + (long)p * HALF + d);
-      const u32x2 sv = *reinterpret_cast<const u32x2*>(sin_tab + (long)p * HALF + d);
+      const u32x2 cv = rr.cv[db][g], sv = rr.sv[db][g];
       const float cc[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
       const float ss[4] = {bf_lo(sv[0]), bf_hi(sv[0]), bf_lo(sv[1]), bf_hi(sv[1])};
 #pragma unroll
@@ -793,12 +803,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
         }
       }
   }
+  RopeRow<DH> rr;
+  if (rope_cos) rr.load(rope_cos, rope_sin, rope_pos[tok0 + qc], hi);     // (in flight across the barrier)
   __syncthreads();                         // everyone is done with the last K / V stage: the LDS is free for the output blocks
   {
     const int qw0 = q0 + w * 32;
     float mul = scale;
     if (rope_cos) {                          // dQ leaves already rotated back (see rope_inverse_block)
-      rope_inverse_block<DH>(dq, scale, rope_cos, rope_sin, rope_pos[tok0 + qc], hi);
+      rope_inverse_block<DH>(dq, scale, rr);
       mul = 1.f;
     }
     store_block_rows<DH, false>(smem + w * (32 * DH * 2), dq, mul, dqkv + (tok0 + qw0) * (long)ld + h * DH, (long)ld, S - qw0, l);
@@ -1275,7 +1287,9 @@ __device__ __forceinline__ void attn_bwd_dkv_fused_body(const bf16_t* __restrict
       bf16_t* g0 = dqkv + (done.tok0 + kw0) * (long)ld + (long)(roleB ? 1 : 2) * H * DH + done.h * DH;
       float mul = roleB ? scale : 1.f;
       if (roleB && rope_cos) {               // dK leaves already rotated back (see rope_inverse_block); dV has no rotation
-        rope_inverse_block<DH>(acc, scale, rope_cos, rope_sin, rope_pos[done.tok0 + min(kw0 + l31, done.S - 1)], hi);
+        RopeRow<DH> rr;                      // (requested here: held across the entry switch, the 32 registers spill)
+        rr.load(rope_cos, rope_sin, rope_pos[done.tok0 + min(kw0 + l31, done.S - 1)], hi);
+        rope_inverse_block<DH>(acc, scale, rr);
         mul = 1.f;
       }
       store_block_rows<DH, false>(smem + EPI_OFF + w * (32 * DH * 2), acc, mul, g0, (long)ld, done.S - kw0, l);
