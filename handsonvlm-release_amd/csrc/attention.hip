@@ -12,7 +12,11 @@
 //              consecutive head-dim elements per register quad -> 8-byte row stores.
 //   backward : two kernels. dQ (one query per lane):  S^T = K Q^T, dP^T = V dO^T,
 //              dS^T = P^T o (dP^T - delta), dQ^T = K^T dS^T.   dK/dV (one key per lane):
-//              S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS.  No atomics, deterministic.
+//              S = Q K^T, dP = dO V^T, dV^T = dO^T P, dK^T = Q^T dS — in ONE pass by role-split waves (attn_bwd_dkv_fused:
+//              four waves own S -> P -> dV, four own dP -> dS -> dK, P is handed over through LDS).  No atomics, deterministic.
+//              The gradient of the rotary embedding can ride in the dQ / dK epilogues (hvlm_attn_bwd_rope).
+//   Workgroups are mapped XCD-aware (xcd_block): the tiles of one (sample, head) share one L2.  Outputs leave through a
+//   wave-private LDS block as 16-byte row-contiguous stores (store_block_rows).
 //   The "transposed" operand fragments (V^T, K^T, Q^T, dO^T) are gathered from the row-major K / V / Q / dO tiles in
 //   LDS with transpose reads (ds_read_b64_tr_b16): no transposed tiles, no pre-passes, no workspace beyond delta.
 //   K/V/Q/dO tiles go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) with the XOR swizzle
