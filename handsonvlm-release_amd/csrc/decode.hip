@@ -405,41 +405,79 @@ static int gemv_pre(const void* W, const void* x, void* y, const void* residual,
   return check_launch("gemv");
 }
 
-// Batched form of attn_decode_kernel for lock-step generation of B samples (BASELINE config 5: batch-32 evaluation):
-// grid (H, B); sample b has its own query row, its own cache slab (sample_stride elements apart) and its own length
-// lens[b] (device int32: keys 0 .. lens[b]-1, the new token's key included).  Same three phases as the batch-1 kernel.
+// Decode attention for lock-step generation of B samples (BASELINE config 5: batch-32 evaluation): grid (H, B); sample b has
+// its own query row, its own cache slab (sample_stride elements apart) and its own length lens[b] (device int32: keys
+// 0 .. lens[b]-1, the new token's key included).  The kernel is a stream of K rows and then V rows (2 * S * DH * 2 bytes per
+// workgroup, nothing re-read), so both phases read a row with DH / 8 ADJACENT lanes x 16 B: one wave instruction covers
+// 64 * 8 / DH whole rows (1 KB, every 128-B line touched once), eight such loads are in flight per wave, and the
+// per-row dot product is closed with DPP adds inside the lane group.  (The first version read K with one lane per row -
+// 64 rows x 16 B per instruction, 24 KB apart - and V four bytes per lane: 3.9 TB/s; profiles/r02v_attn_decode.txt.)
+// sum over a group of 8 or 16 adjacent lanes (aligned to the group); every lane of the group gets the total
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LPR == 8 || LPR == 16, "lane groups of 8 or 16");
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));            // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));           // row_half_mirror: lane i <-> 7 - i
+  if constexpr (LPR == 16) {
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));         // row_mirror: lane i <-> 15 - i
+  }
+  return v;
+}
+
 template <int DH>
 __global__ __launch_bounds__(256) void attn_decode_batched_kernel(const bf16_t* __restrict__ q, int ldq,
                                                                   const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
                                                                   long sample_stride, const int32_t* __restrict__ lens,
                                                                   bf16_t* __restrict__ out, int ldo, int ld, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* qs = reinterpret_cast<float*>(smem);          // [DH]
-  float* red = qs + DH;                                  // [8]
-  float* part = red + 8;                                 // [G][DH] partial outputs
-  constexpr int CP = DH / 2;
-  constexpr int G = 256 / CP;
-  float* sc = part + G * DH;                             // [S] scores / probabilities
-  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  constexpr int LPR = DH / 8;            // lanes per row (16 B each)
+  constexpr int RPI = 64 / LPR;          // rows per wave instruction
+  constexpr int U = 8;                   // loads in flight per lane
+  constexpr int RPP = 4 * RPI * U;       // rows per workgroup pass
+  float* red = reinterpret_cast<float*>(smem);          // [8]
+  float* part = red + 8;                                 // [4 * RPI][DH] partial outputs of every lane group
+  float* sc = part + 4 * RPI * DH;                       // [S] scores / probabilities
+  const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int c = l % LPR, rg = l / LPR;
   const int S = lens[b];
-  kc += (long)b * sample_stride;
-  vc += (long)b * sample_stride;
-  if (t < DH) qs[t] = bf2f(q[(long)b * ldq + h * DH + t]) * scale;
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int s0 = t; s0 < S; s0 += 256) {
-    const bf16_t* kp = kc + (size_t)s0 * ld + h * DH;
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < DH; c += 8) {
-      const u32x4 kv = *reinterpret_cast<const u32x4*>(kp + c);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dot += bf_lo(kv[e]) * qs[c + 2 * e] + bf_hi(kv[e]) * qs[c + 2 * e + 1];
-    }
-    sc[s0] = dot;
-    mx = fmaxf(mx, dot);
+  if (S <= 0) {                          // no keys: defined output, no reads
+    if (t < DH) out[(long)b * ldo + h * DH + t] = 0;
+    return;
   }
-  mx = block_max<4>(mx, red);
+  kc += (long)b * sample_stride + h * DH + c * 8;
+  vc += (long)b * sample_stride + h * DH + c * 8;
+  float qf[8];
+  {
+    const u32x4 qv = *reinterpret_cast<const u32x4*>(q + (long)b * ldq + h * DH + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { qf[2 * e] = bf_lo(qv[e]) * scale; qf[2 * e + 1] = bf_hi(qv[e]) * scale; }
+  }
+  // scores: row = pass base + u * (4 * RPI) + w * RPI + rg
+  float mx = -INFINITY;
+  const int r0 = w * RPI + rg;
+  for (int base = 0; base < S; base += RPP) {
+    u32x4 kv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kv[u] = *reinterpret_cast<const u32x4*>(kc + (size_t)min(base + u * 4 * RPI + r0, S - 1) * ld);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dot += bf_lo(kv[u][e]) * qf[2 * e] + bf_hi(kv[u][e]) * qf[2 * e + 1];
+      dot = group_sum<LPR>(dot);
+      const int row = base + u * 4 * RPI + r0;
+      if (row < S) {
+        if (c == 0) sc[row] = dot;
+        mx = fmaxf(mx, dot);
+      }
+    }
+  }
+  mx = block_max<4>(mx, red);            // (its barriers also publish sc[])
   float sum = 0.f;
   for (int s0 = t; s0 < S; s0 += 256) {
     const float p = __expf(sc[s0] - mx);
@@ -448,24 +486,33 @@ __global__ __launch_bounds__(256) void attn_decode_batched_kernel(const bf16_t* 
   }
   sum = block_sum<4>(sum, red + 4);
   __syncthreads();
-  const int cp = t % CP, g = t / CP;
-  float a0 = 0.f, a1 = 0.f;
-  const bf16_t* vbase = vc + h * DH + 2 * cp;
-#pragma unroll 8
-  for (int s0 = g; s0 < S; s0 += G) {
-    const unsigned v = *reinterpret_cast<const unsigned*>(vbase + (size_t)s0 * ld);
-    const float p = sc[s0];
-    a0 += p * bf_lo(v);
-    a1 += p * bf_hi(v);
+  // P V: the lane keeps its 8 columns; rows as above
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int base = 0; base < S; base += RPP) {
+    u32x4 vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) vv[u] = *reinterpret_cast<const u32x4*>(vc + (size_t)min(base + u * 4 * RPI + r0, S - 1) * ld);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * 4 * RPI + r0;
+      const float p = row < S ? sc[row] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += p * bf_lo(vv[u][e]); acc[2 * e + 1] += p * bf_hi(vv[u][e]); }
+    }
   }
-  part[g * DH + 2 * cp] = a0;
-  part[g * DH + 2 * cp + 1] = a1;
+  {
+    float* pp = part + (w * RPI + rg) * DH + c * 8;
+    *reinterpret_cast<f32x4*>(pp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(pp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
   __syncthreads();
   if (t < DH) {
-    float acc = 0.f;
+    float o = 0.f;
 #pragma unroll
-    for (int i = 0; i < G; ++i) acc += part[i * DH + t];
-    out[(long)b * ldo + h * DH + t] = f2bf(acc / sum);
+    for (int i = 0; i < 4 * RPI; ++i) o += part[i * DH + t];
+    out[(long)b * ldo + h * DH + t] = f2bf(o / sum);
   }
 }
 
@@ -474,8 +521,10 @@ extern "C" int hvlm_attn_decode_batched(const void* q, int ldq, const void* k_ca
                                         float scale, void* stream) {
   HVLM_REQUIRE(q && k_cache && v_cache && lens && out, "attn_decode_batched: null pointer");
   HVLM_REQUIRE(B > 0 && max_S > 0 && H > 0 && ld >= H * dh && ldq >= H * dh && ldo >= H * dh, "attn_decode_batched: bad shape");
+  HVLM_REQUIRE(ld % 8 == 0 && ldq % 8 == 0 && sample_stride % 8 == 0 && ((uintptr_t)q & 15) == 0 && ((uintptr_t)k_cache & 15) == 0 &&
+               ((uintptr_t)v_cache & 15) == 0, "attn_decode_batched: rows must be 16-byte aligned (ld, ldq, sample_stride %% 8)");
   HVLM_REQUIRE(dh == 64 || dh == 128, "attn_decode_batched: dh must be 64 or 128 (got %d)", dh);
-  const size_t lds = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + max_S) * 4;
+  const size_t lds = (size_t)(8 + 4 * (512 / dh) * dh + max_S) * 4;
   HVLM_REQUIRE(lds <= 64 * 1024, "attn_decode_batched: max_S=%d too long for the LDS score buffer", max_S);
   if (dh == 128)
     hipLaunchKernelGGL((attn_decode_batched_kernel<128>), dim3(H, B), dim3(256), lds, as_stream(stream), (const bf16_t*)q, ldq,

@@ -113,6 +113,15 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
   }
 }
 }  // namespace
+
+// shared with gemm_skinny.hip
+int launch_splitk_finalize(const float* ws, int splits, size_t slab, const bf16_t* bias, const bf16_t* res, int ldr, int act,
+                           bf16_t* C, int ldc, int M, int N, hipStream_t stream) {
+  const long total = (long)M * (N / 4);
+  int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, stream, ws, splits, slab, bias, res, ldr, act, C, ldc, M, N);
+  return check_launch("gemm_splitk_finalize");
+}
 }  // namespace hvlm
 
 extern "C" size_t hvlm_gemm_splitk_ws_bytes(int M, int N, int splits) { return (size_t)splits * M * N * 4; }
@@ -145,11 +154,8 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   if (rc) return rc;
   rc = check_launch("gemm_splitk");
   if (rc) return rc;
-  const long total = (long)M * (N / 4);
-  int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
-  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, as_stream(stream), (const float*)ws, splits,
-                     (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act, (bf16_t*)C, ldc, M, N);
-  return check_launch("gemm_splitk_finalize");
+  return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act,
+                                (bf16_t*)C, ldc, M, N, as_stream(stream));
 }
 
 // ---- fp8 (OCP e4m3) operands: CDNA4 v_mfma_scale_f32_32x32x64_f8f6f4 ------------------------------------------------

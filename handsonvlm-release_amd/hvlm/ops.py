@@ -25,6 +25,7 @@ BF16 = torch.bfloat16
 
 _GEMM_CUS = 256                      # persistent GEMM grid (MI355X: 256 CUs); only used to decide the tail split below
 _GEMM_TAIL = os.environ.get("HVLM_GEMM_TAIL", "1") == "1"
+_GEMM_SKINNY = os.environ.get("HVLM_GEMM_SKINNY", "1") == "1"     # 0: M <= 32 goes through the 256 x 256 split-K path (A/B)
 _GEMM_TAIL_MIN_K = int(os.environ.get("HVLM_GEMM_TAIL_MIN_K", "8192"))
 
 # Optional instrumentation (bench.py): hook(M, N, K, True) before / hook(M, N, K, False[, n_kernels]) after each GEMM call.
@@ -84,6 +85,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     hook = _gemm_hook
     if hook is not None:
         hook(M, N, K, True)
+    # M <= 32 (lock-step decode of a batch): the weight-streaming kernel, W straight from HBM into registers
+    if M <= 32 and out.dtype == BF16 and N % 4 == 0 and K % 32 == 0 and K >= 256 and _GEMM_SKINNY:
+        lib = _lib.load()
+        ws = torch.empty((lib.hvlm_gemm_skinny_ws_bytes(M, N, K),), dtype=torch.uint8, device=a.device)
+        check(lib.hvlm_gemm_bf16_nt_skinny(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                           _p(bias), _p(residual), ldr, act, _p(ws), _stream()), "gemm_skinny")
+        if hook is not None:
+            hook(M, N, K, False)
+        return out
     # skinny problems (fewer output tiles than half the CUs): split K across workgroups
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     if tiles <= 96 and out.dtype == BF16 and N % 4 == 0 and K >= 1024:

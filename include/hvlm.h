@@ -69,6 +69,18 @@ int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, int M, int N
                              int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
                              int splits, void* stream);
 
+/* Weight-streaming variant for M <= 32 (lock-step generation of a batch: every projection of a decode step is
+ * x[B, K] @ W[N, K]^T and costs one read of W).  W goes from HBM into registers in coalesced order and is permuted into
+ * MFMA fragments there, x is the LDS-resident operand, K is split over workgroups (hvlm_gemm_skinny_splits slices, fp32
+ * slabs in `ws` of hvlm_gemm_skinny_ws_bytes) and the split-K finalize pass applies bias / activation / residual.
+ * K % 32 == 0, N % 4 == 0, deterministic.  Same function as hvlm_gemm_bf16_nt on the same arguments (reference: the
+ * nn.Linear calls of LlamaDecoderLayer inside generate(), handsonvlm_inference.py:99-113, at batch 32 = BASELINE config 5). */
+int hvlm_gemm_skinny_splits(int N, int K);
+size_t hvlm_gemm_skinny_ws_bytes(int M, int N, int K);
+int hvlm_gemm_bf16_nt_skinny(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb,
+                             int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
+                             void* stream);
+
 /* fp8 (OCP e4m3) operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, block scales fixed to 1):
  *   C[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual, A / B one byte per element, K % 128 == 0,
  *   lda / ldb % 16 == 0; alpha = 1 / (scale_a * scale_b) for per-tensor scaled operands (BASELINE config 5: fp8 forward).

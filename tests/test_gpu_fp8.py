@@ -100,13 +100,17 @@ def test_fp8_forward_accuracy_on_trained_like_weights():
     assert (a0 == a1).float().mean() > 0.9
 
 
-def test_attn_decode_batched_vs_oracle(ops):
-    B, H, dh, maxS = 5, 4, 128, 300
+@pytest.mark.parametrize("B,H,dh,maxS,lens", [(5, 4, 128, 300, [300, 1, 77, 256, 129]), (3, 5, 64, 1100, [1100, 513, 2]),
+                                              (2, 32, 128, 900, [881, 900])])
+def test_attn_decode_batched_vs_oracle(ops, B, H, dh, maxS, lens):
+    """Per-sample lengths from a device array, ragged against the 128- / 256-row passes of the kernel, both head sizes, the
+    7B head count; the query row is a view of the fused qkv row."""
     g = torch.Generator(device="cuda").manual_seed(2)
     cache = (torch.randn(B, maxS, 3 * H * dh, device="cuda", generator=g) * 0.7).to(BF)
     q = (torch.randn(B, 3 * H * dh, device="cuda", generator=g) * 0.7).to(BF)
-    lens = torch.tensor([300, 1, 77, 256, 129], dtype=torch.int32, device="cuda")
+    lens = torch.tensor(lens, dtype=torch.int32, device="cuda")
     out = ops.attn_decode_batched(q, cache, lens, H, dh, dh ** -0.5)
+    assert torch.equal(out, ops.attn_decode_batched(q, cache, lens, H, dh, dh ** -0.5))
     D = H * dh
     for b in range(B):
         n = int(lens[b])

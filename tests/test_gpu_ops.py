@@ -371,6 +371,43 @@ def test_gemm_splitk_vs_oracle(ops, M, N, K, epi):
     assert err < 3e-3, float(err)      # one bf16 rounding of the output (2^-9 relative per element)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(32, 4096, 4096, True), (32, 4096, 11008, True), (32, 12288, 4096, False),
+                                       (17, 22016, 4096, False), (16, 1000, 544, True), (1, 1024, 256, False),
+                                       (5, 32000, 4096, False), (32, 260, 2080, True)])
+def test_gemm_skinny_vs_oracle(ops, M, N, K, epi):
+    """M <= 32 takes the weight-streaming kernel (W from HBM into registers, permuted into MFMA fragments; split K;
+    deterministic finalize): same bound as the tile kernel and bit-identical run to run.  Covers ragged last K slices
+    (11008, 544, 2080), N not a multiple of the 128-row workgroup (1000, 260), one half of x rows (M <= 16) and a
+    row-strided x."""
+    apad, b = rnd(M, K + 64, seed=60), rnd(N, K, seed=61)
+    a = apad[:, :K]
+    bias = rnd(N, seed=62) if epi else None
+    res = rnd(M, N, seed=63) if epi else None
+    ref = a.float() @ b.float().t()
+    if epi:
+        ref = ref + bias.float() + res.float()
+    ops.set_gemm_hook(None)
+    ag, bg = apad.cuda()[:, :K], b.cuda()
+    assert ag.stride(0) == K + 64
+    kw = dict(bias=None if bias is None else bias.cuda(), residual=None if res is None else res.cuda())
+    c1 = ops.gemm_nt(ag, bg, **kw)
+    c2 = ops.gemm_nt(ag, bg, **kw)
+    assert torch.equal(c1, c2)
+    err = (c1.float().cpu() - ref).norm() / ref.norm()
+    assert err < 3e-3, float(err)
+    exact = a.double() @ b.double().t()
+    if epi:
+        exact = exact + bias.double() + res.double()
+    assert (c1.double().cpu() - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()      # one bf16 rounding per element
+    skinny = ops._GEMM_SKINNY
+    try:                                            # the 256 x 256 split-K path on the same operands
+        ops._GEMM_SKINNY = False
+        c3 = ops.gemm_nt(ag, bg, **kw)
+    finally:
+        ops._GEMM_SKINNY = skinny
+    assert (c1.float() - c3.float()).abs().max() <= 2.0 ** -6 * exact.abs().max()
+
+
 def _e4m3_decode(u8: torch.Tensor) -> torch.Tensor:
     """OCP e4m3fn bytes -> fp32 (bias 7, no infinities, S.1111.111 = NaN); written out so the test does not depend on
     torch's float8 support."""
