@@ -399,6 +399,8 @@ def test_gemm_skinny_vs_oracle(ops, M, N, K, epi):
     if epi:
         exact = exact + bias.double() + res.double()
     assert (c1.double().cpu() - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()      # one bf16 rounding per element
+    if K % 64:                                      # the tile kernels need K % 64 == 0: nothing to compare with
+        return
     skinny = ops._GEMM_SKINNY
     try:                                            # the 256 x 256 split-K path on the same operands
         ops._GEMM_SKINNY = False
