@@ -255,8 +255,8 @@ class LlamaStack:
             if cache[li].dim() == 2:                       # batch-1 cache [max_len, 3D] (native decode step)
                 assert seq.B == 1
                 cache[li][:seq.S].copy_(qkv)
-            else:                                          # batched cache [B, max_len, 3D]
-                cache[li][:, :seq.S].copy_(qkv.view(seq.B, seq.S, -1))
+            else:                                          # batched cache [B, max_len, 3D]: only the k | v columns are ever read
+                cache[li][:, :seq.S, self.D:].copy_(qkv.view(seq.B, seq.S, -1)[:, :, self.D:])
         ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
         h = mm(ao, "o", residual=x)
         hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
