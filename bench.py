@@ -433,12 +433,12 @@ def fp8_eval_main(args, real_stdout):
     def run(fp8, dedup, steps, warmup):
         model.config.dedup_frames = dedup
         for _ in range(warmup):
-            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8)
+            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8, fp8_decode=fp8)
         torch.cuda.synchronize()
         ev.pairs, ev.kernels, ev.enabled = [], 0, True
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8)
+            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8, fp8_decode=fp8)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         ev.enabled = False

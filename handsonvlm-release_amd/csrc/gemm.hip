@@ -89,6 +89,7 @@ static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int 
 namespace hvlm {
 namespace {
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ ws, int splits, size_t slab,
+                                                              const float* __restrict__ col_scale,
                                                               const bf16_t* __restrict__ bias,
                                                               const bf16_t* __restrict__ res, int ldr, int act,
                                                               bf16_t* __restrict__ C, int ldc, int M, int N) {
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
     float o[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+      if (col_scale) o[e] *= col_scale[n + e];         // per-output-channel weight scale (e4m3 weights)
       if (bias) o[e] += bf2f(bias[n + e]);
       if (act == HVLM_ACT_QUICK_GELU) o[e] = quick_gelu(o[e]);
       if (res) o[e] += bf2f(res[m * (long)ldr + n + e]);
@@ -115,11 +117,11 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
 }  // namespace
 
 // shared with gemm_skinny.hip
-int launch_splitk_finalize(const float* ws, int splits, size_t slab, const bf16_t* bias, const bf16_t* res, int ldr, int act,
-                           bf16_t* C, int ldc, int M, int N, hipStream_t stream) {
+int launch_splitk_finalize(const float* ws, int splits, size_t slab, const float* col_scale, const bf16_t* bias,
+                           const bf16_t* res, int ldr, int act, bf16_t* C, int ldc, int M, int N, hipStream_t stream) {
   const long total = (long)M * (N / 4);
   int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
-  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, stream, ws, splits, slab, bias, res, ldr, act, C, ldc, M, N);
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(fg), dim3(256), 0, stream, ws, splits, slab, col_scale, bias, res, ldr, act, C, ldc, M, N);
   return check_launch("gemm_splitk_finalize");
 }
 }  // namespace hvlm
@@ -154,8 +156,8 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   if (rc) return rc;
   rc = check_launch("gemm_splitk");
   if (rc) return rc;
-  return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act,
-                                (bf16_t*)C, ldc, M, N, as_stream(stream));
+  return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                act, (bf16_t*)C, ldc, M, N, as_stream(stream));
 }
 
 // ---- fp8 (OCP e4m3) operands: CDNA4 v_mfma_scale_f32_32x32x64_f8f6f4 ------------------------------------------------

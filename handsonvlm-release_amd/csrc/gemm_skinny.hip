@@ -17,8 +17,8 @@
 #include "common.h"
 
 namespace hvlm {
-int launch_splitk_finalize(const float* ws, int splits, size_t slab, const bf16_t* bias, const bf16_t* res, int ldr, int act,
-                           bf16_t* C, int ldc, int M, int N, hipStream_t stream);
+int launch_splitk_finalize(const float* ws, int splits, size_t slab, const float* col_scale, const bf16_t* bias,
+                           const bf16_t* res, int ldr, int act, bf16_t* C, int ldc, int M, int N, hipStream_t stream);
 namespace {
 
 constexpr int SK_WAVES = 8;            // 128 rows of W per workgroup
@@ -26,42 +26,56 @@ constexpr int SK_WAVES = 8;            // 128 rows of W per workgroup
 #define HVLM_SK_DEPTH 8
 #endif
 constexpr int SK_DEPTH = HVLM_SK_DEPTH; // W loads in flight per lane (x 16 B)
-static_assert(SK_WAVES == 8, "x staging assumes 8 waves");
+static_assert(SK_WAVES == 8 && SK_DEPTH % 2 == 0, "x staging assumes 8 waves; the e4m3 ring is half as deep");
 constexpr int SK_PAD = 8;              // elements of padding per x row in LDS
 
-template <int HALVES>                  // 16-row groups of x: 1 (M <= 16) or 2 (M <= 32)
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+// eight e4m3 bytes (two dwords, k ascending with the byte address) -> eight bf16: exact (3 mantissa bits)
+__device__ __forceinline__ bf16x8 e4m3x8_to_bf16(unsigned a, unsigned b) {
+  const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
+  const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
+  const u32x4 r = {pack_bf2(p0[0], p0[1]), pack_bf2(p1[0], p1[1]), pack_bf2(p2[0], p2[1]), pack_bf2(p3[0], p3[1])};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// HALVES: 16-row groups of x, 1 (M <= 16) or 2 (M <= 32).  W8: W is e4m3, one byte per element (weight-only quantisation:
+// converted to bf16 in registers, x stays bf16, the per-output-channel scale is applied by the finalize pass).  A "step" is
+// the 64 bytes of a W row one load instruction covers: 32 k of bf16 or 64 k of e4m3, DEPTH steps in flight.
+template <int HALVES, bool W8>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ A, const char* __restrict__ W,
                                                                      float* __restrict__ ws, int M, int N, int K, int lda,
                                                                      int ldb, int steps_per_split, size_t slab) {
+  constexpr int KPS = W8 ? 64 : 32;      // k per step
+  constexpr int DEPTH = W8 ? SK_DEPTH / 2 : SK_DEPTH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
   const int t = threadIdx.x, w = t >> 6, l = t & 63, r16 = l & 15, g = l >> 4;
-  const int total_steps = K >> 5;
+  const int total_steps = K / KPS;
   const int s0 = blockIdx.y * steps_per_split;
-  const int nsteps = min(steps_per_split, total_steps - s0);                  // 32-deep k steps of this slice
-  const int padded = (steps_per_split + SK_DEPTH - 1) / SK_DEPTH * SK_DEPTH;    // the loop runs whole rings; x is zero beyond nsteps
-  const int xstride = padded * 32 + SK_PAD;
-  const int kbase = s0 * 32;
+  const int nsteps = min(steps_per_split, total_steps - s0);                  // steps of this slice
+  const int padded = (steps_per_split + DEPTH - 1) / DEPTH * DEPTH;            // the loop runs whole rings; x is zero beyond nsteps
+  const int xstride = padded * KPS + SK_PAD;
+  const int kbase = s0 * KPS;
   const int nw = blockIdx.x * (SK_WAVES * 16) + w * 16;                         // first of this wave's 16 rows of W
   const int n = nw + r16;                                                       // MFMA column of this lane
-  const bf16_t* wp = W + (size_t)min(nw + (l >> 2), N - 1) * ldb + kbase + (l & 3) * 8;   // coalesced load order
+  // coalesced load order: lane = (row l >> 2, 16-byte chunk l & 3); byte addressing, 64 B per row and step in both formats
+  const char* wp = W + ((size_t)min(nw + (l >> 2), N - 1) * ldb + kbase) * (W8 ? 1 : 2) + (l & 3) * 16;
   const int perm = (4 * r16 + g) << 2;                                           // fragment lane (r16, g) <- load lane 4 * r16 + g
 
-  u32x4 ring[SK_DEPTH];
+  u32x4 ring[DEPTH];
 #pragma unroll
-  for (int i = 0; i < SK_DEPTH; ++i) ring[i] = *reinterpret_cast<const u32x4*>(wp + min(i, nsteps - 1) * 32);
+  for (int i = 0; i < DEPTH; ++i) ring[i] = *reinterpret_cast<const u32x4*>(wp + min(i, nsteps - 1) * 64);
 
-  // x slice -> LDS: wave w fills rows w, w + 8, ...; rows >= M and steps >= nsteps are zero.  A slice is at most 32 steps = 128
+  // x slice -> LDS: wave w fills rows w, w + 8, ...; rows >= M and steps >= nsteps are zero.  A slice is at most 1024 k = 128
   // chunks of 16 B per row, two per lane: all 4 * HALVES loads are issued behind the ring's, straight-line (a loop here
   // gets a vmcnt(0) in its preheader, which drains the ring, and one load -> wait -> write per trip)
   {
-    constexpr int XR = 2 * HALVES;
+    constexpr int XR = 2 * HALVES, CPS = KPS / 8;      // 16-byte chunks of x per step
     u32x4 v[XR][2];
 #pragma unroll
     for (int mi = 0; mi < XR; ++mi) {
       const bf16_t* ap = A + (size_t)min(w + SK_WAVES * mi, M - 1) * lda + kbase;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) v[mi][u] = *reinterpret_cast<const u32x4*>(ap + min(l + 64 * u, nsteps * 4 - 1) * 8);
+      for (int u = 0; u < 2; ++u) v[mi][u] = *reinterpret_cast<const u32x4*>(ap + min(l + 64 * u, nsteps * CPS - 1) * 8);
     }
 #pragma unroll
     for (int mi = 0; mi < XR; ++mi)
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
       for (int u = 0; u < 2; ++u) {
         const int m = w + SK_WAVES * mi, c = l + 64 * u;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        if (c < padded * 4) *reinterpret_cast<u32x4*>(xs + m * xstride + c * 8) = (m < M && c < nsteps * 4) ? v[mi][u] : z;
+        if (c < padded * CPS) *reinterpret_cast<u32x4*>(xs + m * xstride + c * 8) = (m < M && c < nsteps * CPS) ? v[mi][u] : z;
       }
   }
   __syncthreads();
@@ -77,22 +91,35 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
   f32x4 acc[HALVES];
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* xr = xs + r16 * xstride + g * 8;
-  for (int s = 0; s < padded; s += SK_DEPTH) {
+  // bf16: fragment lane (r16, g) holds k = 8 g .. 8 g + 7 of the step; e4m3: its 16 bytes are k = 16 g .. 16 g + 15, consumed
+  // as two MFMAs (first / second eight) against the x chunks at the same k
+  const bf16_t* xr = xs + r16 * xstride + g * (W8 ? 16 : 8);
+  for (int s = 0; s < padded; s += DEPTH) {
 #pragma unroll
-    for (int i = 0; i < SK_DEPTH; ++i) {
+    for (int i = 0; i < DEPTH; ++i) {
       // the reload is issued after the MFMAs that read the slot, so it can land in the same registers (a reload ahead of
       // them makes the compiler rotate the ring with copies at the loop end, behind vmcnt(0))
       u32x4 wq;
 #pragma unroll
       for (int j = 0; j < 4; ++j) wq[j] = (unsigned)__builtin_amdgcn_ds_bpermute(perm, (int)ring[i][j]);
-      const bf16x8 wf = __builtin_bit_cast(bf16x8, wq);
+      if constexpr (W8) {
+        const bf16x8 wa = e4m3x8_to_bf16(wq[0], wq[1]), wb = e4m3x8_to_bf16(wq[2], wq[3]);
 #pragma unroll
-      for (int h = 0; h < HALVES; ++h) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + h * 16 * xstride + (s + i) * 32);
-        acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf, acc[h], 0, 0, 0);
+        for (int h = 0; h < HALVES; ++h) {
+          const bf16_t* xp = xr + h * 16 * xstride + (s + i) * KPS;
+          const bf16x8 xa = *reinterpret_cast<const bf16x8*>(xp), xb = *reinterpret_cast<const bf16x8*>(xp + 8);
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, wa, acc[h], 0, 0, 0);
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xb, wb, acc[h], 0, 0, 0);
+        }
+      } else {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, wq);
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + h * 16 * xstride + (s + i) * KPS);
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, wf, acc[h], 0, 0, 0);
+        }
       }
-      ring[i] = *reinterpret_cast<const u32x4*>(wp + min(s + i + SK_DEPTH, nsteps - 1) * 32);
+      ring[i] = *reinterpret_cast<const u32x4*>(wp + min(s + i + DEPTH, nsteps - 1) * 64);
       __builtin_amdgcn_sched_barrier(0);     // keep the reload here: sunk to the loop end, the ring runs dry
     }
   }
@@ -115,66 +142,83 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
 
 using namespace hvlm;
 
-// Steps of 32 k per K slice for (N, K): 8, 16, 24 or 32 (the x slice of a workgroup lives in LDS: at most 32 x 1024 bf16).
-// The kernel is a stream with one workgroup-sized quantum, so the choice is a balance question: with `cols` workgroup
-// columns and s slices there are cols * s workgroups dealt over 256 CUs, the busiest CU streams ceil(cols * s / 256)
-// of them, and each costs its `per` steps plus about four steps' worth of bytes for its fp32 partial tile (written here,
-// read by the finalize pass).  Measured on MI355X (profiles/r02v_skinny_gemm.txt): down-projection 11 slices of 32 steps =
-// 352 workgroups 29.0 us, 15 slices of 24 = 480 workgroups 23.2 us; o-projection 8 x 16 steps 9.7 us, 16 x 8 12.8 us.
-// HVLM_SKINNY_PER forces a value (development).
-static int skinny_steps_per_split(int N, int K) {
+// Steps per K slice: q, 2q, 3q or 4q (q = 8 steps of 32 k for bf16 weights, 4 steps of 64 k for e4m3: slices of 256 .. 1024 k;
+// the x slice of a workgroup lives in LDS).  The kernel is a stream with one workgroup-sized quantum, so the choice is a
+// balance question: with `cols` workgroup columns and s slices there are cols * s workgroups dealt over the CUs, the busiest
+// CU streams ceil(cols * s / CUs) of them, and each costs its steps (8 KB of W per workgroup and step in both formats) plus
+// about four steps' worth of bytes for its fp32 partial tile (written here, read by the finalize pass).  Measured on MI355X
+// (profiles/r02v_skinny_gemm.txt): down-projection 11 slices of 32 steps = 352 workgroups 29.0 us, 15 slices of 24 = 480
+// workgroups 23.2 us; o-projection 8 x 16 steps 9.7 us, 16 x 8 12.8 us.  HVLM_SKINNY_PER forces a multiple of q (development).
+static int skinny_steps_per_split(int N, int steps, int q) {
   static int forced = -1, cus = 0;
   if (forced < 0) { const char* e = getenv("HVLM_SKINNY_PER"); forced = e ? atoi(e) : 0; }
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
   }
-  if (forced == 8 || forced == 16 || forced == 24 || forced == 32) return forced;
-  const int cols = cdiv(N, SK_WAVES * 16), steps = K / 32;
-  int best = 8; long best_cost = -1;
-  for (int per = 32; per >= 8; per -= 8) {
+  if (forced >= 1 && forced <= 4) return forced * q;
+  const int cols = cdiv(N, SK_WAVES * 16);
+  int best = q; long best_cost = -1;
+  for (int per = 4 * q; per >= q; per -= q) {
     const long wgs = (long)cols * cdiv(steps, per);
-    const long cost = cdiv(wgs, cus) * (per + 4);
+    const long cost = cdiv(wgs, cus) * (per * (8 / q) + 4);      // in bf16 steps: an e4m3 step of 64 k costs the same 8 KB
     if (best_cost < 0 || cost < best_cost) { best = per; best_cost = cost; }
   }
   return best;
 }
-extern "C" int hvlm_gemm_skinny_splits(int N, int K) { return cdiv(K / 32, skinny_steps_per_split(N, K)); }
-
+extern "C" int hvlm_gemm_skinny_splits(int N, int K) { return cdiv(K / 32, skinny_steps_per_split(N, K / 32, 8)); }
 extern "C" size_t hvlm_gemm_skinny_ws_bytes(int M, int N, int K) { return (size_t)hvlm_gemm_skinny_splits(N, K) * M * N * 4; }
+extern "C" int hvlm_gemm_w8a16_skinny_splits(int N, int K) { return cdiv(K / 64, skinny_steps_per_split(N, K / 64, 4)); }
+extern "C" size_t hvlm_gemm_w8a16_skinny_ws_bytes(int M, int N, int K) {
+  return (size_t)hvlm_gemm_w8a16_skinny_splits(N, K) * M * N * 4;
+}
 
-extern "C" int hvlm_gemm_bf16_nt_skinny(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                                        const void* bias, const void* residual, int ldr, int act, void* ws, void* stream) {
+template <bool W8>
+static int skinny_impl(const void* A, const void* B, const float* col_scale, void* C, int M, int N, int K, int lda, int ldb,
+                       int ldc, const void* bias, const void* residual, int ldr, int act, void* ws, void* stream) {
+  constexpr int KPS = W8 ? 64 : 32, Q = W8 ? 4 : 8, DEPTH = W8 ? SK_DEPTH / 2 : SK_DEPTH;
   HVLM_REQUIRE(A && B && C && ws, "gemm_skinny: null pointer");
   HVLM_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0, "gemm_skinny: M must be 1 .. 32 (got %d)", M);
-  HVLM_REQUIRE(K % 32 == 0, "gemm_skinny: K=%d must be a multiple of 32", K);
-  HVLM_REQUIRE(N % 4 == 0 && lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
-               "gemm_skinny: bad leading dimensions (N %% 4)");
+  HVLM_REQUIRE(K % KPS == 0, "gemm_skinny: K=%d must be a multiple of %d", K, KPS);
+  HVLM_REQUIRE(N % 4 == 0 && lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % (W8 ? 16 : 8) == 0 && ldc % 4 == 0,
+               "gemm_skinny: bad leading dimensions (N %% 4; rows of A and W 16-byte aligned)");
   HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 7) == 0 && ((uintptr_t)ws & 15) == 0,
                "gemm_skinny: alignment");
   HVLM_REQUIRE(!residual || ldr >= N, "gemm_skinny: bad residual");
   HVLM_REQUIRE(act == HVLM_ACT_NONE || act == HVLM_ACT_QUICK_GELU, "gemm_skinny: unknown act %d", act);
-  const int per = skinny_steps_per_split(N, K), splits = cdiv(K / 32, per);
-  const int padded = cdiv(per, SK_DEPTH) * SK_DEPTH;
+  const int per = skinny_steps_per_split(N, K / KPS, Q), splits = cdiv(K / KPS, per);
+  const int padded = cdiv(per, DEPTH) * DEPTH;
   const int halves = M <= 16 ? 1 : 2;
-  const size_t lds = (size_t)halves * 16 * (padded * 32 + SK_PAD) * 2;
+  const size_t lds = (size_t)halves * 16 * (padded * KPS + SK_PAD) * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    const int cap = 2 * 16 * (32 * 32 + SK_PAD) * 2;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    const int cap = 2 * 16 * (1024 + SK_PAD) * 2;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<1, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_skinny_kernel<2, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
     if (e != hipSuccess) { set_error("gemm_skinny: hipFuncSetAttribute: %s", hipGetErrorString(e)); return HVLM_ERR_LAUNCH; }
     attr_done = true;
   }
   const dim3 grid(cdiv(N, SK_WAVES * 16), splits), block(SK_WAVES * 64);
   if (halves == 1)
-    hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, lds, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B,
+    hipLaunchKernelGGL((gemm_skinny_kernel<1, W8>), grid, block, lds, as_stream(stream), (const bf16_t*)A, (const char*)B,
                        (float*)ws, M, N, K, lda, ldb, per, (size_t)M * N);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, lds, as_stream(stream), (const bf16_t*)A, (const bf16_t*)B,
+    hipLaunchKernelGGL((gemm_skinny_kernel<2, W8>), grid, block, lds, as_stream(stream), (const bf16_t*)A, (const char*)B,
                        (float*)ws, M, N, K, lda, ldb, per, (size_t)M * N);
-  const int rc = check_launch("gemm_skinny");
+  const int rc = check_launch(W8 ? "gemm_w8a16_skinny" : "gemm_skinny");
   if (rc) return rc;
-  return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, act,
-                                (bf16_t*)C, ldc, M, N, as_stream(stream));
+  return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, col_scale, (const bf16_t*)bias, (const bf16_t*)residual,
+                                ldr, act, (bf16_t*)C, ldc, M, N, as_stream(stream));
+}
+
+extern "C" int hvlm_gemm_bf16_nt_skinny(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                        const void* bias, const void* residual, int ldr, int act, void* ws, void* stream) {
+  return skinny_impl<false>(A, B, nullptr, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, act, ws, stream);
+}
+
+extern "C" int hvlm_gemm_w8a16_nt_skinny(const void* A, const void* B8, const float* col_scale, void* C, int M, int N, int K,
+                                         int lda, int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
+                                         void* ws, void* stream) {
+  HVLM_REQUIRE(col_scale, "gemm_w8a16_skinny: null col_scale");
+  return skinny_impl<true>(A, B8, col_scale, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, act, ws, stream);
 }

@@ -159,6 +159,7 @@ class LlamaStack:
             if kept is None or kept[0].shape[0] != batch or kept[0].shape[1] < n:
                 kept = None
                 self._kv_cache_b = None                     # free the old one before allocating (22 GB at B = 32)
+                self.__dict__.pop("_dec_graphs_b", None)    # (and the decode graph captured on it)
                 kept = [torch.empty((batch, n, 3 * self.D), dtype=BF16, device=self.device) for _ in range(self.L)]
                 self._kv_cache_b = kept
             return kept
@@ -317,17 +318,60 @@ class LlamaStack:
         """e4m3 copies of the four GEMM weights of every layer, one scale per OUTPUT CHANNEL (row of W); activations are
         quantised per TOKEN at run time (ops.quantize_fp8_rowwise), so nothing has to be calibrated."""
         with torch.no_grad():
+            self.__dict__.pop("_dec_graphs_b", None)        # a captured decode step points at the old copies
             self._fp8_rw = [{k: ops.quantize_fp8_rowwise(lp.w[k]) for k in ("qkv", "o", "gu", "down")} for lp in self.layers]
 
     def _mm_fp8(self, li: int, key: str, a: torch.Tensor, residual=None) -> torch.Tensor:
         w8, inv_w = self._fp8_rw[li][key]
+        if a.shape[0] <= 32 and a.shape[1] % 64 == 0 and w8.shape[0] % 4 == 0 and ops._GEMM_SKINNY:
+            # decode steps (M = batch): weight-only e4m3 on the weight-streaming kernel — the cost is reading W once, the
+            # activations stay bf16 (no per-token quantisation pass, no activation rounding)
+            return ops.gemm_w8a16_nt(a, w8, inv_w, residual=residual)
         a8, inv_a = ops.quantize_fp8_rowwise(a)
         return ops.gemm_fp8_nt_scaled(a8, w8, inv_a, inv_w, residual=residual)
 
     def decode_step_batched(self, x1: torch.Tensor, lens: torch.Tensor, cache: List[torch.Tensor], fp8: bool = False) -> torch.Tensor:
         """One new token for each of B samples in lock step: x1 [B, D], lens int32 [B] (device) = position of the new token
-        of every sample = its current cache length; cache[l] [B, max_len, 3D].  Returns the final-normed hidden [B, D].
-        Weights are streamed once per step for all B samples (GEMMs at M = B) instead of once per sample."""
+        of every sample = its current cache length; cache[l] [B, max_len, 3D].  Returns the final-normed hidden [B, D]
+        (valid until the next call).  Weights are streamed once per step for all B samples (GEMMs at M = B).
+
+        The step is ~450 short launches (5 - 80 us each) and the generation loop needs its result on the host before it can
+        issue the next one, so issuing them from Python is what bounds it once the kernels are fast (7.4 ms issued eagerly
+        against 5 - 6 ms of kernels): the launch sequence is captured ONCE per (batch, cache, weight format) in a hipGraph —
+        positions and lengths are device tensors, nothing in it depends on the token index — and replayed per token.
+        HVLM_DECODE_BATCH_GRAPH=0 issues it eagerly (bit-identical, tests/test_gpu_fp8.py)."""
+        if os.environ.get("HVLM_DECODE_BATCH_GRAPH", "1") != "1" or not x1.is_cuda:
+            return self._decode_step_batched_eager(x1, lens, cache, fp8)
+        wkey = self._fp8_rw[0]["qkv"][0].data_ptr() if fp8 else self.layers[0].w["qkv"].data_ptr()
+        key = (x1.shape[0], bool(fp8), cache[0].data_ptr(), cache[0].shape[1], wkey)       # the graph holds raw pointers
+        graphs = self.__dict__.setdefault("_dec_graphs_b", {})
+        st = graphs.get(key)
+        if st is None:
+            graphs.clear()                              # one live graph (its private pool holds the step's activations)
+            sx, sl = x1.clone(), lens.clone()
+            hook = ops._gemm_hook
+            ops.set_gemm_hook(None)                     # no event records inside the capture
+            try:
+                cur = torch.cuda.current_stream(x1.device)
+                side = torch.cuda.Stream(device=x1.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):           # warm-up outside the capture: lazy one-time initialisation in the library
+                    self._decode_step_batched_eager(sx, sl, cache, fp8)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._decode_step_batched_eager(sx, sl, cache, fp8)
+            finally:
+                ops.set_gemm_hook(hook)
+            st = (g, sx, sl, out)
+            graphs[key] = st
+        g, sx, sl, out = st
+        sx.copy_(x1)
+        sl.copy_(lens)
+        g.replay()
+        return out
+
+    def _decode_step_batched_eager(self, x1: torch.Tensor, lens: torch.Tensor, cache: List[torch.Tensor], fp8: bool = False) -> torch.Tensor:
         B = x1.shape[0]
         eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
         rows = torch.arange(B, device=self.device)

@@ -244,6 +244,36 @@ def gemm_fp8_nt_scaled(a8, b8, row_scale, col_scale, alpha: float = 1.0, bias=No
     return out
 
 
+def gemm_w8a16_nt(a: torch.Tensor, b8: torch.Tensor, col_scale: torch.Tensor, bias=None, residual=None, act: int = ACT_NONE,
+                  out=None) -> torch.Tensor:
+    """out[M,N] = act(col_scale[n] * a[M,K] @ e4m3(b8)[N,K]^T + bias) + residual for M <= 32: bf16 activations against e4m3
+    weights (hvlm_quantize_fp8_rowwise of W) on the weight-streaming kernel — half the HBM bytes of gemm_nt, no
+    activation quantisation."""
+    _chk(a, BF16, "gemm_w8a16.a")
+    assert b8.dtype == torch.uint8 and b8.is_cuda and a.dim() == 2 and b8.dim() == 2 and a.shape[1] == b8.shape[1]
+    assert a.stride(1) == 1 and b8.stride(1) == 1 and col_scale.dtype == torch.float32 and col_scale.numel() == b8.shape[0]
+    M, K = a.shape
+    N = b8.shape[0]
+    assert M <= 32 and K % 64 == 0 and N % 4 == 0, (M, N, K)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    ldr = 0
+    if residual is not None:
+        _chk(residual, BF16, "gemm_w8a16.residual")
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        ldr = residual.stride(0)
+    lib = _lib.load()
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    ws = torch.empty((lib.hvlm_gemm_w8a16_skinny_ws_bytes(M, N, K),), dtype=torch.uint8, device=a.device)
+    check(lib.hvlm_gemm_w8a16_nt_skinny(_p(a), _p(b8), _p(col_scale), _p(out), M, N, K, a.stride(0), b8.stride(0), out.stride(0),
+                                        _p(bias), _p(residual), ldr, act, _p(ws), _stream()), "gemm_w8a16_skinny")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
 def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
     _chk(x, BF16, "transpose.x")

@@ -81,6 +81,17 @@ int hvlm_gemm_bf16_nt_skinny(const void* A, const void* B, void* C, int M, int N
                              int ldc, const void* bias, const void* residual, int ldr, int act, void* ws,
                              void* stream);
 
+/* The same kernel on e4m3 WEIGHTS with bf16 activations (weight-only quantisation for the decode steps of the fp8 evaluation,
+ * BASELINE config 5): B8 is [N, K] e4m3 bytes (hvlm_quantize_fp8_rowwise of W), col_scale[n] its per-output-channel inverse
+ * scale (W[n, :] ~= col_scale[n] * e4m3[n, :]); the bytes are converted to bf16 in registers (exact), the MFMA and x are
+ * bf16, col_scale is applied by the finalize pass before bias / activation / residual.  Half the HBM bytes of the bf16
+ * kernel, no activation quantisation pass.  K % 64 == 0, ldb % 16 == 0. */
+int hvlm_gemm_w8a16_skinny_splits(int N, int K);
+size_t hvlm_gemm_w8a16_skinny_ws_bytes(int M, int N, int K);
+int hvlm_gemm_w8a16_nt_skinny(const void* A, const void* B8, const float* col_scale, void* C, int M, int N, int K,
+                              int lda, int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
+                              void* ws, void* stream);
+
 /* fp8 (OCP e4m3) operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, block scales fixed to 1):
  *   C[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual, A / B one byte per element, K % 128 == 0,
  *   lda / ldb % 16 == 0; alpha = 1 / (scale_a * scale_b) for per-tensor scaled operands (BASELINE config 5: fp8 forward).

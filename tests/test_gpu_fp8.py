@@ -121,6 +121,36 @@ def test_attn_decode_batched_vs_oracle(ops, B, H, dh, maxS, lens):
         assert rel(out[b], ref) < 4e-3, b
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_decode_step_batched_graph_replay_is_bit_identical(fp8, monkeypatch):
+    """The lock-step decode step replayed from its hipGraph == the same launches issued eagerly, for several tokens in a row
+    (positions advance on the device; the cache rows written by one step are read by the next)."""
+    from test_gpu_model import tiny_model
+    m, cfg = tiny_model(training=False)
+    st = m.stack
+    if fp8:
+        st.fp8_prepare_rowwise()
+    B, S0 = 3, 9
+    g = torch.Generator(device="cuda").manual_seed(5)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HVLM_DECODE_BATCH_GRAPH", mode)
+        gg = torch.Generator(device="cuda").manual_seed(5)
+        cache = [torch.randn(B, 32, 3 * st.D, device="cuda", generator=gg).to(BF) * 0.3 for _ in range(st.L)]
+        lens = torch.tensor([S0, S0 - 4, S0 - 1], dtype=torch.int32, device="cuda")
+        hs = []
+        for step in range(4):
+            x1 = (torch.randn(B, st.D, device="cuda", generator=gg) * 0.5).to(BF)
+            hs.append(st.decode_step_batched(x1, lens, cache, fp8=fp8).clone())
+            lens = lens + 1
+        outs[mode] = (hs, [c.clone() for c in cache])
+    for a, b in zip(outs["1"][0], outs["0"][0]):
+        assert torch.equal(a, b)
+    D = st.D
+    for a, b in zip(outs["1"][1], outs["0"][1]):
+        assert torch.equal(a[:, :, D:], b[:, :, D:])
+
+
 def _tiny_eval_model():
     from test_gpu_model import tiny_model
     m, cfg = tiny_model(training=False)

@@ -410,6 +410,29 @@ def test_gemm_skinny_vs_oracle(ops, M, N, K, epi):
     assert (c1.float() - c3.float()).abs().max() <= 2.0 ** -6 * exact.abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(32, 4096, 4096, True), (32, 4096, 11008, True), (32, 12288, 4096, False),
+                                       (9, 22016, 4096, False), (16, 1000, 576, True), (32, 260, 2112, True)])
+def test_gemm_w8a16_skinny_vs_dequantised_weights(ops, M, N, K, epi):
+    """e4m3 weights x bf16 activations on the weight-streaming kernel == the bf16 GEMM on the DEQUANTISED weights
+    (col_scale[n] * e4m3[n, k], exact in fp32) to one output rounding: the e4m3 -> bf16 conversion in registers is exact and the
+    scale is applied to the fp32 sum.  Ragged last K slices (11008, 576, 2112), ragged N, both x halves."""
+    a, w = rnd(M, K, seed=70), rnd(N, K, seed=71, scale=0.05)
+    bias = None
+    res = rnd(M, N, seed=73) if epi else None
+    w8, inv = ops.quantize_fp8_rowwise(w.cuda())
+    wdq = _e4m3_decode(w8.cpu()).double() * inv.cpu().double()[:, None]
+    exact = a.double() @ wdq.t()
+    if epi:
+        exact = exact + res.double()
+    ops.set_gemm_hook(None)
+    c1 = ops.gemm_w8a16_nt(a.cuda(), w8, inv, residual=None if res is None else res.cuda())
+    c2 = ops.gemm_w8a16_nt(a.cuda(), w8, inv, residual=None if res is None else res.cuda())
+    assert torch.equal(c1, c2)
+    assert (c1.double().cpu() - exact).abs().max() <= 2.0 ** -7 * exact.abs().max()      # one bf16 rounding per element
+    err = (c1.double().cpu() - exact).norm() / exact.norm()
+    assert err < 3e-3, float(err)
+
+
 def _e4m3_decode(u8: torch.Tensor) -> torch.Tensor:
     """OCP e4m3fn bytes -> fp32 (bias 7, no infinities, S.1111.111 = NaN); written out so the test does not depend on
     torch's float8 support."""

@@ -22,7 +22,7 @@ def T(fn, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, r
 tb, hb = T(lambda: st.decode_step_batched(x1, lens, cache, fp8=False))
 tf, hf = T(lambda: st.decode_step_batched(x1, lens, cache, fp8=True))
-print(f"decode step B={B} S={S}: bf16 weights {tb:.2f} ms   e4m3 weights {tf:.2f} ms")
+print(f"decode step B={B} S={S}: bf16 weights {tb:.2f} ms   e4m3 weights (x bf16 activations) {tf:.2f} ms")
 # measured on MI355X: 9.4 / 11.9 ms, and the same under a hipGraph replay of the whole step (the step is GPU-bound, not
 # launch-bound): attn_decode_batched 119 us per layer (461 MB of K / V rows: 3.9 TB/s), four split-K GEMMs at M = 32 134 us per
 # layer (405 MB of weights: 3.0 TB/s) — a skinny-M streaming GEMM is the lever, not the launch path

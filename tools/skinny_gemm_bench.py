@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The four projections of one decode step at batch 32 (M = 32, 7B dimensions) and the lm_head: the weight-streaming kernel
 (hvlm_gemm_bf16_nt_skinny) against the 256 x 256 split-K path, in TB/s of W streamed.  Each shape cycles over 8 distinct
-weight matrices so that nothing is served from L2 / Infinity Cache.  HVLM_SKINNY_PER forces the K-slice length (8 / 16 / 24 / 32 steps of 32 k)."""
+weight matrices so that nothing is served from L2 / Infinity Cache.  HVLM_SKINNY_PER = 1 .. 4 forces the K-slice length (x 256 k)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
