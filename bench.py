@@ -405,8 +405,10 @@ def fp8_eval_main(args, real_stdout):
     sample (handsonvlm_inference.py:99-113) — CLIP on the 100 frames of every sample (8 distinct frames tiled), projector,
     splice, decoder prefill of the 512-token prompt, then 12 generated tokens of which 4 are <hand_traj> (each decoded by the
     CVAE head and fed back) — but B samples in lock step (model.sample_batch) with the QKV / O / gate|up / down GEMMs of the
-    prefill on e4m3 operands (per-token activation scales, per-output-channel weight scales) and everything else in bf16.
-    Reported beside it: the same batch in bf16, and both with exact frame de-duplication."""
+    prefill and the q|k|v / out_proj / fc1 / fc2 GEMMs of the CLIP tower on e4m3 operands (per-token activation scales,
+    per-output-channel weight scales), the decode-step GEMMs on e4m3 weights x bf16 activations, everything else in bf16.
+    Reported beside it: the same run with the CLIP tower in fp16, the same batch in bf16, and both with exact frame
+    de-duplication."""
     from hvlm import ops
     from hvlm.model import HandsOnVLMForCausalLM
     from hvlm.synthetic import make_text_batch_np
@@ -430,15 +432,17 @@ def fp8_eval_main(args, real_stdout):
     ev = GemmEvents()
     ops.set_gemm_hook(ev)
 
-    def run(fp8, dedup, steps, warmup):
+    def run(fp8, dedup, steps, warmup, fp8_clip=None):
         model.config.dedup_frames = dedup
+        fp8_clip = fp8 if fp8_clip is None else fp8_clip
+        kw = dict(logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8, fp8_decode=fp8, fp8_clip=fp8_clip)
         for _ in range(warmup):
-            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8, fp8_decode=fp8)
+            out = model.sample_batch(ids, **kw)
         torch.cuda.synchronize()
         ev.pairs, ev.kernels, ev.enabled = [], 0, True
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = model.sample_batch(ids, logits_processor=[force], max_length=T + len(forced), eos_token_id=2, image=img, fp8=fp8, fp8_decode=fp8)
+            out = model.sample_batch(ids, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         ev.enabled = False
@@ -451,7 +455,8 @@ def fp8_eval_main(args, real_stdout):
         return dt, (fl / (ms * 1e-3) / 1e12 if ms > 0 else None), (ms / max(1, len(pre)) * 1e3), fl / max(1, len(pre)) / 1e9, len(pre) // steps
 
     steps, warm = max(1, args.steps), max(1, args.warmup)
-    dt8, tf8, us8, gf8, n8 = run(True, False, steps, warm)
+    dt8, tf8, us8, gf8, n8 = run(True, False, steps, warm + 1)      # first leg of a fresh process: one more warm-up batch
+    dt8c16, _, _, _, _ = run(True, False, steps, warm, fp8_clip=False)
     dt16, tf16, _, _, _ = run(False, False, steps, warm)
     dt8d, _, _, _, _ = run(True, True, steps, warm)
     dt16d, _, _, _, _ = run(False, True, steps, warm)
@@ -459,11 +464,13 @@ def fp8_eval_main(args, real_stdout):
     flops = B * (model.stack.flops_forward(1, S, 0) + cfg.num_frames * model.tower.flops_per_frame())
     res = {"metric": "eval samples/sec HandsOnVLM-7B fp8 forward (batch evaluation)", "value": B / dt8, "unit": "samples/s", "n_gpus": 1,
            "steps": steps, "warmup": warm, "ms_per_step": dt8 * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "fp8 e4m3 (decoder prefill GEMMs) + bf16", "data": "synthetic",
+           "dtype": "fp8 e4m3 (CLIP layer GEMMs and decoder prefill GEMMs W8A8, decode-step GEMMs W8A16) + bf16", "data": "synthetic",
            "config": {"workload": f"eval_batch{B}_T{T}_S{S}_8frames_tiled_to_{cfg.num_frames}_12new_tokens_4hands_fp8", "global_batch": B,
                       "seq_len": S, "parallelism": "dp1", "frames_through_clip_per_sample": cfg.num_frames,
                       "weight_scales": "per output channel", "activation_scales": "per token (dynamic)"},
            "prefill_plus_clip_tflop_algorithmic": flops / 1e12,
+           "fp16_clip_tower": {"samples_per_s": B / dt8c16, "ms_per_batch": dt8c16 * 1e3,
+                               "note": "same run with the CLIP tower in the reference's fp16 (decoder GEMMs still e4m3)"},
            "bf16_same_batch": {"samples_per_s": B / dt16, "ms_per_batch": dt16 * 1e3, "decoder_gemm_tflops": tf16},
            "dedup_clip": {"fp8_samples_per_s": B / dt8d, "bf16_samples_per_s": B / dt16d,
                           "note": "CLIP once per distinct frame (8 of 100 per sample), bit-identical visual tokens"},

@@ -199,12 +199,15 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
   }
 }
 
-template <int TPR, bool F16>
+// Q8: the output row is written as e4m3 with one scale per row (the input of an fp8 GEMM: BASELINE config 5's CLIP tower),
+// bit-identical to quantize_fp8_rowwise of the 16-bit output — the row is already in registers, so the separate pass (a
+// read of the 16-bit row and a second launch) disappears and the write is one byte per element.
+template <int TPR, bool F16, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                             const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ b,
                                                             bf16_t* __restrict__ y, int rows, int D,
-                                                            float eps) {
+                                                            float eps, float* __restrict__ inv_scale = nullptr) {
   __shared__ float red[4];
   constexpr int RPB = 256 / TPR;
   const int t = threadIdx.x % TPR;
@@ -238,22 +241,64 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
   ss = row_sum<TPR>(ss, red);
   const float rstd = rsqrtf(ss / (float)D + eps);
-  if (!active) return;
-  bf16_t* yr = y + (size_t)row * D;
+  if constexpr (!Q8) {
+    if (!active) return;
+    bf16_t* yr = y + (size_t)row * D;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int i = (c * TPR + t) * 8;
-    if (i < D) {
-      const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
-      const u32x4 bv = *reinterpret_cast<const u32x4*>(b + i);
-      u32x4 o;
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * TPR + t) * 8;
+      if (i < D) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(b + i);
+        u32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float r0 = (v[c][2 * e] - mean) * rstd * E16<F16>::lo(wv[e]) + E16<F16>::lo(bv[e]);
-        const float r1 = (v[c][2 * e + 1] - mean) * rstd * E16<F16>::hi(wv[e]) + E16<F16>::hi(bv[e]);
-        o[e] = E16<F16>::pack2(r0, r1);
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = (v[c][2 * e] - mean) * rstd * E16<F16>::lo(wv[e]) + E16<F16>::lo(bv[e]);
+          const float r1 = (v[c][2 * e + 1] - mean) * rstd * E16<F16>::hi(wv[e]) + E16<F16>::hi(bv[e]);
+          o[e] = E16<F16>::pack2(r0, r1);
+        }
+        *reinterpret_cast<u32x4*>(yr + i) = o;
       }
-      *reinterpret_cast<u32x4*>(yr + i) = o;
+    }
+  } else {
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * TPR + t) * 8;
+      if (i < D) {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>(w + i);
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(b + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r0 = (v[c][2 * e] - mean) * rstd * E16<F16>::lo(wv[e]) + E16<F16>::lo(bv[e]);
+          const float r1 = (v[c][2 * e + 1] - mean) * rstd * E16<F16>::hi(wv[e]) + E16<F16>::hi(bv[e]);
+          const unsigned pk = E16<F16>::pack2(r0, r1);                    // the 16-bit output the two-pass path would store
+          v[c][2 * e] = E16<F16>::lo(pk); v[c][2 * e + 1] = E16<F16>::hi(pk);
+          mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));
+        }
+      }
+    }
+    if constexpr (TPR == 64) mx = wave_max(mx); else mx = block_max<TPR / 64>(mx, red);
+    if (!active) return;
+    const float amax = fmaxf(mx, 1e-12f);
+    const float sc = 448.f / amax;
+    if (t == 0) inv_scale[row] = amax / 448.f;
+    unsigned char* yr = reinterpret_cast<unsigned char*>(y) + (size_t)row * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = (c * TPR + t) * 8;
+      if (i < D) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(v[c][e] * sc, -448.f), 448.f);
+        unsigned lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        const u32x2 o = {lo, hi};
+        *reinterpret_cast<u32x2*>(yr + i) = o;
+      }
     }
   }
 }
@@ -316,6 +361,19 @@ static int layernorm_impl(const void* x, const void* w, const void* b, void* y, 
 extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps,
                                   void* stream) {
   return layernorm_impl(x, w, b, y, rows, D, eps, false, stream);
+}
+
+extern "C" int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, int rows, int D,
+                                      float eps, void* stream) {
+  HVLM_REQUIRE(x && w && b && out8 && inv_scale, "layernorm_fwd_fp8: null pointer");
+  HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "layernorm_fwd_fp8: bad D=%d", D);
+  if (D <= 2048)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<64, false, true>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale);
+  else
+    hipLaunchKernelGGL((layernorm_fwd_kernel<256, false, true>), dim3(rows), dim3(256), 0, as_stream(stream),
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale);
+  return check_launch("layernorm_fwd_fp8");
 }
 
 extern "C" int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps,

@@ -111,11 +111,30 @@ class CLIPVisionTower:
         self.is_loaded = True
         return self
 
+    # -- fp8 forward (BASELINE config 5) ----------------------------------------------------------
+    @torch.no_grad()
+    def fp8_prepare(self) -> None:
+        """e4m3 copies of the four GEMM weights of every layer (one scale per output channel) and bf16 copies of everything
+        else (LayerNorm / bias / embedding parameters, the patch-embedding weight): the fp8 forward keeps its activations in
+        bf16 between the GEMMs and quantises each GEMM input per token at run time, like the decoder's fp8 prefill."""
+        q = {}
+        for k, v in self.p.items():
+            if k.endswith(("qkv_w", "o_w", "fc1_w", "fc2_w")):
+                q[k] = ops.quantize_fp8_rowwise(v.to(BF16).contiguous())
+            else:
+                q[k] = v.to(BF16).contiguous()
+        self._p8 = q
+
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
         """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d] (bf16).  `out`: an
-        optional [N, NP+1, d] bf16 destination (a slice of the caller's buffer: no concatenation of chunks afterwards)."""
+        optional [N, NP+1, d] bf16 destination (a slice of the caller's buffer: no concatenation of chunks afterwards).
+        `fp8`: the q|k|v / out_proj / fc1 / fc2 GEMMs of every layer on e4m3 operands (CDNA4 scaled MFMA, fp32 accumulation,
+        per-token activation and per-channel weight scales); LayerNorm, attention, the residual stream, biases and QuickGELU
+        stay bf16, the patch embedding stays a bf16 GEMM (K = 588)."""
+        if fp8:
+            return self._forward_tokens_fp8(images, out)
         cfg, p = self.cfg, self.p
         assert self.is_loaded
         N = images.shape[0]
@@ -154,6 +173,47 @@ class CLIPVisionTower:
         if f16:
             x = ops.cast16(x, BF16, out=None if out is None else out.view(N * T, d))   # image_features.to(images.dtype), clip_encoder.py:48
         elif out is not None:
+            out.view(N * T, d).copy_(x)
+            x = out
+        return x.view(N, T, d)
+
+    def _forward_tokens_fp8(self, images: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+        cfg = self.cfg
+        assert self.is_loaded
+        if getattr(self, "_p8", None) is None:
+            self.fp8_prepare()
+        p = self._p8
+        N = images.shape[0]
+        d, heads = cfg.hidden_size, cfg.num_attention_heads
+        dh = d // heads
+        NP = cfg.num_patches
+        T = NP + 1
+        x_img = images.to(device=self.device, dtype=BF16).contiguous()
+
+        def mm8(a, key, bias=None, residual=None, act=ops.ACT_NONE):
+            w8, inv_w = p[key]
+            a8, inv_a = a if isinstance(a, tuple) else ops.quantize_fp8_rowwise(a)      # LayerNorm hands over e4m3 rows directly
+            return ops.gemm_fp8_nt_scaled(a8, w8, inv_a, inv_w, bias=bias, residual=residual, act=act)
+
+        patches = ops.patch_im2col(x_img, cfg.patch_size, self.kpad)
+        pe = ops.gemm_nt(patches, p["patch_w"])
+        del patches
+        x = ops.clip_embed(pe, p["cls"], p["pos"], N, NP, d).view(N * T, d)
+        del pe
+        x = ops.layernorm_fwd(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
+        scale = dh ** -0.5
+        for i in range(self.n_run):
+            y = ops.layernorm_fwd_fp8(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
+            qkv = mm8(y, f"{i}.qkv_w", bias=p[f"{i}.qkv_b"])
+            a, _ = ops.attn_fwd(qkv, N, T, heads, dh, False, scale, need_lse=False)
+            del qkv, y
+            x = mm8(a, f"{i}.o_w", bias=p[f"{i}.o_b"], residual=x)
+            y = ops.layernorm_fwd_fp8(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps)
+            hmid = mm8(y, f"{i}.fc1_w", bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+            del y
+            x = mm8(hmid, f"{i}.fc2_w", bias=p[f"{i}.fc2_b"], residual=x)
+            del hmid
+        if out is not None:
             out.view(N * T, d).copy_(x)
             x = out
         return x.view(N, T, d)

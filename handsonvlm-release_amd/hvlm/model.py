@@ -191,7 +191,7 @@ class HandsOnVLMForCausalLM:
     # ------------------------------------------------------------------------------------------
     # visual tokens (VisualToTokenHelper.pipeline, 'origin' + 'temporal_spatial_pool')
     # ------------------------------------------------------------------------------------------
-    def visual_tokens(self, image: torch.Tensor, keep_for_backward: bool = False) -> torch.Tensor:
+    def visual_tokens(self, image: torch.Tensor, keep_for_backward: bool = False, fp8: bool = False) -> torch.Tensor:
         cfg = self.config
         B, T = image.shape[:2]
         assert cfg.fuse_input_mode == "origin" and cfg.video_compress_mode == "temporal_spatial_pool", \
@@ -217,7 +217,7 @@ class HandsOnVLMForCausalLM:
         NT = cfg.vision.num_patches + 1
         tok = torch.empty((n, NT, d), dtype=BF16, device=self.device)          # [n, 257, d]: every chunk writes its slice
         for s in range(0, n, cfg.clip_chunk_frames):
-            self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames], out=tok[s:s + cfg.clip_chunk_frames])
+            self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames], out=tok[s:s + cfg.clip_chunk_frames], fp8=fp8)
         if inv is not None:
             tok = tok[inv]
         tok = tok.contiguous()
@@ -636,13 +636,14 @@ class HandsOnVLMForCausalLM:
     @torch.no_grad()
     def sample_batch(self, input_ids, logits_processor=None, max_length=None, eos_token_id=None, pad_token_id=None,
                      attention_mask=None, image=None, hand_noise=None, fp8: bool = False, fp8_decode: bool = False,
-                     output_scores: bool = False):
+                     fp8_clip: bool = False, output_scores: bool = False):
         """Lock-step generation of B samples (BASELINE config 5: batch-32 evaluation).  The reference's sample() is batch 1
         (`.item()` at handsonvlm.py:609) and re-runs CLIP + the whole prefix per token; this is the same per-sample function
         — multinomial sampling, a CVAE hand decoded from the last hidden state whenever token 32100 is drawn, that hand's
         sinusoidal encoding added to the token's embedding when it is fed back (handsonvlm.py:380-396,543-647) — with one
         batched prefill (bf16, or the e4m3 GEMMs with `fp8`) filling a [B, max_len, 3D] KV cache per layer and one batched
-        decode step per generated token (weights streamed once for all B samples).  Right-padded prompts (attention_mask)
+        decode step per generated token (weights streamed once for all B samples; e4m3 weights with `fp8_decode`).
+        `fp8_clip` runs the CLIP tower's layer GEMMs on e4m3 operands as well.  Right-padded prompts (attention_mask)
         are supported: a sample's pad rows are never attended (its own length bounds its keys).
         `logits_processor`: callables (input_ids [B, cur], scores [B, V]) -> scores.  `hand_noise[b][j]`: optional z for the
         j-th hand of sample b.  Returns SampleDecoderOnlyOutput(sequences [B, T_max] padded with pad_token_id,
@@ -653,7 +654,7 @@ class HandsOnVLMForCausalLM:
         pad_token_id = cfg.pad_token_id if pad_token_id is None else pad_token_id
         eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
         eos = [eos] if isinstance(eos, int) else list(eos)
-        vis = self.visual_tokens(image.to(dev))
+        vis = self.visual_tokens(image.to(dev), fp8=fp8_clip)
         NV = vis.shape[1]
         plan = self.build_splice_plan(input_ids, None, NV, 0, True, False, pack=False)
         if attention_mask is not None:          # true prompt lengths (right padding): rows past them are pads

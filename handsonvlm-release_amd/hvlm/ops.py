@@ -335,6 +335,18 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
     return y
 
 
+def layernorm_fwd_fp8(x, w, b, eps: float):
+    """LayerNorm of bf16 rows, written as (e4m3 bytes [rows, D], inv_scale f32 [rows]) == quantize_fp8_rowwise(layernorm_fwd(x))."""
+    _chk(x, BF16, "layernorm_fp8.x")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvlm_layernorm_fwd_fp8(_p(x), _p(w), _p(b), _p(out), _p(inv), rows, D, eps, _stream()), "layernorm_fwd_fp8")
+    return out, inv
+
+
 # ------------------------------------------------------------------------------------------------
 # rope / attention / swiglu
 # ------------------------------------------------------------------------------------------------

@@ -349,6 +349,11 @@ int hvlm_hand_gather_bwd(const void* dout, const int32_t* rows, void* dhidden, i
 int hvlm_gemm_f16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                      const void* bias, const void* residual, int ldr, int act, int out_f32, void* stream);
 int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, void* stream);
+/* LayerNorm (bf16 in, as hvlm_layernorm_fwd) whose output row is written as e4m3 bytes with one scale per row: out8[r, :] and
+ * inv_scale[r] are bit-identical to hvlm_quantize_fp8_rowwise of hvlm_layernorm_fwd's bf16 output — the input of the q|k|v
+ * and fc1 GEMMs of the CLIP tower in the fp8 forward (BASELINE config 5; CLIPEncoderLayer.layer_norm1 / layer_norm2). */
+int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, int rows, int D,
+                           float eps, void* stream);
 int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,
                         void* stream);
 int hvlm_attn_fwd_f16(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh, int ld, int causal,
