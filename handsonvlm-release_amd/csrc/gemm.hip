@@ -305,7 +305,7 @@ extern "C" int hvlm_quantize_fp8_rowwise(const void* x, void* out, float* inv_sc
 
 static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          float alpha, const float* row_scale, const float* col_scale, const void* bias,
-                         const void* residual, int ldr, int act, int out_f32, void* stream);
+                         const void* residual, int ldr, int act, int out_f32, void* stream, const float* out_inv = nullptr);
 
 extern "C" int hvlm_gemm_fp8_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                 float alpha, const void* bias, const void* residual, int ldr, int act, int out_f32,
@@ -319,10 +319,19 @@ extern "C" int hvlm_gemm_fp8_nt_scaled(const void* A, const void* B, void* C, in
   return gemm_fp8_impl(A, B, C, M, N, K, lda, ldb, ldc, alpha, row_scale, col_scale, bias, residual, ldr, act, out_f32, stream);
 }
 
+extern "C" int hvlm_gemm_fp8_nt_scaled_q8(const void* A, const void* B, void* C8, int M, int N, int K, int lda, int ldb, int ldc,
+                                          float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                                          int act, const float* out_inv, void* stream) {
+  HVLM_REQUIRE(out_inv, "gemm_fp8_q8: null out_inv");
+  HVLM_REQUIRE(ldc % 16 == 0, "gemm_fp8_q8: ldc must be a multiple of 16");
+  return gemm_fp8_impl(A, B, C8, M, N, K, lda, ldb, ldc, alpha, row_scale, col_scale, bias, nullptr, 0, act, 0, stream, out_inv);
+}
+
 static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                          float alpha, const float* row_scale, const float* col_scale, const void* bias,
-                         const void* residual, int ldr, int act, int out_f32, void* stream) {
+                         const void* residual, int ldr, int act, int out_f32, void* stream, const float* out_inv) {
   HVLM_REQUIRE(A && B && C, "gemm_fp8: null operand");
+  HVLM_REQUIRE(!out_inv || (!residual && !out_f32), "gemm_fp8: e4m3 output takes no residual and is not fp32");
   HVLM_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K=%d must be a positive multiple of 128", K);
   HVLM_REQUIRE(lda >= K && ldb >= K && ldc >= N && lda % 16 == 0 && ldb % 16 == 0 && ldc % 4 == 0, "gemm_fp8: bad leading dimensions");
   HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_fp8: 16-byte alignment");
@@ -334,7 +343,7 @@ static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, in
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
   p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0; p.dbg = 0;
-  p.row_scale = row_scale; p.col_scale = col_scale;
+  p.row_scale = row_scale; p.col_scale = col_scale; p.out_inv = out_inv;
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;

@@ -18,6 +18,8 @@ struct GemmArgs {
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
   const float* row_scale = nullptr;   // fp8 kernel only, optional: C[m, :] *= row_scale[m]  (per-token activation de-scale)
   const float* col_scale = nullptr;   // fp8 kernel only, optional: C[:, n] *= col_scale[n]  (per-output-channel weight de-scale)
+  const float* out_inv = nullptr;     // fp8 kernel only, optional: C is e4m3 BYTES, C[m, n] = e4m3(clamp(bf16(v) / out_inv[m])) — the
+                                      // next GEMM's A operand with row_scale = out_inv (no residual in this mode)
 };
 
 // gemm_pp.hip: 8-phase ping-pong kernel (persistent 256x256 tiles); grid = workgroups to launch.

@@ -62,6 +62,24 @@ __device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
 }
 
+__device__ __forceinline__ void store8_untracked(void* ptr, u32x2 v) {
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+}
+// eight bf16 (as stored by the epilogue) * s -> eight e4m3 bytes, saturating
+__device__ __forceinline__ u32x2 bf16x8_to_e4m3(u32x4 o, float s) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[2 * e] = bf_lo(o[e]) * s; f[2 * e + 1] = bf_hi(o[e]) * s; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], -448.f), 448.f);
+  unsigned lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return u32x2{lo, hi};
+}
+
 // Dynamic tile scheduling state (GemmArgs::dyn): one tile counter per XCD chunk of the swizzled tile order, a completion
 // counter (the last workgroup to finish resets everything for the next launch) and, per workgroup, a 4-deep ring of
 // fetched tile indices through which wave 0 hands its fetches to the other waves one tile ahead of their use.
@@ -390,6 +408,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             const bf16_t* rp = p.res + (size_t)m * p.ldr + nb;
             for (int e = 0; e < 4; ++e) if (nb + e < p.N) v[e] += EL::to_f(rp[e]);
           }
+          if constexpr (FP8) {
+            if (p.out_inv) {                 // e4m3 output (see GemmArgs::out_inv)
+              const float sq = 1.f / p.out_inv[m];
+              unsigned char* cp = reinterpret_cast<unsigned char*>(p.C) + (size_t)m * p.ldc + nb;
+              const u32x4 ob = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3]), 0u, 0u};
+              const u32x2 o8 = bf16x8_to_e4m3(ob, sq);
+              for (int e = 0; e < 4; ++e) if (nb + e < p.N) cp[e] = (unsigned char)((o8[0] >> (8 * e)) & 0xffu);
+              continue;
+            }
+          }
           if (p.out_f32) {
             float* cp = reinterpret_cast<float*>(p.C) + c_slab + (size_t)m * p.ldc + nb;
             if (full) {
@@ -442,6 +470,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       // buffers: write(f) never targets the buffer read(f-1) may still be reading (issuing a write right behind an
       // unfinished read of the same buffer produced wrong elements), and write(f+2) is ordered after read(f) through
       // the registers store(f) consumed.
+      float osc[4][2];                       // e4m3 output: out_inv of the eight rows this lane stores (fetching them together
+      if constexpr (FP8) {                   // with the row / column scales, ahead of the de-scale block, measured no faster and
+        if (p.out_inv) {                     // doubled the scratch of the kernel)
+#pragma unroll
+          for (int ip = 0; ip < 4; ++ip)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              osc[ip][q] = p.out_inv[min(m0 + (ip >> 1) * 128 + grp * 64 + (ip & 1) * 32 + t_row + 16 * q, p.M - 1)];
+        }
+      }
       u32x4 o_prev[2];
 #pragma unroll
       for (int f = 0; f <= 8; ++f) {
@@ -471,7 +509,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int m = mrow0 + 16 * q;
-            if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + jp * 32, o_prev[q]);
+            bool done8 = false;
+            if constexpr (FP8) {
+              if (p.out_inv) {
+                if (m < p.M)
+                  store8_untracked(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * p.ldc + ncol0 + jp * 32,
+                                   bf16x8_to_e4m3(o_prev[q], __builtin_amdgcn_rcpf(osc[ip][q])));
+                done8 = true;
+              }
+            }
+            if (!done8 && m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + jp * 32, o_prev[q]);
           }
         }
         if (f < 8) {

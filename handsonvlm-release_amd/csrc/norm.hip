@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ w,
                                                             const bf16_t* __restrict__ b,
                                                             bf16_t* __restrict__ y, int rows, int D,
-                                                            float eps, float* __restrict__ inv_scale = nullptr) {
+                                                            float eps, float* __restrict__ inv_scale = nullptr,
+                                                            float* __restrict__ next_inv = nullptr, float bound_mul = 0.f,
+                                                            float bound_add = 0.f) {
   __shared__ float red[4];
   constexpr int RPB = 256 / TPR;
   const int t = threadIdx.x % TPR;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
       }
     }
   } else {
-    float mx = 0.f;
+    float mx = 0.f, sq = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       const int i = (c * TPR + t) * 8;
@@ -275,10 +277,15 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
           const unsigned pk = E16<F16>::pack2(r0, r1);                    // the 16-bit output the two-pass path would store
           v[c][2 * e] = E16<F16>::lo(pk); v[c][2 * e + 1] = E16<F16>::hi(pk);
           mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));
+          sq += v[c][2 * e] * v[c][2 * e] + v[c][2 * e + 1] * v[c][2 * e + 1];
         }
       }
     }
     if constexpr (TPR == 64) mx = wave_max(mx); else mx = block_max<TPR / 64>(mx, red);
+    if (next_inv) {
+      sq = row_sum<TPR>(sq, red);
+      if (active && t == 0) next_inv[row] = (sqrtf(sq) * bound_mul + bound_add) * (1.f / 448.f);
+    }
     if (!active) return;
     const float amax = fmaxf(mx, 1e-12f);
     const float sc = 448.f / amax;
@@ -363,16 +370,18 @@ extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, v
   return layernorm_impl(x, w, b, y, rows, D, eps, false, stream);
 }
 
-extern "C" int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, int rows, int D,
-                                      float eps, void* stream) {
+extern "C" int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
+                                      float bound_mul, float bound_add, int rows, int D, float eps, void* stream) {
   HVLM_REQUIRE(x && w && b && out8 && inv_scale, "layernorm_fwd_fp8: null pointer");
   HVLM_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 256 * 8 * MAXC, "layernorm_fwd_fp8: bad D=%d", D);
   if (D <= 2048)
     hipLaunchKernelGGL((layernorm_fwd_kernel<64, false, true>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale);
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale, next_inv,
+                       bound_mul, bound_add);
   else
     hipLaunchKernelGGL((layernorm_fwd_kernel<256, false, true>), dim3(rows), dim3(256), 0, as_stream(stream),
-                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale);
+                       (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out8, rows, D, eps, inv_scale, next_inv,
+                       bound_mul, bound_add);
   return check_launch("layernorm_fwd_fp8");
 }
 

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -123,6 +125,17 @@ class CLIPVisionTower:
                 q[k] = ops.quantize_fp8_rowwise(v.to(BF16).contiguous())
             else:
                 q[k] = v.to(BF16).contiguous()
+        # fc1 writes its output as e4m3 itself (the input of fc2): the scale of a row has to be known before the row exists,
+        # so it is an upper bound, |QuickGELU(y W^T + b)| <= |y W^T + b| <= |y|_2 max_n |W_n|_2 + max |b| (Cauchy-Schwarz on the
+        # de-quantised operands; 1.0625 covers the e4m3 rounding of y, 1.01 the fp32 arithmetic).  It sits ~3 binades above the
+        # true row maximum, which costs a floating-point format nothing but its smallest subnormals.
+        for i in range(self.n_run):
+            w8, inv_w = q[f"{i}.fc1_w"]
+            try:
+                wn = float((w8.view(torch.float8_e4m3fn).float() * inv_w[:, None]).norm(dim=1).max())
+            except (RuntimeError, TypeError, AttributeError):
+                wn = 1.07 * float(self.p[f"{i}.fc1_w"].float().norm(dim=1).max())
+            q[f"{i}.fc1_bound"] = (1.0625 * 1.01 * wn, 1.01 * float(q[f"{i}.fc1_b"].float().abs().max()) + 1e-12)
         self._p8 = q
 
     # -- forward --------------------------------------------------------------------------------
@@ -202,17 +215,26 @@ class CLIPVisionTower:
         del pe
         x = ops.layernorm_fwd(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
         scale = dh ** -0.5
+        q8_out = os.environ.get("HVLM_CLIP_FP8_Q8OUT", "1") == "1"      # 0: fc1 writes bf16 and a rowwise quantise pass follows (A/B)
         for i in range(self.n_run):
             y = ops.layernorm_fwd_fp8(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
             qkv = mm8(y, f"{i}.qkv_w", bias=p[f"{i}.qkv_b"])
             a, _ = ops.attn_fwd(qkv, N, T, heads, dh, False, scale, need_lse=False)
             del qkv, y
             x = mm8(a, f"{i}.o_w", bias=p[f"{i}.o_b"], residual=x)
-            y = ops.layernorm_fwd_fp8(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps)
-            hmid = mm8(y, f"{i}.fc1_w", bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
-            del y
-            x = mm8(hmid, f"{i}.fc2_w", bias=p[f"{i}.fc2_b"], residual=x)
-            del hmid
+            if q8_out:
+                y8, inv_y, inv_h = ops.layernorm_fwd_fp8(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps, bound=p[f"{i}.fc1_bound"])
+                w8, inv_w = p[f"{i}.fc1_w"]
+                h8 = ops.gemm_fp8_nt_scaled_q8(y8, w8, inv_y, inv_w, inv_h, bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+                del y8
+                x = mm8((h8, inv_h), f"{i}.fc2_w", bias=p[f"{i}.fc2_b"], residual=x)
+                del h8
+            else:
+                y = ops.layernorm_fwd_fp8(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps)
+                hmid = mm8(y, f"{i}.fc1_w", bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+                del y
+                x = mm8(hmid, f"{i}.fc2_w", bias=p[f"{i}.fc2_b"], residual=x)
+                del hmid
         if out is not None:
             out.view(N * T, d).copy_(x)
             x = out

@@ -335,16 +335,39 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
     return y
 
 
-def layernorm_fwd_fp8(x, w, b, eps: float):
-    """LayerNorm of bf16 rows, written as (e4m3 bytes [rows, D], inv_scale f32 [rows]) == quantize_fp8_rowwise(layernorm_fwd(x))."""
+def layernorm_fwd_fp8(x, w, b, eps: float, bound=None):
+    """LayerNorm of bf16 rows, written as (e4m3 bytes [rows, D], inv_scale f32 [rows]) == quantize_fp8_rowwise(layernorm_fwd(x)).
+    bound = (mul, add): also returns next_inv[r] = (|y_r|_2 * mul + add) / 448, the e4m3 output scale of the GEMM that consumes
+    these rows (gemm_fp8_nt_scaled_q8)."""
     _chk(x, BF16, "layernorm_fp8.x")
     assert x.is_contiguous()
     D = x.shape[-1]
     rows = x.numel() // D
     out = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
     inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    check(_lib.load().hvlm_layernorm_fwd_fp8(_p(x), _p(w), _p(b), _p(out), _p(inv), rows, D, eps, _stream()), "layernorm_fwd_fp8")
-    return out, inv
+    nxt = torch.empty((rows,), dtype=torch.float32, device=x.device) if bound is not None else None
+    mul, add = bound if bound is not None else (0.0, 0.0)
+    check(_lib.load().hvlm_layernorm_fwd_fp8(_p(x), _p(w), _p(b), _p(out), _p(inv), _p(nxt), float(mul), float(add), rows, D, eps,
+                                             _stream()), "layernorm_fwd_fp8")
+    return (out, inv) if bound is None else (out, inv, nxt)
+
+
+def gemm_fp8_nt_scaled_q8(a8, b8, row_scale, col_scale, out_inv, bias=None, act: int = ACT_NONE):
+    """e4m3 in, e4m3 out: (bytes [M, N], out_inv) with out[m, n] = e4m3(bf16(act(rs[m] cs[n] a8 b8^T + bias)) / out_inv[m]);
+    out_inv must bound the row (see hvlm_gemm_fp8_nt_scaled_q8)."""
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2 and a8.shape[1] == b8.shape[1]
+    M, K = a8.shape
+    N = b8.shape[0]
+    assert out_inv.dtype == torch.float32 and out_inv.numel() == M and N % 16 == 0
+    out = torch.empty((M, N), dtype=torch.uint8, device=a8.device)
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_fp8_nt_scaled_q8(_p(a8), _p(b8), _p(out), M, N, K, a8.stride(0), b8.stride(0), out.stride(0), 1.0,
+                                                 _p(row_scale), _p(col_scale), _p(bias), act, _p(out_inv), _stream()), "gemm_fp8_q8")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -117,6 +117,14 @@ int hvlm_quantize_fp8_rowwise(const void* x, void* out, float* inv_scale, int ro
 int hvlm_gemm_fp8_nt_scaled(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                             float alpha, const float* row_scale, const float* col_scale, const void* bias,
                             const void* residual, int ldr, int act, int out_f32, void* stream);
+/* hvlm_gemm_fp8_nt_scaled whose OUTPUT is e4m3 as well: C8[m, n] = e4m3(clamp(bf16(act(alpha * rs[m] * cs[n] * A B^T + bias)) /
+ * out_inv[m], +-448)), one byte per element, ldc in bytes — the A operand of the next GEMM with row_scale = out_inv.  The scale
+ * has to be known before the row is complete, so the caller supplies an upper BOUND of the row's |output| (a floating-point
+ * format loses nothing to a scale that is a few binades high); used for fc1 -> fc2 of the CLIP tower, where
+ * |QuickGELU(y W^T + b)| <= |y|_2 max_n |W_n|_2 + max|b| (hvlm_layernorm_fwd_fp8 produces that bound).  No residual. */
+int hvlm_gemm_fp8_nt_scaled_q8(const void* A, const void* B, void* C8, int M, int N, int K, int lda, int ldb, int ldc,
+                               float alpha, const float* row_scale, const float* col_scale, const void* bias,
+                               int act, const float* out_inv, void* stream);
 
 /* General form with K-strided operands (no transposed copies for the backward GEMMs):
  *   trans_a: A is stored [K, M] (M contiguous, lda >= M); trans_b: B is stored [K, N] (ldb >= N).
@@ -351,9 +359,11 @@ int hvlm_gemm_f16_nt(const void* A, const void* B, void* C, int M, int N, int K,
 int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, void* stream);
 /* LayerNorm (bf16 in, as hvlm_layernorm_fwd) whose output row is written as e4m3 bytes with one scale per row: out8[r, :] and
  * inv_scale[r] are bit-identical to hvlm_quantize_fp8_rowwise of hvlm_layernorm_fwd's bf16 output — the input of the q|k|v
- * and fc1 GEMMs of the CLIP tower in the fp8 forward (BASELINE config 5; CLIPEncoderLayer.layer_norm1 / layer_norm2). */
-int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, int rows, int D,
-                           float eps, void* stream);
+ * and fc1 GEMMs of the CLIP tower in the fp8 forward (BASELINE config 5; CLIPEncoderLayer.layer_norm1 / layer_norm2).
+ * next_inv (optional): next_inv[r] = (|y_r|_2 * bound_mul + bound_add) / 448 with y_r the bf16 output row — the output scale of
+ * a GEMM that consumes this row and writes e4m3 itself (hvlm_gemm_fp8_nt_scaled_q8). */
+int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
+                           float bound_mul, float bound_add, int rows, int D, float eps, void* stream);
 int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,
                         void* stream);
 int hvlm_attn_fwd_f16(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh, int ld, int causal,
