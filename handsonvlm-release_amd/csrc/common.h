@@ -77,6 +77,24 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// The same reductions on DPP row operations + four readlanes (no LDS-crossbar shuffles: ~80 cycles instead of ~500 of dependent
+// ds_bpermute latency).  The max is order-independent, so wave_max_dpp == wave_max bit for bit; wave_sum_dpp adds in a different
+// order than wave_sum and is used only where no other kernel has to reproduce the bits.
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce_dpp(float v) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));    // quad_perm [1,0,3,2]
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));    // quad_perm [2,3,0,1]
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));   // row_half_mirror
+  v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));   // row_mirror
+  const int b = __float_as_int(v);                       // every lane of a 16-lane row now holds its row's result
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_reduce_dpp<true>(v); }
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_reduce_dpp<false>(v); }
+
 // block-wide sum for blocks of NW waves; `red` is NW floats of LDS. All threads get the result.
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_rowwise_reg_kernel(const bf1
       for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(bf_lo(v[c][e])), fabsf(bf_hi(v[c][e]))));
     }
   }
-  if constexpr (TPR == 64) mx = wave_max(mx); else mx = block_max<4>(mx, red);
+  if constexpr (TPR == 64) mx = wave_max_dpp(mx); else mx = block_max<4>(mx, red);
   if (!active) return;
   const float amax = fmaxf(mx, 1e-12f);
   const float sc = 448.f / amax;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_rowwise_reg_kernel(const bf1
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f[2 * e] = bf_lo(v[c][e]) * sc; f[2 * e + 1] = bf_hi(v[c][e]) * sc; }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e], -448.f), 448.f);
+      for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e], -448.f, 448.f);
       unsigned lo = 0, hi = 0;
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
       lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);

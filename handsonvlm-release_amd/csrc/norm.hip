@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
         }
       }
     }
-    if constexpr (TPR == 64) mx = wave_max(mx); else mx = block_max<TPR / 64>(mx, red);
+    if constexpr (TPR == 64) mx = wave_max_dpp(mx); else mx = block_max<TPR / 64>(mx, red);
     if (next_inv) {
-      sq = row_sum<TPR>(sq, red);
+      if constexpr (TPR == 64) sq = wave_sum_dpp(sq); else sq = row_sum<TPR>(sq, red);
       if (active && t == 0) next_inv[row] = (sqrtf(sq) * bound_mul + bound_add) * (1.f / 448.f);
     }
     if (!active) return;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
       if (i < D) {
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(v[c][e] * sc, -448.f), 448.f);
+        for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(v[c][e] * sc, -448.f, 448.f);
         unsigned lo = 0, hi = 0;
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
         lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
