@@ -235,8 +235,7 @@ __global__ __launch_bounds__(256) void quantize_fp8_rowwise_kernel(const bf16_t*
 // The same function with the row held in registers (K <= TPR * 8 * QC): one read of x instead of two, and for short rows
 // (K <= 2048: the CLIP tower's 1024) ONE WAVE per row, four rows per workgroup, no LDS, no barrier — the kernel above runs
 // a 256-thread workgroup with two block reductions per row, half of it idle at K = 1024 (416 -> 2xx us on 411200 x 1024).
-constexpr int QC = 4;
-template <int TPR>
+template <int TPR, int QC>
 __global__ __launch_bounds__(256) void quantize_fp8_rowwise_reg_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ out,
                                                                        float* __restrict__ inv_scale, long rows, int K, long ldx,
                                                                        long ldo) {
@@ -291,11 +290,14 @@ extern "C" int hvlm_quantize_fp8_rowwise(const void* x, void* out, float* inv_sc
   HVLM_REQUIRE(x && out && inv_scale && rows > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ldx >= K && ldo >= K,
                "quantize_fp8_rowwise: bad args (K, ldx, ldo multiples of 8)");
   HVLM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0, "quantize_fp8_rowwise: alignment");
-  if (K <= 64 * 8 * QC)
-    hipLaunchKernelGGL(quantize_fp8_rowwise_reg_kernel<64>, dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+  if (K <= 64 * 8 * 4)
+    hipLaunchKernelGGL((quantize_fp8_rowwise_reg_kernel<64, 4>), dim3(cdiv(rows, 4)), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
                        (unsigned char*)out, inv_scale, (long)rows, K, (long)ldx, (long)ldo);
-  else if (K <= 256 * 8 * QC)
-    hipLaunchKernelGGL(quantize_fp8_rowwise_reg_kernel<256>, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+  else if (K <= 256 * 8 * 2)
+    hipLaunchKernelGGL((quantize_fp8_rowwise_reg_kernel<256, 2>), dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                       (unsigned char*)out, inv_scale, (long)rows, K, (long)ldx, (long)ldo);
+  else if (K <= 256 * 8 * 7)          // up to 14336: the SwiGLU output of the 7B (11008) and 13B (13824) decoders
+    hipLaunchKernelGGL((quantize_fp8_rowwise_reg_kernel<256, 7>), dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
                        (unsigned char*)out, inv_scale, (long)rows, K, (long)ldx, (long)ldo);
   else
     hipLaunchKernelGGL(quantize_fp8_rowwise_kernel, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x,

@@ -310,6 +310,62 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
 }
 
+// RMSNorm -> e4m3 for rows of exactly 2048 * NC elements (the decoder's hidden size 4096: NC = 2), one workgroup per row, straight
+// line: the input of the q|k|v and gate|up GEMMs of the fp8 prefill, bit-identical to rmsnorm_fwd_kernel followed by the
+// rowwise quantise kernel (same roundings: bf16(x * rstd), then * w, then bf16).
+template <int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                             unsigned char* __restrict__ y8, float* __restrict__ inv_scale,
+                                                             float eps) {
+  __shared__ float red[4];
+  constexpr int D = 2048 * NC;
+  const int t = threadIdx.x;
+  const size_t row = blockIdx.x;
+  const bf16_t* xr = x + row * D;
+  u32x4 xv[NC], wv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xv[c] = *reinterpret_cast<const u32x4*>(xr + (c * 256 + t) * 8);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) wv[c] = *reinterpret_cast<const u32x4*>(w + (c * 256 + t) * 8);
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float a = bf_lo(xv[c][e]), b = bf_hi(xv[c][e]); ss += a * a + b * b; }
+  ss = block_sum<4>(ss, red);
+  const float rstd = rsqrtf(ss / (float)D + eps);
+  float v[NC][8];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bf2f(f2bf(bf_lo(xv[c][e]) * rstd)) * bf_lo(wv[c][e]);
+      const float b = bf2f(f2bf(bf_hi(xv[c][e]) * rstd)) * bf_hi(wv[c][e]);
+      const unsigned pk = pack_bf2(a, b);
+      v[c][2 * e] = bf_lo(pk); v[c][2 * e + 1] = bf_hi(pk);
+      mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));
+    }
+  mx = block_max<4>(mx, red);
+  const float amax = fmaxf(mx, 1e-12f);
+  const float sc = 448.f / amax;
+  if (t == 0) inv_scale[row] = amax / 448.f;
+  unsigned char* yr = y8 + row * D;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(v[c][e] * sc, -448.f, 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    const u32x2 o = {lo, hi};
+    *reinterpret_cast<u32x2*>(yr + (c * 256 + t) * 8) = o;
+  }
+}
+
 // LayerNorm -> e4m3 for rows of exactly 512 * NC elements (CLIP ViT-L: 1024), one wave per row, no predicates: the NC loads of
 // the row and the 2 * NC loads of weight / bias are all in flight before the first wait.  The general kernel above issues each
 // chunk under its own `i < D` branch with a vmcnt(0) behind it — six dependent memory latencies per row, which the 16-bit
@@ -445,6 +501,19 @@ static int layernorm_impl(const void* x, const void* w, const void* b, void* y, 
 extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps,
                                   void* stream) {
   return layernorm_impl(x, w, b, y, rows, D, eps, false, stream);
+}
+
+extern "C" int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_scale, int rows, int D, float eps,
+                                    void* stream) {
+  HVLM_REQUIRE(x && w && out8 && inv_scale && rows > 0, "rmsnorm_fwd_fp8: bad args");
+  HVLM_REQUIRE(D == 4096 || D == 2048, "rmsnorm_fwd_fp8: D must be 2048 or 4096 (got %d): use hvlm_rmsnorm_fwd + hvlm_quantize_fp8_rowwise", D);
+  if (D == 4096)
+    hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<2>, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
+                       (unsigned char*)out8, inv_scale, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<1>, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
+                       (unsigned char*)out8, inv_scale, eps);
+  return check_launch("rmsnorm_fwd_fp8");
 }
 
 extern "C" int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,

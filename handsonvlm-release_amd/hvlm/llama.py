@@ -31,6 +31,7 @@ from .config import HandsOnVLMConfig
 
 BF16 = torch.bfloat16
 _FUSED_T = os.environ.get("HVLM_FUSED_T", "1") == "1"   # SwiGLU kernels also write the token-contiguous copies the dW GEMMs need
+_FP8_FUSED_NORM = os.environ.get("HVLM_FP8_FUSED_NORM", "1") == "1"     # 0: RMSNorm in bf16 + a rowwise quantise pass (A/B)
 _DW_TN = os.environ.get("HVLM_DW_TN", "0") == "1"      # weight-gradient GEMMs on K-strided operands (A/B switch, see _dw)
 
 
@@ -246,8 +247,13 @@ class LlamaStack:
         eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
         mm = (lambda a, k, residual=None: self._mm_fp8(li, k, a, residual)) if seq.fp8 else \
              (lambda a, k, residual=None: ops.gemm_nt(a, lp.w[k], residual=residual))
-        xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
         probe = getattr(self, "_fp8_probe", None)
+        # fp8 inference: RMSNorm writes the e4m3 rows + scales of the next GEMM itself (no bf16 copy, no quantise pass)
+        fuse8 = seq.fp8 and not save and probe is None and self.D in (2048, 4096) and _FP8_FUSED_NORM
+        if fuse8:
+            xn, rstd1 = ops.rmsnorm_fwd_fp8(x, lp.w["ln1"], eps), None
+        else:
+            xn, rstd1 = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=save)
         if probe is not None:
             probe[li]["qkv"] = float(xn.abs().max())
         qkv = mm(xn, "qkv")
@@ -260,7 +266,10 @@ class LlamaStack:
                 cache[li][:, :seq.S, self.D:].copy_(qkv.view(seq.B, seq.S, -1)[:, :, self.D:])
         ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
         h = mm(ao, "o", residual=x)
-        hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
+        if fuse8:
+            hn, rstd2 = ops.rmsnorm_fwd_fp8(h, lp.w["ln2"], eps), None
+        else:
+            hn, rstd2 = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=save)
         gu = mm(hn, "gu")
         actT = None
         if save and _FUSED_T and self.F % 64 == 0:
@@ -323,11 +332,11 @@ class LlamaStack:
 
     def _mm_fp8(self, li: int, key: str, a: torch.Tensor, residual=None) -> torch.Tensor:
         w8, inv_w = self._fp8_rw[li][key]
-        if a.shape[0] <= 32 and a.shape[1] % 64 == 0 and w8.shape[0] % 4 == 0 and ops._GEMM_SKINNY:
+        if not isinstance(a, tuple) and a.shape[0] <= 32 and a.shape[1] % 64 == 0 and w8.shape[0] % 4 == 0 and ops._GEMM_SKINNY:
             # decode steps (M = batch): weight-only e4m3 on the weight-streaming kernel — the cost is reading W once, the
             # activations stay bf16 (no per-token quantisation pass, no activation rounding)
             return ops.gemm_w8a16_nt(a, w8, inv_w, residual=residual)
-        a8, inv_a = ops.quantize_fp8_rowwise(a)
+        a8, inv_a = a if isinstance(a, tuple) else ops.quantize_fp8_rowwise(a)     # RMSNorm hands over e4m3 rows directly
         return ops.gemm_fp8_nt_scaled(a8, w8, inv_a, inv_w, residual=residual)
 
     def decode_step_batched(self, x1: torch.Tensor, lens: torch.Tensor, cache: List[torch.Tensor], fp8: bool = False) -> torch.Tensor:

@@ -335,6 +335,18 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
     return y
 
 
+def rmsnorm_fwd_fp8(x: torch.Tensor, w: torch.Tensor, eps: float):
+    """RMSNorm of bf16 rows (D = 2048 / 4096) written as (e4m3 bytes, inv_scale) == quantize_fp8_rowwise(rmsnorm_fwd(x)[0])."""
+    _chk(x, BF16, "rmsnorm_fp8.x"); _chk(w, BF16, "rmsnorm_fp8.w")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out = torch.empty((rows, D), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.load().hvlm_rmsnorm_fwd_fp8(_p(x), _p(w), _p(out), _p(inv), rows, D, eps, _stream()), "rmsnorm_fwd_fp8")
+    return out, inv
+
+
 def layernorm_fwd_fp8(x, w, b, eps: float, bound=None):
     """LayerNorm of bf16 rows, written as (e4m3 bytes [rows, D], inv_scale f32 [rows]) == quantize_fp8_rowwise(layernorm_fwd(x)).
     bound = (mul, add): also returns next_inv[r] = (|y_r|_2 * mul + add) / 448, the e4m3 output scale of the GEMM that consumes

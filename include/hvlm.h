@@ -362,6 +362,10 @@ int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y,
  * and fc1 GEMMs of the CLIP tower in the fp8 forward (BASELINE config 5; CLIPEncoderLayer.layer_norm1 / layer_norm2).
  * next_inv (optional): next_inv[r] = (|y_r|_2 * bound_mul + bound_add) / 448 with y_r the bf16 output row — the output scale of
  * a GEMM that consumes this row and writes e4m3 itself (hvlm_gemm_fp8_nt_scaled_q8). */
+/* RMSNorm with the same e4m3 row output (== hvlm_quantize_fp8_rowwise of hvlm_rmsnorm_fwd's output, bit for bit): the input of
+ * the q|k|v and gate|up GEMMs of the decoder's fp8 prefill (LlamaRMSNorm input_layernorm / post_attention_layernorm).
+ * D = 2048 or 4096. */
+int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_scale, int rows, int D, float eps, void* stream);
 int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
                            float bound_mul, float bound_add, int rows, int D, float eps, void* stream);
 int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,

@@ -208,6 +208,46 @@ def test_gemm_fp8_e4m3_output_with_row_bounds(ops, M, N, K, act):
     assert ratio < 64.0, ratio                     # how far above the true row maximum the bound sits (binades lost: log2)
 
 
+@pytest.mark.parametrize("rows,D", [(333, 4096), (17, 2048)])
+def test_rmsnorm_fp8_equals_rmsnorm_then_rowwise_quantise(ops, rows, D):
+    g = torch.Generator(device="cuda").manual_seed(D + rows)
+    x = (torch.randn(rows, D, device="cuda", generator=g) * 2.1).to(BF)
+    x[::7, 5] *= 30.0                                            # outlier channel on some rows
+    w = (1 + 0.3 * torch.randn(D, device="cuda", generator=g)).to(BF)
+    y, _ = ops.rmsnorm_fwd(x, w, 1e-6, save_rstd=False)
+    q_ref, s_ref = ops.quantize_fp8_rowwise(y)
+    q, sc = ops.rmsnorm_fwd_fp8(x, w, 1e-6)
+    assert torch.equal(q, q_ref) and torch.equal(sc, s_ref)
+    wide = (torch.randn(5, 11008, device="cuda", generator=g)).to(BF)      # the register-resident K <= 14336 quantiser
+    qw, sw = ops.quantize_fp8_rowwise(wide)
+    amax = wide.float().abs().amax(dim=1)
+    assert torch.allclose(sw, amax / 448.0, rtol=1e-6, atol=0)
+    from test_gpu_ops import _e4m3_decode
+    assert ((_e4m3_decode(qw.cpu()) * sw.cpu()[:, None] - wide.float().cpu()).abs() <= 2.0 ** -4 * amax.cpu()[:, None]).all()
+
+
+def test_fp8_prefill_fused_norm_is_bit_identical():
+    """The decoder's fp8 prefill with RMSNorm writing e4m3 rows itself == the same prefill with a bf16 RMSNorm and a rowwise
+    quantise pass in front of the q|k|v and gate|up GEMMs (2 layers at hidden size 2048)."""
+    from hvlm import llama
+    from hvlm.config import HandsOnVLMConfig
+    cfg = HandsOnVLMConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=2, num_attention_heads=16)
+    st = llama.LlamaStack(cfg, device="cuda:0", training=False)
+    st.init_random(3)
+    st.fp8_prepare_rowwise()
+    B, S = 2, 200
+    x = (torch.randn(B * S, 2048, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.5).to(BF)
+    fused = llama._FP8_FUSED_NORM
+    try:
+        llama._FP8_FUSED_NORM = True
+        a = st.forward(x, B, S, save=False, fp8=True)
+        llama._FP8_FUSED_NORM = False
+        b = st.forward(x, B, S, save=False, fp8=True)
+    finally:
+        llama._FP8_FUSED_NORM = fused
+    assert torch.equal(a, b)
+
+
 def _trained_like_tower(layers, dtype, seed=0):
     """A CLIP tower whose weights have the spread of a trained one (log-normal channel gains, a few x4 outlier channels in
     the LayerNorm gains, residual branches ~0.2 x the stream) instead of iid N(0, 0.02), which fp8 would flatter."""
