@@ -37,6 +37,61 @@ __global__ __launch_bounds__(EW_THREADS) void swiglu_fwd_kernel(const bf16_t* __
   }
 }
 
+// SwiGLU whose output row is written as e4m3 with one scale per row — the input of the down-projection in the fp8 prefill
+// (BASELINE config 5), bit-identical to swiglu_fwd_kernel followed by the rowwise quantise kernel.  One workgroup per row, the
+// row (F <= 256 * 8 * NCH) in registers: gate and up are read once, one byte per element is written, and the separate pass
+// (a read of the bf16 row and a second launch) disappears.
+template <int NCH>
+__global__ __launch_bounds__(256) void swiglu_fwd_q8_kernel(const bf16_t* __restrict__ gu, unsigned char* __restrict__ act8,
+                                                            float* __restrict__ inv_scale, int F) {
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const size_t m = blockIdx.x;
+  const bf16_t* row = gu + m * (2 * (size_t)F);
+  u32x4 g[NCH], u[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = min((c * 256 + t) * 8, F - 8);        // always in bounds; chunks past F are masked below
+    g[c] = *reinterpret_cast<const u32x4*>(row + i);
+    u[c] = *reinterpret_cast<const u32x4*>(row + F + i);
+  }
+  float v[NCH][8];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const bool live = (c * 256 + t) * 8 < F;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g0 = bf_lo(g[c][e]), g1 = bf_hi(g[c][e]);
+      const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
+      const unsigned pk = pack_bf2(s0 * bf_lo(u[c][e]), s1 * bf_hi(u[c][e]));
+      v[c][2 * e] = live ? bf_lo(pk) : 0.f; v[c][2 * e + 1] = live ? bf_hi(pk) : 0.f;
+      mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));
+    }
+  }
+  mx = block_max<4>(mx, red);
+  const float amax = fmaxf(mx, 1e-12f);
+  const float sc = 448.f / amax;
+  if (t == 0) inv_scale[m] = amax / 448.f;
+  unsigned char* orow = act8 + m * (size_t)F;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = (c * 256 + t) * 8;
+    if (i < F) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(v[c][e] * sc, -448.f, 448.f);
+      unsigned lo = 0, hi = 0;
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      const u32x2 o = {lo, hi};
+      *reinterpret_cast<u32x2*>(orow + i) = o;
+    }
+  }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu,
                                                                 const bf16_t* __restrict__ dact,
                                                                 bf16_t* __restrict__ dgu, long M,
@@ -355,6 +410,18 @@ extern "C" int hvlm_swiglu_fwd(const void* gu, void* act, int M, int F, void* st
   hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid((long)M * F / 8)), dim3(EW_THREADS), 0,
                      as_stream(stream), (const bf16_t*)gu, (bf16_t*)act, (long)M, F);
   return check_launch("swiglu_fwd");
+}
+
+extern "C" int hvlm_swiglu_fwd_fp8(const void* gu, void* act8, float* inv_scale, int M, int F, void* stream) {
+  HVLM_REQUIRE(gu && act8 && inv_scale && M > 0 && F >= 8 && F % 8 == 0 && F <= 256 * 8 * 7,
+               "swiglu_fwd_fp8: bad args (F %% 8, F <= 14336)");
+  if (F <= 256 * 8 * 6)
+    hipLaunchKernelGGL(swiglu_fwd_q8_kernel<6>, dim3(M), dim3(256), 0, as_stream(stream), (const bf16_t*)gu, (unsigned char*)act8,
+                       inv_scale, F);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_q8_kernel<7>, dim3(M), dim3(256), 0, as_stream(stream), (const bf16_t*)gu, (unsigned char*)act8,
+                       inv_scale, F);
+  return check_launch("swiglu_fwd_fp8");
 }
 
 extern "C" int hvlm_swiglu_bwd(const void* gu, const void* dact, void* dgu, int M, int F, void* stream) {

@@ -276,6 +276,8 @@ class LlamaStack:
             # the token-contiguous copy of act (operand of dW_down) is written by the SwiGLU kernel itself; the row-major
             # act is only needed by down_proj right below and is not kept
             act, actT = ops.swiglu_fwd_t(gu, _round_up(seq.M, 64))
+        elif fuse8 and self.F % 8 == 0 and self.F <= 14336:
+            act = ops.swiglu_fwd_fp8(gu)                  # e4m3 rows + scales: the down-projection's operand as it is
         else:
             act = ops.swiglu_fwd(gu)
         if probe is not None:

@@ -480,6 +480,17 @@ def attn_decode_batched(q: torch.Tensor, cache: torch.Tensor, lens: torch.Tensor
     return out
 
 
+def swiglu_fwd_fp8(gu: torch.Tensor):
+    """gu [M, 2F] bf16 -> (e4m3 bytes [M, F], inv_scale f32 [M]) == quantize_fp8_rowwise(swiglu_fwd(gu))."""
+    _chk(gu, BF16, "swiglu_fp8.gu")
+    assert gu.is_contiguous()
+    M, F2 = gu.shape
+    out = torch.empty((M, F2 // 2), dtype=torch.uint8, device=gu.device)
+    inv = torch.empty((M,), dtype=torch.float32, device=gu.device)
+    check(_lib.load().hvlm_swiglu_fwd_fp8(_p(gu), _p(out), _p(inv), M, F2 // 2, _stream()), "swiglu_fwd_fp8")
+    return out, inv
+
+
 def swiglu_fwd(gu: torch.Tensor, out=None) -> torch.Tensor:
     _chk(gu, BF16, "swiglu.gu")
     assert gu.is_contiguous()

@@ -261,6 +261,9 @@ int hvlm_llama_decode_step_dev(const void* const* w_qkv, const void* const* w_o,
  * the concatenated gate|up projection (gate in columns [0,F), up in [F,2F)).
  * ------------------------------------------------------------------------------------------ */
 int hvlm_swiglu_fwd(const void* gu, void* act, int M, int F, void* stream);
+/* SwiGLU with the row written as e4m3 bytes + one scale per row (== hvlm_quantize_fp8_rowwise of hvlm_swiglu_fwd's output, bit for
+ * bit): the input of down_proj in the fp8 prefill (LlamaMLP.act_fn(gate) * up).  F % 8 == 0, F <= 14336. */
+int hvlm_swiglu_fwd_fp8(const void* gu, void* act8, float* inv_scale, int M, int F, void* stream);
 int hvlm_swiglu_bwd(const void* gu, const void* dact, void* dgu, int M, int F, void* stream);
 
 /* The same two functions with a fused TRANSPOSED second output ([features, R_pad] with the token index contiguous, columns

@@ -226,9 +226,18 @@ def test_rmsnorm_fp8_equals_rmsnorm_then_rowwise_quantise(ops, rows, D):
     assert ((_e4m3_decode(qw.cpu()) * sw.cpu()[:, None] - wide.float().cpu()).abs() <= 2.0 ** -4 * amax.cpu()[:, None]).all()
 
 
+@pytest.mark.parametrize("M,F", [(77, 11008), (5, 13824), (9, 5632), (3, 64)])
+def test_swiglu_fp8_equals_swiglu_then_rowwise_quantise(ops, M, F):
+    g = torch.Generator(device="cuda").manual_seed(F)
+    gu = (torch.randn(M, 2 * F, device="cuda", generator=g) * 1.5).to(BF)
+    q_ref, s_ref = ops.quantize_fp8_rowwise(ops.swiglu_fwd(gu))
+    q, sc = ops.swiglu_fwd_fp8(gu)
+    assert torch.equal(q, q_ref) and torch.equal(sc, s_ref)
+
+
 def test_fp8_prefill_fused_norm_is_bit_identical():
-    """The decoder's fp8 prefill with RMSNorm writing e4m3 rows itself == the same prefill with a bf16 RMSNorm and a rowwise
-    quantise pass in front of the q|k|v and gate|up GEMMs (2 layers at hidden size 2048)."""
+    """The decoder's fp8 prefill with RMSNorm and SwiGLU writing e4m3 rows themselves == the same prefill with bf16 RMSNorm /
+    SwiGLU outputs and a rowwise quantise pass in front of the q|k|v, gate|up and down GEMMs (2 layers at hidden size 2048)."""
     from hvlm import llama
     from hvlm.config import HandsOnVLMConfig
     cfg = HandsOnVLMConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=2, num_attention_heads=16)
