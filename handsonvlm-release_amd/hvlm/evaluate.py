@@ -25,9 +25,11 @@ def inference(model, sample: Dict, temperature=0.5, top_p=0.9, max_new_tokens=10
 
 
 @torch.no_grad()
-def inference_batch(model, batch, temperature=0.5, top_p=0.9, max_new_tokens=100, do_sample=True, fp8=False, pad_token_id=0):
+def inference_batch(model, batch, temperature=0.5, top_p=0.9, max_new_tokens=100, do_sample=True, fp8=False, pad_token_id=0,
+                    fp8_decode=False, fp8_clip=False):
     """A list of samples -> list of pred_hands ([1,2,n,2] or None), generated in lock step (model.generate_batch): prompts
-    are right-padded to the longest one, exactly like the reference's collator would."""
+    are right-padded to the longest one, exactly like the reference's collator would.  fp8 / fp8_decode / fp8_clip: e4m3 prefill
+    GEMMs / e4m3-weight decode steps / e4m3 CLIP tower (BASELINE config 5; all off = the reference's bf16 + fp16-tower numerics)."""
     T = max(s["input_ids"].shape[1] for s in batch)
     ids = torch.full((len(batch), T), pad_token_id, dtype=torch.long)
     mask = torch.zeros((len(batch), T), dtype=torch.bool)
@@ -37,7 +39,7 @@ def inference_batch(model, batch, temperature=0.5, top_p=0.9, max_new_tokens=100
         mask[b, :n] = True
     image = torch.cat([s["image"] for s in batch], 0)
     out = model.generate_batch(ids, image=image, attention_mask=mask, do_sample=do_sample, temperature=temperature, top_p=top_p,
-                               max_new_tokens=max_new_tokens, fp8=fp8)
+                               max_new_tokens=max_new_tokens, fp8=fp8, fp8_decode=fp8_decode, fp8_clip=fp8_clip)
     return [out.pred_hands[b:b + 1, :, : out.num_hands[b]] if out.num_hands[b] > 0 else None for b in range(len(batch))]
 
 
