@@ -174,6 +174,22 @@ __global__ __launch_bounds__(EW_THREADS) void rope_kernel(bf16_t* __restrict__ q
   }
 }
 
+// K | V columns of the prefill's fused qkv rows -> the per-sample cache slabs (lock-step generation): row (b, s) of
+// qkv [B * S, 3D] goes to cache[b, s, D .. 3D) of a [B, max_len, 3D] cache; the q columns are never read from the cache and are
+// not copied.  16 bytes per lane, a row's 2D columns contiguous on both sides.
+__global__ __launch_bounds__(EW_THREADS) void kv_cache_fill_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ cache,
+                                                                   long rows, int S, long max_len, int D) {
+  const int cpr = 2 * D / 8;                         // 16-byte chunks per row
+  const long total = rows * cpr;
+  for (long i = (long)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * EW_THREADS) {
+    const long r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    const long b = r / S, s_ = r - b * S;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(qkv + r * (3L * D) + D + c);
+    *reinterpret_cast<u32x4*>(cache + (b * max_len + s_) * (3L * D) + D + c) = v;
+  }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void add_kernel(const bf16_t* __restrict__ a,
                                                          const bf16_t* __restrict__ b,
                                                          bf16_t* __restrict__ y, long n8) {
@@ -457,6 +473,15 @@ extern "C" int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab,
                      (bf16_t*)qkv, (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, pos, (long)M, H, dh,
                      ld, inverse);
   return check_launch("rope_qk");
+}
+
+extern "C" int hvlm_kv_cache_fill(const void* qkv, void* cache, int B, int S, int max_len, int D, void* stream) {
+  HVLM_REQUIRE(qkv && cache && B > 0 && S > 0 && max_len >= S && D > 0 && D % 8 == 0, "kv_cache_fill: bad args (D %% 8, max_len >= S)");
+  HVLM_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)cache & 15) == 0, "kv_cache_fill: alignment");
+  const long rows = (long)B * S;
+  hipLaunchKernelGGL(kv_cache_fill_kernel, dim3(ew_grid(rows * (2 * D / 8))), dim3(EW_THREADS), 0, as_stream(stream),
+                     (const bf16_t*)qkv, (bf16_t*)cache, rows, S, (long)max_len, D);
+  return check_launch("kv_cache_fill");
 }
 
 extern "C" int hvlm_add_bf16(const void* a, const void* b, void* y, long n, void* stream) {

@@ -263,7 +263,10 @@ class LlamaStack:
                 assert seq.B == 1
                 cache[li][:seq.S].copy_(qkv)
             else:                                          # batched cache [B, max_len, 3D]: only the k | v columns are ever read
-                cache[li][:, :seq.S, self.D:].copy_(qkv.view(seq.B, seq.S, -1)[:, :, self.D:])
+                if qkv.is_cuda and seq.cu is None:
+                    ops.kv_cache_fill(qkv, cache[li], seq.B, seq.S)
+                else:
+                    cache[li][:, :seq.S, self.D:].copy_(qkv.view(seq.B, seq.S, -1)[:, :, self.D:])
         ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
         h = mm(ao, "o", residual=x)
         if fuse8:

@@ -480,6 +480,14 @@ def attn_decode_batched(q: torch.Tensor, cache: torch.Tensor, lens: torch.Tensor
     return out
 
 
+def kv_cache_fill(qkv: torch.Tensor, cache: torch.Tensor, B: int, S: int) -> None:
+    """cache[b, s, D:] = qkv[b * S + s, D:] for the [B, max_len, 3D] cache of lock-step generation (k | v columns only)."""
+    _chk(qkv, BF16, "kv_cache_fill.qkv"); _chk(cache, BF16, "kv_cache_fill.cache")
+    assert qkv.is_contiguous() and cache.is_contiguous() and cache.dim() == 3 and cache.shape[0] == B and cache.shape[2] == qkv.shape[1]
+    assert qkv.shape[0] == B * S and cache.shape[1] >= S and qkv.shape[1] % 3 == 0
+    check(_lib.load().hvlm_kv_cache_fill(_p(qkv), _p(cache), B, S, cache.shape[1], qkv.shape[1] // 3, _stream()), "kv_cache_fill")
+
+
 def swiglu_fwd_fp8(gu: torch.Tensor):
     """gu [M, 2F] bf16 -> (e4m3 bytes [M, F], inv_scale f32 [M]) == quantize_fp8_rowwise(swiglu_fwd(gu))."""
     _chk(gu, BF16, "swiglu_fp8.gu")

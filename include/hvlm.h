@@ -389,6 +389,10 @@ int hvlm_adamw_step(float* master, float* m, float* v, const void* grad, void* w
                     int C, float lr, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, int step, void* stream);
 /* y = a + b (bf16, n elements). */
+/* Prefill -> KV cache of lock-step generation: the k | v columns of qkv [B * S, 3D] (fused q|k|v rows after RoPE) are copied to
+ * cache [B, max_len, 3D] rows 0 .. S-1 of every sample (columns D .. 3D; the q columns of the cache are never read).
+ * Replaces the `past_key_value` concatenation of LlamaAttention.forward under use_cache. */
+int hvlm_kv_cache_fill(const void* qkv, void* cache, int B, int S, int max_len, int D, void* stream);
 int hvlm_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
 /* f32 -> bf16 and bf16 -> f32 casts (n elements). */
 int hvlm_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);

@@ -235,6 +235,16 @@ def test_swiglu_fp8_equals_swiglu_then_rowwise_quantise(ops, M, F):
     assert torch.equal(q, q_ref) and torch.equal(sc, s_ref)
 
 
+def test_kv_cache_fill(ops):
+    B, S, L, D = 3, 37, 50, 256
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B * S, 3 * D, device="cuda", generator=g).to(BF)
+    cache = torch.full((B, L, 3 * D), 7.0, device="cuda", dtype=BF)
+    ops.kv_cache_fill(qkv, cache, B, S)
+    assert torch.equal(cache[:, :S, D:], qkv.view(B, S, 3 * D)[:, :, D:])
+    assert bool((cache[:, S:] == 7.0).all()) and bool((cache[:, :, :D] == 7.0).all())       # nothing else is touched
+
+
 def test_fp8_prefill_fused_norm_is_bit_identical():
     """The decoder's fp8 prefill with RMSNorm and SwiGLU writing e4m3 rows themselves == the same prefill with bf16 RMSNorm /
     SwiGLU outputs and a rowwise quantise pass in front of the q|k|v, gate|up and down GEMMs (2 layers at hidden size 2048)."""
