@@ -137,6 +137,98 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const bf16_t
   }
 }
 
+// ---- finalize passes of the lock-step decode step that also do the consumer's work (same slab order and the same bf16 rounding
+// of the GEMM output as the plain finalize pass followed by the separate kernel: bit-identical, three launches fewer per layer)
+
+// gate|up projection: act[m, f] = SwiGLU(bf16(sum gate), bf16(sum up)) — hvlm_swiglu_fwd's arithmetic
+__global__ __launch_bounds__(256) void skinny_finalize_swiglu_kernel(const float* __restrict__ ws, int splits, size_t slab,
+                                                                     const float* __restrict__ col_scale, bf16_t* __restrict__ act,
+                                                                     int M, int F) {
+  const long total = (long)M * (F / 4);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / (F / 4);
+    const int f = (int)(i - m * (F / 4)) * 4;
+    const float* p = ws + m * (2L * F) + f;
+    f32x4 g = *reinterpret_cast<const f32x4*>(p), u = *reinterpret_cast<const f32x4*>(p + F);
+    for (int s = 1; s < splits; ++s) {
+      g += *reinterpret_cast<const f32x4*>(p + s * slab);
+      u += *reinterpret_cast<const f32x4*>(p + s * slab + F);
+    }
+    if (col_scale) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] *= col_scale[f + e]; u[e] *= col_scale[F + f + e]; }
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gb = bf2f(f2bf(g[e])), ub = bf2f(f2bf(u[e]));               // the bf16 gate|up row the unfused path stores
+      const float sg = bf2f(f2bf(gb * (1.f / (1.f + __expf(-gb)))));
+      o[e] = sg * ub;
+    }
+    const u32x2 pk = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(act + m * (long)F + f) = pk;
+  }
+}
+
+// q|k|v projection: bf16(sum) -> RoPE of the q and k heads at position lens[m] (hvlm_rope_qk's arithmetic) -> the qkv row AND
+// the k | v columns of cache row lens[m] of sample m.  One item = 4 rotation pairs of a q / k head, or 4 v columns.
+__global__ __launch_bounds__(256) void skinny_finalize_qkv_kernel(const float* __restrict__ ws, int splits, size_t slab,
+                                                                  const float* __restrict__ col_scale, bf16_t* __restrict__ qkv,
+                                                                  int ldq, bf16_t* __restrict__ cache, long max_len,
+                                                                  const int32_t* __restrict__ lens, const bf16_t* __restrict__ cos_tab,
+                                                                  const bf16_t* __restrict__ sin_tab, int M, int H, int dh) {
+  const int D = H * dh, half = dh / 2, N = 3 * D;
+  const int rot_items = 2 * H * (half / 4), v_items = D / 4, per_row = rot_items + v_items;
+  const long total = (long)M * per_row;
+  auto sum4 = [&](long m, int c) {
+    const float* p = ws + m * (long)N + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slab);
+    if (col_scale) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= col_scale[c + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));                    // the bf16 qkv row the unfused path stores
+    return v;
+  };
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / per_row;
+    const int r = (int)(i - m * per_row);
+    const int pos = lens[m];
+    bf16_t* qrow = qkv + m * (long)ldq;
+    bf16_t* crow = cache + (m * max_len + pos) * (long)N;
+    if (r < rot_items) {
+      const int hh = r / (half / 4), c = (r - hh * (half / 4)) * 4;        // head 0 .. 2H-1 (q heads, then k heads), pair offset
+      const int col = hh * dh + c;
+      const f32x4 x1 = sum4(m, col), x2 = sum4(m, col + half);
+      const u32x2 cv = *reinterpret_cast<const u32x2*>(cos_tab + (long)pos * half + c);
+      const u32x2 sv = *reinterpret_cast<const u32x2*>(sin_tab + (long)pos * half + c);
+      const float cc[4] = {bf_lo(cv[0]), bf_hi(cv[0]), bf_lo(cv[1]), bf_hi(cv[1])};
+      const float ss[4] = {bf_lo(sv[0]), bf_hi(sv[0]), bf_lo(sv[1]), bf_hi(sv[1])};
+      float r1[4], r2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r1[e] = bf2f(f2bf(x1[e] * cc[e])) + bf2f(f2bf(-x2[e] * ss[e]));
+        r2[e] = bf2f(f2bf(x2[e] * cc[e])) + bf2f(f2bf(x1[e] * ss[e]));
+      }
+      const u32x2 o1 = {pack_bf2(r1[0], r1[1]), pack_bf2(r1[2], r1[3])}, o2 = {pack_bf2(r2[0], r2[1]), pack_bf2(r2[2], r2[3])};
+      *reinterpret_cast<u32x2*>(qrow + col) = o1;
+      *reinterpret_cast<u32x2*>(qrow + col + half) = o2;
+      if (hh >= H) {                                                           // k heads also go to the cache
+        *reinterpret_cast<u32x2*>(crow + col) = o1;
+        *reinterpret_cast<u32x2*>(crow + col + half) = o2;
+      }
+    } else {
+      const int col = 2 * D + (r - rot_items) * 4;
+      const f32x4 v = sum4(m, col);
+      const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(qrow + col) = o;
+      *reinterpret_cast<u32x2*>(crow + col) = o;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace hvlm
 
@@ -173,19 +265,16 @@ extern "C" size_t hvlm_gemm_w8a16_skinny_ws_bytes(int M, int N, int K) {
   return (size_t)hvlm_gemm_w8a16_skinny_splits(N, K) * M * N * 4;
 }
 
+// launches the streaming kernel into the slabs of `ws`; *splits_out = number of slabs
 template <bool W8>
-static int skinny_impl(const void* A, const void* B, const float* col_scale, void* C, int M, int N, int K, int lda, int ldb,
-                       int ldc, const void* bias, const void* residual, int ldr, int act, void* ws, void* stream) {
+static int skinny_launch(const void* A, const void* B, int M, int N, int K, int lda, int ldb, void* ws, void* stream, int* splits_out) {
   constexpr int KPS = W8 ? 64 : 32, Q = W8 ? 4 : 8, DEPTH = W8 ? SK_DEPTH / 2 : SK_DEPTH;
-  HVLM_REQUIRE(A && B && C && ws, "gemm_skinny: null pointer");
+  HVLM_REQUIRE(A && B && ws, "gemm_skinny: null pointer");
   HVLM_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0, "gemm_skinny: M must be 1 .. 32 (got %d)", M);
   HVLM_REQUIRE(K % KPS == 0, "gemm_skinny: K=%d must be a multiple of %d", K, KPS);
-  HVLM_REQUIRE(N % 4 == 0 && lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % (W8 ? 16 : 8) == 0 && ldc % 4 == 0,
+  HVLM_REQUIRE(N % 4 == 0 && lda >= K && ldb >= K && lda % 8 == 0 && ldb % (W8 ? 16 : 8) == 0,
                "gemm_skinny: bad leading dimensions (N %% 4; rows of A and W 16-byte aligned)");
-  HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 7) == 0 && ((uintptr_t)ws & 15) == 0,
-               "gemm_skinny: alignment");
-  HVLM_REQUIRE(!residual || ldr >= N, "gemm_skinny: bad residual");
-  HVLM_REQUIRE(act == HVLM_ACT_NONE || act == HVLM_ACT_QUICK_GELU, "gemm_skinny: unknown act %d", act);
+  HVLM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)ws & 15) == 0, "gemm_skinny: alignment");
   const int per = skinny_steps_per_split(N, K / KPS, Q), splits = cdiv(K / KPS, per);
   const int padded = cdiv(per, DEPTH) * DEPTH;
   const int halves = M <= 16 ? 1 : 2;
@@ -205,10 +294,53 @@ static int skinny_impl(const void* A, const void* B, const float* col_scale, voi
   else
     hipLaunchKernelGGL((gemm_skinny_kernel<2, W8>), grid, block, lds, as_stream(stream), (const bf16_t*)A, (const char*)B,
                        (float*)ws, M, N, K, lda, ldb, per, (size_t)M * N);
-  const int rc = check_launch(W8 ? "gemm_w8a16_skinny" : "gemm_skinny");
+  *splits_out = splits;
+  return check_launch(W8 ? "gemm_w8a16_skinny" : "gemm_skinny");
+}
+
+template <bool W8>
+static int skinny_impl(const void* A, const void* B, const float* col_scale, void* C, int M, int N, int K, int lda, int ldb,
+                       int ldc, const void* bias, const void* residual, int ldr, int act, void* ws, void* stream) {
+  HVLM_REQUIRE(C && ldc >= N && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0, "gemm_skinny: bad C / ldc");
+  HVLM_REQUIRE(!residual || ldr >= N, "gemm_skinny: bad residual");
+  HVLM_REQUIRE(act == HVLM_ACT_NONE || act == HVLM_ACT_QUICK_GELU, "gemm_skinny: unknown act %d", act);
+  int splits = 0;
+  const int rc = skinny_launch<W8>(A, B, M, N, K, lda, ldb, ws, stream, &splits);
   if (rc) return rc;
   return launch_splitk_finalize((const float*)ws, splits, (size_t)M * N, col_scale, (const bf16_t*)bias, (const bf16_t*)residual,
                                 ldr, act, (bf16_t*)C, ldc, M, N, as_stream(stream));
+}
+
+// ---- the two projections of the decode step whose consumer rides in the finalize pass ---------------------------------------
+extern "C" int hvlm_gemm_skinny_swiglu(const void* A, const void* B, const float* col_scale, void* act, int M, int F, int K, int lda,
+                                       int ldb, void* ws, void* stream) {
+  HVLM_REQUIRE(act && F > 0 && F % 4 == 0 && ((uintptr_t)act & 7) == 0, "gemm_skinny_swiglu: bad act / F");
+  int splits = 0;
+  const int rc = col_scale ? skinny_launch<true>(A, B, M, 2 * F, K, lda, ldb, ws, stream, &splits)
+                           : skinny_launch<false>(A, B, M, 2 * F, K, lda, ldb, ws, stream, &splits);
+  if (rc) return rc;
+  const long total = (long)M * (F / 4);
+  int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
+  hipLaunchKernelGGL(skinny_finalize_swiglu_kernel, dim3(fg), dim3(256), 0, as_stream(stream), (const float*)ws, splits,
+                     (size_t)M * 2 * F, col_scale, (bf16_t*)act, M, F);
+  return check_launch("gemm_skinny_swiglu");
+}
+
+extern "C" int hvlm_gemm_skinny_qkv(const void* A, const void* B, const float* col_scale, void* qkv, int ldq, void* cache,
+                                    long max_len, const int32_t* lens, const void* cos_tab, const void* sin_tab, int M, int H,
+                                    int dh, int K, int lda, int ldb, void* ws, void* stream) {
+  HVLM_REQUIRE(qkv && cache && lens && cos_tab && sin_tab, "gemm_skinny_qkv: null pointer");
+  HVLM_REQUIRE(H > 0 && dh % 8 == 0 && ldq >= 3 * H * dh && ldq % 4 == 0 && max_len > 0, "gemm_skinny_qkv: bad shape");
+  const int N = 3 * H * dh;
+  int splits = 0;
+  const int rc = col_scale ? skinny_launch<true>(A, B, M, N, K, lda, ldb, ws, stream, &splits)
+                           : skinny_launch<false>(A, B, M, N, K, lda, ldb, ws, stream, &splits);
+  if (rc) return rc;
+  const long total = (long)M * (2 * H * (dh / 8) + H * dh / 4);
+  int fg = (int)((total + 255) / 256); if (fg > 2048) fg = 2048;
+  hipLaunchKernelGGL(skinny_finalize_qkv_kernel, dim3(fg), dim3(256), 0, as_stream(stream), (const float*)ws, splits, (size_t)M * N,
+                     col_scale, (bf16_t*)qkv, ldq, (bf16_t*)cache, max_len, lens, (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, M, H, dh);
+  return check_launch("gemm_skinny_qkv");
 }
 
 extern "C" int hvlm_gemm_bf16_nt_skinny(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,

@@ -31,6 +31,7 @@ from .config import HandsOnVLMConfig
 
 BF16 = torch.bfloat16
 _FUSED_T = os.environ.get("HVLM_FUSED_T", "1") == "1"   # SwiGLU kernels also write the token-contiguous copies the dW GEMMs need
+_DECODE_FUSED_FINALIZE = os.environ.get("HVLM_DECODE_FUSED_FINALIZE", "1") == "1"   # lock-step decode: RoPE + cache write / SwiGLU in the GEMM's finalize pass
 _FP8_FUSED_NORM = os.environ.get("HVLM_FP8_FUSED_NORM", "1") == "1"     # 0: RMSNorm in bf16 + a rowwise quantise pass (A/B)
 _DW_TN = os.environ.get("HVLM_DW_TN", "0") == "1"      # weight-gradient GEMMs on K-strided operands (A/B switch, see _dw)
 
@@ -396,17 +397,25 @@ class LlamaStack:
         idx = lens.long()
         lens1 = (lens + 1).contiguous()
         x = x1
+        # q|k|v and gate|up: RoPE + cache row write / SwiGLU ride in the split-K finalize pass of the weight-streaming GEMM
+        # (bit-identical, three launches fewer per layer); HVLM_DECODE_FUSED_FINALIZE=0 keeps them as separate kernels
+        fused = (_DECODE_FUSED_FINALIZE and ops._GEMM_SKINNY and x1.is_cuda and B <= 32 and self.D % 64 == 0 and self.F % 4 == 0
+                 and self.D >= 256 and self.dh % 8 == 0)
         for li, lp in enumerate(self.layers):
             mm = (lambda a, k, residual=None: self._mm_fp8(li, k, a, residual)) if fp8 else \
                  (lambda a, k, residual=None: ops.gemm_nt(a, lp.w[k], residual=residual))
+            wsel = (lambda k: self._fp8_rw[li][k]) if fp8 else (lambda k: lp.w[k])
             xn, _ = ops.rmsnorm_fwd(x, lp.w["ln1"], eps, save_rstd=False)
-            qkv = mm(xn, "qkv")
-            ops.rope_qk_(qkv, self.cos, self.sin, lens, self.H, self.dh)
-            cache[li][rows, idx] = qkv                                   # the new token's k / v row of every sample
+            if fused:
+                qkv = ops.gemm_skinny_qkv(xn, wsel("qkv"), cache[li], lens, self.cos, self.sin, self.H, self.dh)
+            else:
+                qkv = mm(xn, "qkv")
+                ops.rope_qk_(qkv, self.cos, self.sin, lens, self.H, self.dh)
+                cache[li][rows, idx] = qkv                               # the new token's k / v row of every sample
             ao = ops.attn_decode_batched(qkv, cache[li], lens1, self.H, self.dh, scale)
             h = mm(ao, "o", residual=x)
             hn, _ = ops.rmsnorm_fwd(h, lp.w["ln2"], eps, save_rstd=False)
-            act = ops.swiglu_fwd(mm(hn, "gu"))
+            act = ops.gemm_skinny_swiglu(hn, wsel("gu")) if fused else ops.swiglu_fwd(mm(hn, "gu"))
             x = mm(act, "down", residual=h)
         hidden, _ = ops.rmsnorm_fwd(x, self.norm_w, eps, save_rstd=False)
         return hidden

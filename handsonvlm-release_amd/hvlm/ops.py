@@ -274,6 +274,44 @@ def gemm_w8a16_nt(a: torch.Tensor, b8: torch.Tensor, col_scale: torch.Tensor, bi
     return out
 
 
+def _skinny_w(w):
+    """(weight tensor, col_scale or None, ws-size function) for a bf16 weight or an (e4m3 bytes, inv_scale) pair."""
+    lib = _lib.load()
+    if isinstance(w, tuple):
+        return w[0], w[1], lib.hvlm_gemm_w8a16_skinny_ws_bytes
+    return w, None, lib.hvlm_gemm_skinny_ws_bytes
+
+
+def gemm_skinny_swiglu(a: torch.Tensor, w_gu) -> torch.Tensor:
+    """act[M, F] = SwiGLU(a @ w_gate^T, a @ w_up^T) for M <= 32; w_gu = [gate; up] rows as bf16 [2F, K] or (e4m3, inv_scale).
+    == swiglu_fwd(gemm_nt(a, w_gu)) bit for bit (the SwiGLU rides in the split-K finalize pass)."""
+    _chk(a, BF16, "gemm_skinny_swiglu.a")
+    w, cs, wsb = _skinny_w(w_gu)
+    M, K = a.shape
+    F = w.shape[0] // 2
+    act = torch.empty((M, F), dtype=BF16, device=a.device)
+    ws = torch.empty((wsb(M, 2 * F, K),), dtype=torch.uint8, device=a.device)
+    check(_lib.load().hvlm_gemm_skinny_swiglu(_p(a), _p(w), _p(cs), _p(act), M, F, K, a.stride(0), w.stride(0), _p(ws), _stream()),
+          "gemm_skinny_swiglu")
+    return act
+
+
+def gemm_skinny_qkv(a: torch.Tensor, w_qkv, cache: torch.Tensor, lens: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                    H: int, dh: int) -> torch.Tensor:
+    """qkv[M, 3D] = RoPE(a @ w_qkv^T) at positions lens[m], k | v columns also written to cache[m, lens[m]] ([M, max_len, 3D]).
+    == gemm_nt + rope_qk_ + the cache row write, bit for bit."""
+    _chk(a, BF16, "gemm_skinny_qkv.a"); _chk(cache, BF16, "gemm_skinny_qkv.cache"); _chk(lens, torch.int32, "gemm_skinny_qkv.lens")
+    w, cs, wsb = _skinny_w(w_qkv)
+    M, K = a.shape
+    N = 3 * H * dh
+    assert w.shape[0] == N and cache.is_contiguous() and cache.shape[0] == M and cache.shape[2] == N
+    qkv = torch.empty((M, N), dtype=BF16, device=a.device)
+    ws = torch.empty((wsb(M, N, K),), dtype=torch.uint8, device=a.device)
+    check(_lib.load().hvlm_gemm_skinny_qkv(_p(a), _p(w), _p(cs), _p(qkv), N, _p(cache), cache.shape[1], _p(lens), _p(cos), _p(sin),
+                                           M, H, dh, K, a.stride(0), w.stride(0), _p(ws), _stream()), "gemm_skinny_qkv")
+    return qkv
+
+
 def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x[R,C] -> out[C,R_pad] (columns R..R_pad-1 zero)."""
     _chk(x, BF16, "transpose.x")

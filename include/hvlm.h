@@ -92,6 +92,19 @@ int hvlm_gemm_w8a16_nt_skinny(const void* A, const void* B8, const float* col_sc
                               int lda, int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
                               void* ws, void* stream);
 
+/* The two projections of the lock-step decode step whose consumer rides in the finalize pass (bit-identical to the plain
+ * calls followed by hvlm_swiglu_fwd / hvlm_rope_qk + the cache row write; three launches fewer per layer).  B is bf16 [N, K]
+ * when col_scale == NULL, e4m3 [N, K] with per-output-channel scales otherwise (the W8A16 form); ws as for the plain calls
+ * with N = 2F / 3 H dh.
+ *   swiglu: act[M, F] = SwiGLU(x W_gate^T, x W_up^T), B = [gate; up] rows (LlamaMLP).
+ *   qkv   : qkv[m, :] = RoPE(x W_qkv^T) at position lens[m] (q and k heads; v passes through), and its k | v columns are also
+ *           written to cache[m, lens[m], :] of the [M, max_len, 3 H dh] cache (LlamaAttention with past_key_value). */
+int hvlm_gemm_skinny_swiglu(const void* A, const void* B, const float* col_scale, void* act, int M, int F, int K, int lda,
+                            int ldb, void* ws, void* stream);
+int hvlm_gemm_skinny_qkv(const void* A, const void* B, const float* col_scale, void* qkv, int ldq, void* cache,
+                         long max_len, const int32_t* lens, const void* cos_tab, const void* sin_tab, int M, int H,
+                         int dh, int K, int lda, int ldb, void* ws, void* stream);
+
 /* fp8 (OCP e4m3) operands on the CDNA4 scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, block scales fixed to 1):
  *   C[M,N] = act(alpha * A[M,K] @ B[N,K]^T + bias) + residual, A / B one byte per element, K % 128 == 0,
  *   lda / ldb % 16 == 0; alpha = 1 / (scale_a * scale_b) for per-tensor scaled operands (BASELINE config 5: fp8 forward).

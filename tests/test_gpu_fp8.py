@@ -235,6 +235,42 @@ def test_swiglu_fp8_equals_swiglu_then_rowwise_quantise(ops, M, F):
     assert torch.equal(q, q_ref) and torch.equal(sc, s_ref)
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_decode_step_fused_finalize_is_bit_identical(fp8, monkeypatch):
+    """Lock-step decode step with RoPE + cache row write and SwiGLU inside the weight-streaming GEMM's finalize pass == the same
+    step with them as separate kernels, hidden states and cache rows, several tokens in a row (2 layers at hidden size 2048,
+    bf16 weights and e4m3 weights, ragged lengths)."""
+    from hvlm import llama
+    from hvlm.config import HandsOnVLMConfig
+    monkeypatch.setenv("HVLM_DECODE_BATCH_GRAPH", "0")
+    cfg = HandsOnVLMConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=2, num_attention_heads=16)
+    st = llama.LlamaStack(cfg, device="cuda:0", training=False)
+    st.init_random(3)
+    if fp8:
+        st.fp8_prepare_rowwise()
+    B = 5
+    outs = {}
+    for mode in (True, False):
+        llama._DECODE_FUSED_FINALIZE = mode
+        try:
+            gg = torch.Generator(device="cuda").manual_seed(5)
+            cache = [(torch.randn(B, 40, 3 * st.D, device="cuda", generator=gg) * 0.3).to(BF) for _ in range(st.L)]
+            lens = torch.tensor([9, 5, 30, 1, 17], dtype=torch.int32, device="cuda")
+            hs = []
+            for step in range(3):
+                x1 = (torch.randn(B, st.D, device="cuda", generator=gg) * 0.5).to(BF)
+                hs.append(st.decode_step_batched(x1, lens, cache, fp8=fp8).clone())
+                lens = lens + 1
+            outs[mode] = (hs, [c.clone() for c in cache])
+        finally:
+            llama._DECODE_FUSED_FINALIZE = True
+    for a, b in zip(outs[True][0], outs[False][0]):
+        assert torch.equal(a, b)
+    D = st.D
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(a[:, :, D:], b[:, :, D:])
+
+
 def test_kv_cache_fill(ops):
     B, S, L, D = 3, 37, 50, 256
     g = torch.Generator(device="cuda").manual_seed(0)
