@@ -13,7 +13,11 @@
 // of a column block behind an agent-scope release / acquire pair — was measured 2x SLOWER: every workgroup's release
 // writes back its XCD's L2, 25 -> 58 us on the qkv projection; profiles/r02v_skinny_gemm.txt.)
 //
-// Bound: HBM.  Algorithmic bytes per launch = N * K * 2 (W once); x is 32 * K * 2 per workgroup column, L2-resident.
+// Also here: the same kernel on e4m3 weights (W8 = true: one byte per element, converted to bf16 in registers; per-channel scale
+// in the finalize pass), and the two finalize passes of the decode step that do their consumer's work (RoPE + cache row write
+// for q|k|v, SwiGLU for gate|up).
+//
+// Bound: HBM.  Algorithmic bytes per launch = N * K * 2 (W once; N * K for e4m3); x is 32 * K * 2 per workgroup column, L2-resident.
 #include "common.h"
 
 namespace hvlm {
