@@ -88,6 +88,7 @@ class CLIPVisionTower:
             p[f"{i}.fc1_w"], p[f"{i}.fc1_b"] = g(lp + "mlp.fc1.weight"), g(lp + "mlp.fc1.bias")
             p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = g(lp + "mlp.fc2.weight"), g(lp + "mlp.fc2.bias")
         self.p = p
+        self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
         self.is_loaded = True
         return self
 
@@ -110,6 +111,7 @@ class CLIPVisionTower:
             p[f"{i}.fc1_w"], p[f"{i}.fc1_b"] = rn(m, d), rn(m)
             p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = rn(d, m), rn(d)
         self.p = p
+        self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
         self.is_loaded = True
         return self
 

@@ -106,7 +106,14 @@ class LlamaStack:
         self.on_layer_grad_ready: Optional[Callable[[int], None]] = None   # DP hook: bucket i is final
 
     # -- parameters -----------------------------------------------------------------------------
+    def invalidate_fp8(self) -> None:
+        """Drops the e4m3 copies of the weights (and the decode graphs captured on them): they are made lazily from the bf16
+        weights at the first fp8 call, so call this whenever the bf16 weights change (loading a checkpoint, a training step)."""
+        self._fp8_rw = None
+        self.__dict__.pop("_dec_graphs_b", None)
+
     def init_random(self, seed: int = 0, std: float = 0.02):
+        self.invalidate_fp8()
         gen = torch.Generator(device=self.device).manual_seed(seed)
         for lp in self.layers:
             for k in ("qkv", "o", "gu", "down"):
@@ -117,6 +124,7 @@ class LlamaStack:
 
     def load_hf(self, sd: Dict[str, torch.Tensor], prefix: str = "model."):
         """HF-named Llama weights (model.layers.{i}.self_attn.q_proj.weight, ...) -> fused buffers."""
+        self.invalidate_fp8()
         dev = self.device
         g = lambda k: sd[prefix + k].to(device=dev, dtype=BF16)  # noqa: E731
         for i, lp in enumerate(self.layers):
