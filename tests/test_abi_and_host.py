@@ -39,6 +39,26 @@ def test_header_symbols_all_exported(lib):
     assert l.hvlm_attn_bwd_ws_bytes(1, 64, 1, 64) >= 64 * 4
 
 
+def test_skinny_gemm_slice_choice_is_the_measured_one(lib):
+    """The K-slice choice of the weight-streaming GEMM (pure host arithmetic; 256 CUs assumed without a device) on the five
+    projections of a 7B decode step: the slice counts profiles/r02v_skinny_gemm.txt measured fastest, and the workspace sizes
+    that follow from them.  e4m3 weights: slices of 64-k steps."""
+    l = lib.load()
+    shapes = {"qkv": (12288, 4096, 8), "o": (4096, 4096, 8), "gate|up": (22016, 4096, 4), "down": (4096, 11008, 15),
+              "lm_head": (32000, 4096, 4)}
+    for name, (N, K, want) in shapes.items():
+        assert l.hvlm_gemm_skinny_splits(N, K) == want, name
+        assert l.hvlm_gemm_skinny_ws_bytes(32, N, K) == want * 32 * N * 4
+        s8 = l.hvlm_gemm_w8a16_skinny_splits(N, K)
+        assert 1 <= s8 <= K // 256 and l.hvlm_gemm_w8a16_skinny_ws_bytes(32, N, K) == s8 * 32 * N * 4
+    # argument validation without touching a device
+    rc = l.hvlm_gemm_bf16_nt_skinny(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 33, 64, 256, 256, 256, 64,
+                                    None, None, 0, 0, ctypes.c_void_p(16), None)
+    assert rc == -1 and b"M must be 1 .. 32" in l.hvlm_last_error()
+    rc = l.hvlm_rmsnorm_fwd_fp8(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 5120, 1e-6, None)
+    assert rc == -1 and b"D must be 2048 or 4096" in l.hvlm_last_error()
+
+
 def test_argument_validation_returns_error_not_crash(lib):
     l = lib.load()
     rc = l.hvlm_gemm_bf16_nt(None, None, None, 16, 16, 64, 64, 64, 16, None, None, 0, 0, 0, None)
