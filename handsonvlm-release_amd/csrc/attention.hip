@@ -824,7 +824,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
 // =================================================================================================
 // backward, dK / dV  (one key per lane)
 // =================================================================================================
-// The TWO-PASS form (the A/B alternative of the role-split single pass further down, HVLM_ATTN_DKV_FUSED=0).  MODE 1: dV only
+// (development builds only, `make DEV=1`; hvlm_configure("attn_dkv_fused", 0) selects it there)
+#ifdef HVLM_DEV
+// The TWO-PASS form (the A/B alternative of the role-split single pass further down).  MODE 1: dV only
 // (S -> P -> dV^T += dO^T P), MODE 2: dK only (S, dP -> dS -> dK^T += Q^T dS): half the accumulators each, so two waves per
 // SIMD fit at dh = 128 (a single pass with both accumulators needs 412 registers = one wave per SIMD and ran at 608 us per layer
 // against 501 for the two passes); S and the exponentials are computed in both passes.
@@ -1022,6 +1024,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(
       }
   }
 }
+
+#endif  // HVLM_DEV
 
 // =================================================================================================
 // backward, dK AND dV in one pass by ROLE-SPLIT waves (8 waves, 128 keys per workgroup, one workgroup per CU)
@@ -1327,7 +1331,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   if (!cu) if constexpr (!CAUSAL && DH == 64) {
     // short sequences: K/V resident in LDS, one workgroup per (batch, head), no V^T pre-pass
     const int nkb = (S + 31) / 32;
-    if (nkb <= 9 && !getenv("HVLM_ATTN_NO_RESIDENT")) {
+    if (nkb <= 9 && !config().attn_no_resident) {
       const int lds = 2 * 2 * nkb * 32 * DH * 2;       // two (K + V) buffers
       rc = set_lds(attn_fwd_resident_kernel<DH, F16>, lds, "attn_fwd_resident");
       if (rc) return rc;
@@ -1343,15 +1347,9 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
     }
   }
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
-  // rows per workgroup: 128 (4 waves) or 96 (3 waves) — whichever wastes fewer query rows (S=257 -> 96)
-  const int waste4 = (S + 127) / 128 * 128 - S, waste3 = (S + 95) / 96 * 96 - S;
-  if (false && waste3 < waste4) {   // 96-row workgroups measured slower in situ (649 vs 593 us per CLIP layer): kept for A/B only
-    rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 3, F16>, LDS, "attn_fwd");
-    if (rc) return rc;
-    dim3 grid((S + 95) / 96, H, B);
-    hipLaunchKernelGGL((attn_fwd_kernel<DH, CAUSAL, 3, F16>), grid, dim3(192), LDS, st, qkv, (const bf16_t*)ws, out,
-                       lse, S, H, ld, spad(S), scale * LOG2E, cu);
-  } else {
+  // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us
+  // per CLIP layer, and were removed)
+  {
     rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4, F16>, LDS, "attn_fwd");
     if (rc) return rc;
     dim3 grid((S + 127) / 128, H, B);
@@ -1368,7 +1366,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
                     const bf16_t* rope_sin = nullptr, const int32_t* rope_pos = nullptr) {
   bf16_t* qT = nullptr; bf16_t* kT = nullptr; bf16_t* doT = nullptr;     // (unused kernel arguments, kept for signature stability)
   float* delta = reinterpret_cast<float*>(ws);
-  static const int fused = getenv("HVLM_ATTN_DKV_FUSED") ? atoi(getenv("HVLM_ATTN_DKV_FUSED")) : 1;
+  const int fused = config().attn_dkv_fused;
   int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
   {
     const long tokens = cu ? total_tokens : (long)B * S;
@@ -1407,6 +1405,7 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
                          qkv, dout, lse, (const float*)delta, dqkv, S, H, ld, scale, cu, B, ctr, rope_cos, rope_sin, rope_pos);
       if ((rc = check_launch("attn_bwd_dkv_fused"))) return rc;
     } else {
+#ifdef HVLM_DEV
       // the two-pass form: dV, then dK (two waves per SIMD each)
       if ((rc = set_lds(attn_bwd_dkv_kernel<DH, CAUSAL, 1>, LDS, "attn_bwd_dv"))) return rc;
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, CAUSAL, 1>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)qT,
@@ -1421,6 +1420,11 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
         const long tokens = cu ? total_tokens : (long)B * S;
         if ((rc = hvlm_rope_qk(dqkv, rope_cos, rope_sin, rope_pos, (int)tokens, H, DH, ld, 1, st))) return rc;
       }
+#else
+      (void)grid; (void)LDS; (void)qT; (void)doT;
+      set_error("attn_bwd: the two-pass dK/dV kernels are compiled into development builds only (make DEV=1)");
+      return HVLM_ERR_UNSUPPORTED;
+#endif
     }
   }
   return HVLM_OK;

@@ -582,7 +582,7 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   bf16_t* gu = xb + D;       // [2F]
   float* apart = reinterpret_cast<float*>(gu + 2 * (size_t)F + 64);   // [H][NS][dh + 2] attention partials
   int* cnt = reinterpret_cast<int*>(apart + (size_t)128 * 8 * 130);    // [H] tickets of the fused combine (zero at rest)
-  const bool fused = !(getenv("HVLM_DECODE_UNFUSED") && atoi(getenv("HVLM_DECODE_UNFUSED")));   // read per call: the tests toggle it
+  const bool fused = !config().decode_unfused;          // (hvlm_configure("decode_unfused", 1): A/B and the parity test)
   HVLM_REQUIRE(H <= 128, "decode_step: more than 128 heads");
   HVLM_REQUIRE(dh == 64 || dh == 128, "decode_step: dh must be 64 or 128");
   HVLM_REQUIRE(((size_t)F * 2) <= 64 * 1024 && (size_t)D * 2 <= 64 * 1024, "decode_step: D / F too large for the LDS copy of x");

@@ -27,10 +27,7 @@ using namespace hvlm;
 // development ablations of the ping-pong kernel's K loop (wrong results by construction; timing / PMC only):
 // 1 = no LDS-DMA in load segment B, 2 = none in load segment A, 4 = staging cursors never advance (cache-hot source),
 // 8 = no fragment reads in load segment B (8 of the 24 ds_read_b128 per K-tile and wave)
-static int gemm_dbg() {
-  static const int v = getenv("HVLM_GEMM_DBG") ? atoi(getenv("HVLM_GEMM_DBG")) : 0;
-  return v;
-}
+static int gemm_dbg() { return config().gemm_dbg; }      // (always 0 in a production build: hvlm_configure refuses it)
 
 static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const void* bias, const void* residual, int ldr, int act, int out_f32, bool f16, void* stream);
@@ -67,7 +64,7 @@ static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int 
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
   p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg();
-  { const char* ge = getenv("HVLM_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : GROUP_M; if (p.group_m < 1) p.group_m = 1; }
+  p.group_m = config().gemm_group_m;
   int grid = p.tiles_m * p.tiles_n;
   static int pgrid = 0;
   if (!pgrid) {
@@ -78,7 +75,7 @@ static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int 
   }
   // dynamic tile scheduling needs >= 3 units per workgroup: every workgroup commits to three units when it starts,
   // so with fewer the first arrivals would take everything (256 tiles on 256 CUs: 1383 -> 917 TFLOP/s)
-  p.dyn = (K / BK >= 3 && pgrid <= 512 && grid >= 3 * pgrid && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
+  p.dyn = (K / BK >= 3 && pgrid <= 512 && grid >= 3 * pgrid && !config().gemm_static) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
   const int rc = f16 ? launch_gemm_pp_f16(p, grid < pgrid ? grid : pgrid, as_stream(stream))
                      : launch_gemm_pp(p, grid < pgrid ? grid : pgrid, as_stream(stream));
   if (rc) return rc;
@@ -151,7 +148,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   }
   int grid = p.tiles_m * p.tiles_n * splits;
   if (grid > cus) grid = cus;
-  p.dyn = (p.k_split / BK >= 3 && cus <= 512 && p.tiles_m * p.tiles_n * splits >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
+  p.dyn = (p.k_split / BK >= 3 && cus <= 512 && p.tiles_m * p.tiles_n * splits >= 3 * cus && !config().gemm_static) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
   int rc = launch_gemm_pp(p, grid, as_stream(stream));
   if (rc) return rc;
   rc = check_launch("gemm_splitk");
@@ -354,7 +351,7 @@ static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, in
   }
   int grid = p.tiles_m * p.tiles_n;
   if (grid > cus) grid = cus;
-  p.dyn = (K / 128 >= 3 && cus <= 512 && p.tiles_m * p.tiles_n >= 3 * cus && !getenv("HVLM_GEMM_STATIC")) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
+  p.dyn = (K / 128 >= 3 && cus <= 512 && p.tiles_m * p.tiles_n >= 3 * cus && !config().gemm_static) ? 1 + pp_sched_slot(as_stream(stream)) : 0;
   const int rc = launch_gemm_pp_fp8(p, grid, as_stream(stream));
   if (rc) return rc;
   return check_launch("gemm_fp8_nt");

@@ -920,44 +920,36 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #undef HVLM_PHASE_SYNC
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false, false>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true, false>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_body<false, false, true>(p); }
-// the same kernel with the K-loop ablation switches of GemmArgs::dbg compiled in (HVLM_GEMM_DBG != 0 only)
-__global__ __launch_bounds__(512, 2) void gemm_pp4_dbg_kernel(GemmArgs p) { gemm_pp_body<false, false, true, true>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp4_tn_kernel(GemmArgs p) { gemm_pp_body<true, false, true>(p); }
-// IEEE-half operands / output on v_mfma_f32_32x32x16_f16 (same rate): the CLIP tower in the reference's own dtype
-__global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true>(p); }
-// the 16x16x32 forms (default; HVLM_GEMM_M16=0 selects the 32x32x16 kernels above for A/B)
+// Production kernels: the 4-segment schedule; 16-bit operands on 16x16x32 MFMAs (bf16, and the CLIP tower's IEEE-half twin),
+// e4m3 operands on 32x32x64, K-strided (TN) operands on 32x32x16.
 __global__ __launch_bounds__(512, 2) void gemm_pp4m_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, false, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4m_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true, true>(p); }
-__global__ __launch_bounds__(512, 2) void gemm_pp4m_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true, false, false, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_tn_kernel(GemmArgs p) { gemm_pp_body<true, false, true>(p); }
+#ifdef HVLM_DEV
+// Development builds only (`make DEV=1`): the superseded schedules / MFMA shapes kept for A/B measurements, and the K-loop
+// ablation kernel (GemmArgs::dbg — WRONG RESULTS by construction, timing / PMC only).  hvlm_configure selects them.
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs p) { gemm_pp_body<false, false>(p); }          // 8-phase
+__global__ __launch_bounds__(512, 2) void gemm_pp_tn_kernel(GemmArgs p) { gemm_pp_body<true, false>(p); }        // 8-phase
+__global__ __launch_bounds__(512, 2) void gemm_pp_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true>(p); }       // 8-phase
+__global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_body<false, false, true>(p); }   // 32x32x16
+__global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_dbg_kernel(GemmArgs p) { gemm_pp_body<false, false, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true, false, false, true>(p); }   // 16x16x128
+#endif
 
-template <int KIND>   // 0 = NT bf16, 1 = TN bf16, 2 = NT fp8; 3, 4, 6 = NT bf16, NT fp8, TN bf16 on the 4-segment schedule; 5 = 3 + ablation switches
+template <void (*kfn)(GemmArgs)>
 int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
-  static bool attr_done = false;
-  const void* kfn = KIND == 10 ? (const void*)gemm_pp4m_fp8_kernel : KIND == 9 ? (const void*)gemm_pp4m_f16_kernel : KIND == 8 ? (const void*)gemm_pp4m_kernel : KIND == 7 ? (const void*)gemm_pp4_f16_kernel : KIND == 6 ? (const void*)gemm_pp4_tn_kernel : KIND == 5 ? (const void*)gemm_pp4_dbg_kernel : KIND == 4 ? (const void*)gemm_pp4_fp8_kernel : KIND == 3 ? (const void*)gemm_pp4_kernel : KIND == 1 ? (const void*)gemm_pp_tn_kernel : KIND == 2 ? (const void*)gemm_pp_fp8_kernel : (const void*)gemm_pp_kernel;
+  static bool attr_done = false;          // one per kernel (the kernel is the template argument)
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (e != hipSuccess) {
       set_error("gemm_pp: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return HVLM_ERR_LAUNCH;
     }
     attr_done = true;
   }
-  if (KIND == 10) hipLaunchKernelGGL(gemm_pp4m_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 9) hipLaunchKernelGGL(gemm_pp4m_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 8) hipLaunchKernelGGL(gemm_pp4m_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 7) hipLaunchKernelGGL(gemm_pp4_f16_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 6) hipLaunchKernelGGL(gemm_pp4_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 1) hipLaunchKernelGGL(gemm_pp_tn_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 4) hipLaunchKernelGGL(gemm_pp4_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 5) hipLaunchKernelGGL(gemm_pp4_dbg_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 3) hipLaunchKernelGGL(gemm_pp4_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else if (KIND == 2) hipLaunchKernelGGL(gemm_pp_fp8_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(gemm_pp_kernel, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), PP_LDS_BYTES, stream, p);
   return HVLM_OK;
 }
 
@@ -973,36 +965,39 @@ int pp_sched_slot(hipStream_t stream) {
   return n++;
 }
 
-// HVLM_GEMM_SEG4=0 selects the 8-phase schedule for the K-contiguous kernels (A/B switch; default = 4-segment)
-static bool use_seg4() {
-  static const bool v = !(getenv("HVLM_GEMM_SEG4") && atoi(getenv("HVLM_GEMM_SEG4")) == 0);
-  return v;
-}
-// HVLM_GEMM_M16=0 selects the 32x32x16 kernels (A/B switch; default = the 16x16x32 form)
-static bool use_m16() {
-  static const bool v = !(getenv("HVLM_GEMM_M16") && atoi(getenv("HVLM_GEMM_M16")) == 0);
-  return v;
-}
+// The A/B switches (config().gemm_seg4 / gemm_m16 / gemm_tn_seg4 / gemm_fp8_m16 / gemm_dbg) select kernels that exist in
+// development builds only; hvlm_configure refuses non-default values in a production build, so they are constant here.
+static bool use_seg4() { return config().gemm_seg4 != 0; }
+static bool use_m16() { return config().gemm_m16 != 0; }
 int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream) {
-  return use_m16() ? launch_pp<9>(p, grid, stream) : launch_pp<7>(p, grid, stream);
+#ifdef HVLM_DEV
+  if (!use_m16()) return launch_pp<gemm_pp4_f16_kernel>(p, grid, stream);
+#endif
+  return launch_pp<gemm_pp4m_f16_kernel>(p, grid, stream);
 }
 int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
-  if (p.dbg) return launch_pp<5>(p, grid, stream);
-  if (!use_seg4()) return launch_pp<0>(p, grid, stream);
-  return use_m16() ? launch_pp<8>(p, grid, stream) : launch_pp<3>(p, grid, stream);
+#ifdef HVLM_DEV
+  if (p.dbg) return launch_pp<gemm_pp4_dbg_kernel>(p, grid, stream);
+  if (!use_seg4()) return launch_pp<gemm_pp_kernel>(p, grid, stream);
+  if (!use_m16()) return launch_pp<gemm_pp4_kernel>(p, grid, stream);
+#endif
+  return launch_pp<gemm_pp4m_kernel>(p, grid, stream);
 }
-// HVLM_GEMM_TN_SEG4=0 keeps the K-strided (TN) kernel on the 8-phase schedule (A/B switch; default = 4-segment)
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream) {
-  static const bool seg4 = !(getenv("HVLM_GEMM_TN_SEG4") && atoi(getenv("HVLM_GEMM_TN_SEG4")) == 0);
-  return seg4 ? launch_pp<6>(p, grid, stream) : launch_pp<1>(p, grid, stream);
+#ifdef HVLM_DEV
+  if (!config().gemm_tn_seg4) return launch_pp<gemm_pp_tn_kernel>(p, grid, stream);
+#endif
+  return launch_pp<gemm_pp4_tn_kernel>(p, grid, stream);
 }
 int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
-  if (!use_seg4()) return launch_pp<2>(p, grid, stream);
   // fp8: the 16x16x128 form is NOT the default — the matrix pipe alone gains 5 % from it under the power cap (4605 vs 4369
   // TFLOP/s), but this kernel is not matrix-power-bound at fp8 (operand traffic per unit time doubles): measured 2471 vs 2506
-  // TFLOP/s on 13872x12288x4096, 2875 vs 2859 on 8192^3.  HVLM_GEMM_FP8_M16=1 selects it.
-  static const bool m16 = getenv("HVLM_GEMM_FP8_M16") && atoi(getenv("HVLM_GEMM_FP8_M16")) == 1;
-  return m16 ? launch_pp<10>(p, grid, stream) : launch_pp<4>(p, grid, stream);
+  // TFLOP/s on 13872x12288x4096, 2875 vs 2859 on 8192^3.
+#ifdef HVLM_DEV
+  if (!use_seg4()) return launch_pp<gemm_pp_fp8_kernel>(p, grid, stream);
+  if (config().gemm_fp8_m16 == 1) return launch_pp<gemm_pp4m_fp8_kernel>(p, grid, stream);
+#endif
+  return launch_pp<gemm_pp4_fp8_kernel>(p, grid, stream);
 }
 
 }  // namespace hvlm

@@ -246,8 +246,8 @@ using namespace hvlm;
 // (profiles/r02v_skinny_gemm.txt): down-projection 11 slices of 32 steps = 352 workgroups 29.0 us, 15 slices of 24 = 480
 // workgroups 23.2 us; o-projection 8 x 16 steps 9.7 us, 16 x 8 12.8 us.  HVLM_SKINNY_PER forces a multiple of q (development).
 static int skinny_steps_per_split(int N, int steps, int q) {
-  static int forced = -1, cus = 0;
-  if (forced < 0) { const char* e = getenv("HVLM_SKINNY_PER"); forced = e ? atoi(e) : 0; }
+  static int cus = 0;
+  const int forced = config().skinny_per;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
     cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;

@@ -310,28 +310,35 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
 }
 
-// RMSNorm -> e4m3 for rows of exactly 2048 * NC elements (the decoder's hidden size 4096: NC = 2), one workgroup per row, straight
+// RMSNorm -> e4m3 for rows of D = 2048 / 4096 / 5120 elements (the decoder's hidden size: 7B 4096, 13B 5120; NC = ceil(D / 2048)
+// register chunks per thread, the last one predicated when D is not a multiple of 2048), one workgroup per row, straight
 // line: the input of the q|k|v and gate|up GEMMs of the fp8 prefill, bit-identical to rmsnorm_fwd_kernel followed by the
-// rowwise quantise kernel (same roundings: bf16(x * rstd), then * w, then bf16).
-template <int NC>
+// rowwise quantise kernel (same element -> thread mapping and reduction order; same roundings: bf16(x * rstd), then * w, then bf16).
+template <int NC, int D>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                              unsigned char* __restrict__ y8, float* __restrict__ inv_scale,
                                                              float eps) {
   __shared__ float red[4];
-  constexpr int D = 2048 * NC;
+  static_assert(D <= 2048 * NC && D > 2048 * (NC - 1) && D % 8 == 0, "NC = ceil(D / 2048)");
+  constexpr bool FULL = (D == 2048 * NC);
   const int t = threadIdx.x;
   const size_t row = blockIdx.x;
   const bf16_t* xr = x + row * D;
   u32x4 xv[NC], wv[NC];
+  bool on[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) xv[c] = *reinterpret_cast<const u32x4*>(xr + (c * 256 + t) * 8);
+  for (int c = 0; c < NC; ++c) on[c] = FULL || (c * 256 + t) * 8 < D;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) wv[c] = *reinterpret_cast<const u32x4*>(w + (c * 256 + t) * 8);
+  for (int c = 0; c < NC; ++c) { xv[c] = u32x4{0u, 0u, 0u, 0u}; if (on[c]) xv[c] = *reinterpret_cast<const u32x4*>(xr + (c * 256 + t) * 8); }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { wv[c] = u32x4{0u, 0u, 0u, 0u}; if (on[c]) wv[c] = *reinterpret_cast<const u32x4*>(w + (c * 256 + t) * 8); }
   float ss = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c)
+    if (on[c]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const float a = bf_lo(xv[c][e]), b = bf_hi(xv[c][e]); ss += a * a + b * b; }
+      for (int e = 0; e < 4; ++e) { const float a = bf_lo(xv[c][e]), b = bf_hi(xv[c][e]); ss += a * a + b * b; }
+    }
   ss = block_sum<4>(ss, red);
   const float rstd = rsqrtf(ss / (float)D + eps);
   float v[NC][8];
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const bf16_t* __res
       const float b = bf2f(f2bf(bf_hi(xv[c][e]) * rstd)) * bf_hi(wv[c][e]);
       const unsigned pk = pack_bf2(a, b);
       v[c][2 * e] = bf_lo(pk); v[c][2 * e + 1] = bf_hi(pk);
-      mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));
+      mx = fmaxf(mx, fmaxf(fabsf(v[c][2 * e]), fabsf(v[c][2 * e + 1])));        // (predicated-off chunks hold zeros)
     }
   mx = block_max<4>(mx, red);
   const float amax = fmaxf(mx, 1e-12f);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_q8_kernel(const bf16_t* __res
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
     hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
     const u32x2 o = {lo, hi};
-    *reinterpret_cast<u32x2*>(yr + (c * 256 + t) * 8) = o;
+    if (on[c]) *reinterpret_cast<u32x2*>(yr + (c * 256 + t) * 8) = o;
   }
 }
 
@@ -506,12 +513,17 @@ extern "C" int hvlm_layernorm_fwd(const void* x, const void* w, const void* b, v
 extern "C" int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_scale, int rows, int D, float eps,
                                     void* stream) {
   HVLM_REQUIRE(x && w && out8 && inv_scale && rows > 0, "rmsnorm_fwd_fp8: bad args");
-  HVLM_REQUIRE(D == 4096 || D == 2048, "rmsnorm_fwd_fp8: D must be 2048 or 4096 (got %d): use hvlm_rmsnorm_fwd + hvlm_quantize_fp8_rowwise", D);
+  HVLM_REQUIRE(D == 4096 || D == 2048 || D == 5120,
+               "rmsnorm_fwd_fp8: D must be 2048, 4096 or 5120 (got %d): use hvlm_rmsnorm_fwd + hvlm_quantize_fp8_rowwise", D);
+  HVLM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out8 & 7) == 0, "rmsnorm_fwd_fp8: alignment");
   if (D == 4096)
-    hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<2>, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
+    hipLaunchKernelGGL((rmsnorm_fwd_q8_kernel<2, 4096>), dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
+                       (unsigned char*)out8, inv_scale, eps);
+  else if (D == 5120)
+    hipLaunchKernelGGL((rmsnorm_fwd_q8_kernel<3, 5120>), dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
                        (unsigned char*)out8, inv_scale, eps);
   else
-    hipLaunchKernelGGL(rmsnorm_fwd_q8_kernel<1>, dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
+    hipLaunchKernelGGL((rmsnorm_fwd_q8_kernel<1, 2048>), dim3(rows), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)w,
                        (unsigned char*)out8, inv_scale, eps);
   return check_launch("rmsnorm_fwd_fp8");
 }

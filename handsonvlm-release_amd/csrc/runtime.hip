@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace hvlm {
@@ -24,7 +25,76 @@ int check_launch(const char* what) {
   return HVLM_OK;
 }
 
+// ---- switches ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Key { const char* name; int Config::*field; bool dev_only; int dflt; };
+const Key kKeys[] = {
+    {"gemm_group_m", &Config::gemm_group_m, false, 4},     {"gemm_static", &Config::gemm_static, false, 0},
+    {"gemm_tail_half", &Config::gemm_tail_half, false, 1}, {"gemm_epi_swap", &Config::gemm_epi_swap, false, 1},
+    {"attn_no_resident", &Config::attn_no_resident, false, 0},
+    {"decode_unfused", &Config::decode_unfused, false, 0}, {"skinny_per", &Config::skinny_per, false, 0},
+    {"gemm_dbg", &Config::gemm_dbg, true, 0},              {"gemm_seg4", &Config::gemm_seg4, true, 1},
+    {"gemm_m16", &Config::gemm_m16, true, 1},              {"gemm_tn_seg4", &Config::gemm_tn_seg4, true, 1},
+    {"gemm_fp8_m16", &Config::gemm_fp8_m16, true, 0},      {"attn_dkv_fused", &Config::attn_dkv_fused, true, 1},
+};
+#ifdef HVLM_DEV
+constexpr bool kDevBuild = true;
+#else
+constexpr bool kDevBuild = false;
+#endif
+const Key* find_key(const char* name) {
+  for (const Key& k : kKeys)
+    if (name && strcmp(k.name, name) == 0) return &k;
+  return nullptr;
+}
+Config load_env() {
+  Config c;
+  for (const Key& k : kKeys) {
+    char env[64] = "HVLM_";
+    size_t n = 5;
+    for (const char* s = k.name; *s && n + 1 < sizeof(env); ++s) env[n++] = (char)((*s >= 'a' && *s <= 'z') ? *s - 32 : *s);
+    env[n] = 0;
+    const char* v = getenv(env);
+    if (!v) continue;
+    const int iv = atoi(v);
+    if (k.dev_only && !kDevBuild && iv != k.dflt) {
+      fprintf(stderr, "libhvlm_hip: %s=%d ignored: that variant is compiled into development builds only (make DEV=1)\n", env, iv);
+      continue;
+    }
+    c.*(k.field) = iv;
+  }
+  if (c.gemm_group_m < 1) c.gemm_group_m = 1;
+  return c;
+}
+}  // namespace
+
+Config& config() {
+  static Config c = load_env();       // (function-local static: initialised once, thread-safe)
+  return c;
+}
+
 }  // namespace hvlm
+
+extern "C" int hvlm_configure(const char* key, int value) {
+  const hvlm::Key* k = hvlm::find_key(key);
+  HVLM_REQUIRE(k, "configure: unknown switch '%s'", key ? key : "(null)");
+  if (k->dev_only && !hvlm::kDevBuild && value != k->dflt) {
+    hvlm::set_error("configure: %s=%d selects a variant that is compiled into development builds only (make DEV=1)", key, value);
+    return HVLM_ERR_UNSUPPORTED;
+  }
+  HVLM_REQUIRE(strcmp(key, "gemm_group_m") != 0 || value >= 1, "configure: gemm_group_m must be >= 1");
+  hvlm::config().*(k->field) = value;
+  return HVLM_OK;
+}
+
+extern "C" int hvlm_config_get(const char* key, int* value) {
+  const hvlm::Key* k = hvlm::find_key(key);
+  HVLM_REQUIRE(k && value, "config_get: unknown switch '%s'", key ? key : "(null)");
+  *value = hvlm::config().*(k->field);
+  return HVLM_OK;
+}
+
+extern "C" int hvlm_is_dev_build(void) { return hvlm::kDevBuild ? 1 : 0; }
 
 extern "C" int hvlm_abi_version(void) { return HVLM_ABI_VERSION; }
 

@@ -111,3 +111,33 @@ def last_error() -> str:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         raise HvlmError(f"{what}: rc={rc}: {last_error()}")
+
+
+def configure(key: str, value: int) -> None:
+    """hvlm_configure: sets one named library switch (include/hvlm.h).  Raises HvlmError for an unknown switch, or for a
+    development-only variant in a production build."""
+    check(load().hvlm_configure(key.encode(), int(value)), f"configure({key}={value})")
+
+
+def config_get(key: str) -> int:
+    v = ctypes.c_int(0)
+    check(load().hvlm_config_get(key.encode(), ctypes.byref(v)), f"config_get({key})")
+    return v.value
+
+
+class configured:
+    """Context manager: `with configured(decode_unfused=1): ...` sets switches and restores the previous values."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = config_get(k)
+            configure(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            configure(k, v)
+        return False

@@ -57,18 +57,23 @@ def load_state(path: str) -> Dict[str, torch.Tensor]:
             return sorted(set(json.load(open(idx))["weight_map"].values()))
         return [single] if os.path.exists(os.path.join(path, single)) else None
 
+    # probe order of transformers' from_pretrained for a local directory (4.31 — the reference's pin — and later):
+    # model.safetensors, model.safetensors.index.json, pytorch_model.bin, pytorch_model.bin.index.json.  A directory re-saved
+    # by a newer transformers next to an old .bin must load the tensors the reference's builder.py would load.
     sd: Dict[str, torch.Tensor] = {}
-    files = shard_files(INDEX, "pytorch_model.bin")
-    if files is not None:
-        for f in files:
-            sd.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
-        return sd
     files = shard_files("model.safetensors.index.json", "model.safetensors")
+    if files is not None and os.path.exists(os.path.join(path, "model.safetensors")):
+        files = ["model.safetensors"]
+    if files is not None:
+        from safetensors.torch import load_file
+        for f in files:
+            sd.update(load_file(os.path.join(path, f), device="cpu"))
+        return sd
+    files = ["pytorch_model.bin"] if os.path.exists(os.path.join(path, "pytorch_model.bin")) else shard_files(INDEX, "pytorch_model.bin")
     if files is None:
-        raise FileNotFoundError(f"{path}: neither pytorch_model*.bin nor model*.safetensors found")
-    from safetensors.torch import load_file
+        raise FileNotFoundError(f"{path}: neither model*.safetensors nor pytorch_model*.bin found")
     for f in files:
-        sd.update(load_file(os.path.join(path, f), device="cpu"))
+        sd.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
     return sd
 
 
@@ -149,9 +154,13 @@ def save_pretrained(model, path: str, max_shard_bytes: int = 10 * 2 ** 30):
 TRAINER_STATE = "trainer_state.json"
 
 
-def save_training_state(opt, path: str, global_step: int, epoch: int, rank: int = 0, extra: Optional[dict] = None):
+def save_training_state(opt, path: str, global_step: int, epoch: int, rank: int = 0, extra: Optional[dict] = None,
+                        write_marker: bool = True):
     """Rank 0 writes the optimizer (fp32 master weights, both moments, step count, the CVAE head's torch optimizer) as
-    one file per gradient bucket under `path`/optimizer/ plus trainer_state.json; EVERY rank writes its RNG state."""
+    one file per gradient bucket under `path`/optimizer/ plus trainer_state.json; EVERY rank writes its RNG state.
+    trainer_state.json is the marker `latest_checkpoint` trusts: with several ranks pass write_marker=False, barrier once every
+    rank has returned, and let rank 0 call mark_complete() — so a crash while another rank is still writing leaves a directory
+    that is NOT taken for a checkpoint (hvlm/train.py::save)."""
     os.makedirs(os.path.join(path, "optimizer"), exist_ok=True)
     rng = {"cpu": torch.get_rng_state()}
     if torch.cuda.is_available():
@@ -163,9 +172,21 @@ def save_training_state(opt, path: str, global_step: int, epoch: int, rank: int 
         torch.save({n: {k: v.detach().cpu() for k, v in d.items()} for n, d in tensors.items()},
                    os.path.join(path, "optimizer", key + ".pt"))
     torch.save(opt.meta_state(), os.path.join(path, "optimizer", "meta.pt"))
+    if write_marker:
+        mark_complete(path, global_step, epoch, extra)
+
+
+def mark_complete(path: str, global_step: int, epoch: int, extra: Optional[dict] = None):
+    """Writes trainer_state.json atomically (temporary file + rename): its presence means every file of the checkpoint is
+    complete."""
     st = {"global_step": int(global_step), "epoch": int(epoch)}
     st.update(extra or {})
-    json.dump(st, open(os.path.join(path, TRAINER_STATE), "w"), indent=1)
+    tmp = os.path.join(path, TRAINER_STATE + ".tmp")
+    with open(tmp, "w") as f:
+        json.dump(st, f, indent=1)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, os.path.join(path, TRAINER_STATE))
 
 
 def load_training_state(opt, path: str, rank: int = 0) -> dict:
@@ -178,7 +199,11 @@ def load_training_state(opt, path: str, rank: int = 0) -> dict:
         opt.load_group(key, torch.load(os.path.join(odir, key + ".pt"), map_location="cpu", weights_only=True))
     opt.load_meta_state(torch.load(os.path.join(odir, "meta.pt"), map_location="cpu", weights_only=True))
     rp = os.path.join(path, f"rng_state_{rank}.pth")
-    if os.path.exists(rp):
+    if not os.path.exists(rp):
+        import warnings
+        warnings.warn(f"{rp} is missing (checkpoint written by fewer ranks?): this rank's RNG stream is NOT restored, the "
+                      "continued run will not be bit-identical to an uninterrupted one")
+    else:
         rng = torch.load(rp, map_location="cpu", weights_only=True)
         torch.set_rng_state(rng["cpu"])
         if "cuda" in rng and torch.cuda.is_available():

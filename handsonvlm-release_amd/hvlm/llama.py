@@ -258,7 +258,7 @@ class LlamaStack:
              (lambda a, k, residual=None: ops.gemm_nt(a, lp.w[k], residual=residual))
         probe = getattr(self, "_fp8_probe", None)
         # fp8 inference: RMSNorm writes the e4m3 rows + scales of the next GEMM itself (no bf16 copy, no quantise pass)
-        fuse8 = seq.fp8 and not save and probe is None and self.D in (2048, 4096) and _FP8_FUSED_NORM
+        fuse8 = seq.fp8 and not save and probe is None and self.D in (2048, 4096, 5120) and _FP8_FUSED_NORM
         if fuse8:
             xn, rstd1 = ops.rmsnorm_fwd_fp8(x, lp.w["ln1"], eps), None
         else:
@@ -363,6 +363,8 @@ class LlamaStack:
         against 5 - 6 ms of kernels): the launch sequence is captured ONCE per (batch, cache, weight format) in a hipGraph —
         positions and lengths are device tensors, nothing in it depends on the token index — and replayed per token.
         HVLM_DECODE_BATCH_GRAPH=0 issues it eagerly (bit-identical, tests/test_gpu_fp8.py)."""
+        if fp8 and getattr(self, "_fp8_rw", None) is None:
+            self.fp8_prepare_rowwise()                  # fp8_decode without an fp8 prefill: the e4m3 copies are made here
         if os.environ.get("HVLM_DECODE_BATCH_GRAPH", "1") != "1" or not x1.is_cuda:
             return self._decode_step_batched_eager(x1, lens, cache, fp8)
         wkey = self._fp8_rw[0]["qkv"][0].data_ptr() if fp8 else self.layers[0].w["qkv"].data_ptr()
@@ -399,6 +401,8 @@ class LlamaStack:
         return out
 
     def _decode_step_batched_eager(self, x1: torch.Tensor, lens: torch.Tensor, cache: List[torch.Tensor], fp8: bool = False) -> torch.Tensor:
+        if fp8 and getattr(self, "_fp8_rw", None) is None:
+            self.fp8_prepare_rowwise()
         B = x1.shape[0]
         eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
         rows = torch.arange(B, device=self.device)

@@ -659,7 +659,8 @@ class HandsOnVLMForCausalLM:
         plan = self.build_splice_plan(input_ids, None, NV, 0, True, False, pack=False)
         if attention_mask is not None:          # true prompt lengths (right padding): rows past them are pads
             am = attention_mask.detach().cpu().numpy().astype(bool)
-            npad = np.array([T - (int(np.nonzero(am[b])[0][-1]) + 1) for b in range(B)])
+            # (an all-False row = an empty prompt: one row is kept, as build_splice_plan does)
+            npad = np.array([T - (int(np.nonzero(am[b])[0][-1]) + 1 if am[b].any() else 1) for b in range(B)])
         else:
             npad = np.zeros(B, dtype=np.int64)
         S = plan.S
@@ -673,6 +674,7 @@ class HandsOnVLMForCausalLM:
         last = hidden[rows].contiguous()                                        # [B, D]
         del hidden, x
         lens = torch.from_numpy(lengths.astype(np.int32)).to(dev)
+        lens_h = lengths.astype(np.int64).copy()                                # host mirror of `lens`
         seqs = [input_ids[b, : T - npad[b]].tolist() for b in range(B)]
         hands: List[List[torch.Tensor]] = [[] for _ in range(B)]
         done = np.zeros(B, dtype=bool)
@@ -705,15 +707,19 @@ class HandsOnVLMForCausalLM:
                     if tl[b] in eos or (max_length is not None and n_new >= max_length - T):
                         done[b] = True
             cur = torch.cat([cur, toks[:, None]], dim=1)
-            if done.all() or int(lens.max()) + 1 >= max_len:
+            # the cache bounds the samples still generating; a finished sample's rows keep advancing in lock step but are
+            # never read again, so only the live ones can end the batch early
+            if done.all() or int(lens_h[~done].max()) + 1 >= max_len:
                 break
             # feed the drawn tokens back: embedding (+ the sinusoidal encoding of the hand this token just produced)
             src = toks.to(torch.int32)
             slot = torch.tensor([0 if h else -1 for h in is_hand], dtype=torch.int32, device=dev)
             x1 = ops.embed_splice_fwd(self.embed, None, src, slot, hand_new.contiguous(), torch.ones(B, device=dev), B, 1,
                                       self.token_dim, 0, 1)
+            # (finished samples stay at their last row: their writes must not run past the cache)
             last = self.stack.decode_step_batched(x1, lens, cache, fp8=fp8_decode)
-            lens = lens + 1
+            lens_h[~done] += 1
+            lens = lens + torch.from_numpy((~done).astype(np.int32)).to(dev)
         tmax = max(len(q) for q in seqs)
         out_ids = torch.full((B, tmax), pad_token_id, dtype=torch.long)
         for b in range(B):

@@ -374,7 +374,7 @@ def layernorm_fwd(x, w, b, eps: float, out=None):
 
 
 def rmsnorm_fwd_fp8(x: torch.Tensor, w: torch.Tensor, eps: float):
-    """RMSNorm of bf16 rows (D = 2048 / 4096) written as (e4m3 bytes, inv_scale) == quantize_fp8_rowwise(rmsnorm_fwd(x)[0])."""
+    """RMSNorm of bf16 rows (D = 2048 / 4096 / 5120) written as (e4m3 bytes, inv_scale) == quantize_fp8_rowwise(rmsnorm_fwd(x)[0])."""
     _chk(x, BF16, "rmsnorm_fp8.x"); _chk(w, BF16, "rmsnorm_fp8.w")
     assert x.is_contiguous()
     D = x.shape[-1]

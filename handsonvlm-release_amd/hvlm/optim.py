@@ -59,6 +59,13 @@ class AdamW:
         self._open = None                  # (lr, grad_scale) between begin_step() and step()
         self._done = set()
 
+    def _weights_changed(self):
+        """The bf16 weights are about to be / were rewritten in place: the e4m3 copies made from them (fp8 evaluation, and the
+        decode graphs captured on those copies) are stale — drop them; they are rebuilt lazily at the next fp8 call."""
+        stack = getattr(self.model, "stack", None)
+        if stack is not None and hasattr(stack, "invalidate_fp8"):
+            stack.invalidate_fp8()
+
     def _update(self, sts, lr, grad_scale):
         b1, b2 = self.betas
         for st in sts:
@@ -70,6 +77,7 @@ class AdamW:
         self.step_count += 1
         self._open = (self.lr if lr is None else lr, grad_scale)
         self._done = set()
+        self._weights_changed()
 
     def bucket_ready(self, key: str, after=()):
         """The gradients of bucket `key` are final once the work handles in `after` (its all-reduces) complete, or —
@@ -91,6 +99,7 @@ class AdamW:
     def step(self, lr: Optional[float] = None, grad_scale: float = 1.0):
         """grad_scale multiplies every gradient (1/world_size after a SUM all-reduce).  After begin_step(): finishes
         the step (buckets not yet updated + the CVAE head) and joins the optimizer stream."""
+        self._weights_changed()
         if self._open is None:
             self.step_count += 1
             lr = self.lr if lr is None else lr
@@ -122,6 +131,7 @@ class AdamW:
             st["master"].copy_(st["w"].to(torch.float32))
             st["m"].zero_(); st["v"].zero_()
         self.step_count = 0
+        self._weights_changed()                     # (the weights were loaded behind the optimizer's back)
 
     def state_groups(self):
         """Yields (bucket key, {tensor name: {"master","m","v"}}) — one checkpoint shard per gradient bucket."""
@@ -132,6 +142,7 @@ class AdamW:
         return {"step_count": self.step_count, "head": self.head.state_dict()}
 
     def load_group(self, key: str, tensors: dict):
+        self._weights_changed()
         for st in self.groups[key]:
             src = tensors[st["name"]]
             for k in ("master", "m", "v"):

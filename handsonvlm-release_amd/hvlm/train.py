@@ -77,9 +77,16 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
         path = os.path.join(output_dir, f"checkpoint-{step}")
         if rank == 0:
             checkpoint.save_pretrained(model, path)
-        if torch.distributed.is_initialized():
+        dist = torch.distributed.is_initialized()
+        if dist:
             torch.distributed.barrier()                               # the directory exists before the other ranks write
-        checkpoint.save_training_state(opt, path, step, step // per_epoch, rank)
+        checkpoint.save_training_state(opt, path, step, step // per_epoch, rank, write_marker=False)
+        if dist:
+            torch.distributed.barrier()                               # every rank's RNG file / every optimizer shard is on disk ...
+        if rank == 0:
+            checkpoint.mark_complete(path, step, step // per_epoch)   # ... before the marker latest_checkpoint() trusts appears
+        if dist:
+            torch.distributed.barrier()
         last_saved = step
 
     epoch = step // per_epoch

@@ -46,6 +46,20 @@ int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int 
  * for a collective running beside the compute stream (tools/contention_bench.py). */
 int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
 
+/* Library switches.  Every A/B switch of the library is one named integer: initialised ONCE, at the library's first use, from
+ * the environment variable HVLM_<KEY IN CAPITALS>, changed at run time through hvlm_configure; no entry point reads the
+ * environment.  Production switches: "gemm_group_m" (row panels per group of the XCD-aware tile order, default 4),
+ * "gemm_static" (1: static tile assignment), "gemm_tail_half" (1: the last partial round of GEMM tiles runs as half-tile
+ * units), "gemm_epi_swap" (1: register-exchange GEMM epilogue), "attn_no_resident" (1: CLIP attention on the streaming kernel),
+ * "decode_unfused" (1: RoPE / split combine of the native decode step as separate launches), "skinny_per" (forced K-slice of
+ * the weight-streaming GEMM).  Switches that select a superseded kernel variant or the K-loop ablation kernel ("gemm_dbg",
+ * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "attn_dkv_fused") exist in development builds only
+ * (`make DEV=1`; hvlm_is_dev_build() == 1): a production build returns HVLM_ERR_UNSUPPORTED for any non-default value, and
+ * does not contain those kernels.  Not thread-safe against concurrent launches (set switches before issuing work). */
+int hvlm_configure(const char* key, int value);
+int hvlm_config_get(const char* key, int* value);
+int hvlm_is_dev_build(void);
+
 /* ------------------------------------------------------------------------------------------ *
  * GEMM (MFMA, bf16 in, fp32 accumulate)
  *   C[M,N] = act(A[M,K] @ B[N,K]^T + bias[N]) + residual[M,N]
@@ -373,15 +387,15 @@ int hvlm_hand_gather_bwd(const void* dout, const int32_t* rows, void* dhidden, i
 int hvlm_gemm_f16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                      const void* bias, const void* residual, int ldr, int act, int out_f32, void* stream);
 int hvlm_layernorm_fwd_f16(const void* x, const void* w, const void* b, void* y, int rows, int D, float eps, void* stream);
+/* RMSNorm with an e4m3 row output (== hvlm_quantize_fp8_rowwise of hvlm_rmsnorm_fwd's output, bit for bit): the input of the
+ * q|k|v and gate|up GEMMs of the decoder's fp8 prefill (LlamaRMSNorm input_layernorm / post_attention_layernorm).
+ * D = 2048, 4096 (7B) or 5120 (13B). */
+int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_scale, int rows, int D, float eps, void* stream);
 /* LayerNorm (bf16 in, as hvlm_layernorm_fwd) whose output row is written as e4m3 bytes with one scale per row: out8[r, :] and
  * inv_scale[r] are bit-identical to hvlm_quantize_fp8_rowwise of hvlm_layernorm_fwd's bf16 output — the input of the q|k|v
  * and fc1 GEMMs of the CLIP tower in the fp8 forward (BASELINE config 5; CLIPEncoderLayer.layer_norm1 / layer_norm2).
  * next_inv (optional): next_inv[r] = (|y_r|_2 * bound_mul + bound_add) / 448 with y_r the bf16 output row — the output scale of
  * a GEMM that consumes this row and writes e4m3 itself (hvlm_gemm_fp8_nt_scaled_q8). */
-/* RMSNorm with the same e4m3 row output (== hvlm_quantize_fp8_rowwise of hvlm_rmsnorm_fwd's output, bit for bit): the input of
- * the q|k|v and gate|up GEMMs of the decoder's fp8 prefill (LlamaRMSNorm input_layernorm / post_attention_layernorm).
- * D = 2048 or 4096. */
-int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_scale, int rows, int D, float eps, void* stream);
 int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
                            float bound_mul, float bound_add, int rows, int D, float eps, void* stream);
 int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,
@@ -401,11 +415,11 @@ int hvlm_cast_f16_to_bf16(const void* in, void* out, long n, void* stream);
 int hvlm_adamw_step(float* master, float* m, float* v, const void* grad, void* w, void* wt, int R,
                     int C, float lr, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, int step, void* stream);
-/* y = a + b (bf16, n elements). */
 /* Prefill -> KV cache of lock-step generation: the k | v columns of qkv [B * S, 3D] (fused q|k|v rows after RoPE) are copied to
  * cache [B, max_len, 3D] rows 0 .. S-1 of every sample (columns D .. 3D; the q columns of the cache are never read).
  * Replaces the `past_key_value` concatenation of LlamaAttention.forward under use_cache. */
 int hvlm_kv_cache_fill(const void* qkv, void* cache, int B, int S, int max_len, int D, void* stream);
+/* y = a + b (bf16, n elements). */
 int hvlm_add_bf16(const void* a, const void* b, void* y, long n, void* stream);
 /* f32 -> bf16 and bf16 -> f32 casts (n elements). */
 int hvlm_cast_f32_to_bf16(const float* in, void* out, long n, void* stream);

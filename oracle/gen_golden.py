@@ -14,6 +14,8 @@ Fixtures:
   g5_cvae.npz        TrajCVAE.forward / .inference at token_dim 2048 with fixed noise
   g6_sample.npz      HandsOnVLMForCausalLM.sample() trace with forced tokens (sequences, pred_hands)
   g7_traj_eval.npz   evaluate_traj_stochastic known answer (pins the ADE/FDE label swap)
+  g3_forward_dh128.npz / g3_bf16_dh128.npz / g6_sample_dh128.npz   (`g23_dh128`, `g3bf16_dh128`)
+                     the same end-to-end fixtures on synth.MID: D = 256, H = 2 -> dh = 128, the production head size
 """
 import os
 import sys
@@ -114,7 +116,8 @@ def build_reference_model(cfg):
     return model
 
 
-def g2_g3(cfg):
+def g2_g3(cfg, tag=""):
+    """tag "": the TINY family (dh = 64), also writes g2_splice; tag "_dh128": synth.MID (dh = 128), g3 / g6 only."""
     model = build_reference_model(cfg)
     model.train()
     B, T = 2, 24
@@ -129,7 +132,8 @@ def g2_g3(cfg):
     with torch.no_grad():
         _, am, _, emb, lab = model.prepare_inputs_labels_for_multimodal(
             ids, mask, None, labels, images, future_hands=fh[:, :, 1:, :], future_valid=fv.clone(), is_evaluate=False)
-    save("g2_splice.npz", inputs_embeds=emb, labels=lab, attention_mask=am.to(torch.int64))
+    if not tag:
+        save("g2_splice.npz", inputs_embeds=emb, labels=lab, attention_mask=am.to(torch.int64))
 
     # ---- G3: full forward + backward -------------------------------------------------------------
     torch.manual_seed(123)
@@ -142,7 +146,7 @@ def g2_g3(cfg):
     sd = dict(model.named_parameters())
     # recompute the loss components the same way the reference does, for the record
     hidden = out.hidden_states[-1]
-    save("g3_forward.npz",
+    save(f"g3_forward{tag}.npz",
          loss=out.loss, eps_noise=eps_noise,
          logits_slice=out.logits[:, ::7, ::251], logits_last=out.logits[:, -1, :],
          hidden=hidden,
@@ -187,7 +191,7 @@ def g2_g3(cfg):
                               attention_mask=torch.ones_like(prompt, dtype=torch.bool))
     finally:
         torch.randn = real_randn
-    save("g6_sample.npz", prompt=prompt, forced=np.array(forced), sequences=so.sequences, pred_hands=so.pred_hands,
+    save(f"g6_sample{tag}.npz", prompt=prompt, forced=np.array(forced), sequences=so.sequences, pred_hands=so.pred_hands,
          z=torch.stack(zs, 0))
 
 
@@ -275,9 +279,10 @@ if __name__ == "__main__":
     if "g5" in which: g5_cvae()
     if "g4" in which: g4_ops()
     if "g23" in which: g2_g3(synth.TINY)
+    if "g23_dh128" in which: g2_g3(synth.MID, "_dh128")
 
 
-def g3_bf16(cfg):
+def g3_bf16(cfg, tag=""):
     """The bf16-EAGER envelope of G3: the same reference model and batch as g2_g3, but run the way the reference trains
     (`--bf16 True`, scripts/finetune.sh:15): every LLM / projector / head module in bfloat16, the CLIP tower in float16
     (handsonvlm/train/train.py:316), PyTorch eager kernels with their own fp32 accumulation.  Its distance from the fp32
@@ -305,7 +310,7 @@ def g3_bf16(cfg):
     out.loss.backward()
     sd = dict(model.named_parameters())
     f = lambda t: t.detach().float()  # noqa: E731
-    save("g3_bf16.npz", loss=f(out.loss), logits_slice=f(out.logits[:, ::7, ::251]), hidden=f(out.hidden_states[-1]),
+    save(f"g3_bf16{tag}.npz", loss=f(out.loss), logits_slice=f(out.logits[:, ::7, ::251]), hidden=f(out.hidden_states[-1]),
          g_proj_w=f(sd["model.mm_projector.weight"].grad), g_proj_b=f(sd["model.mm_projector.bias"].grad),
          g_q0=f(sd["model.layers.0.self_attn.q_proj.weight"].grad),
          g_down1=f(sd["model.layers.1.mlp.down_proj.weight"].grad),
@@ -317,3 +322,5 @@ def g3_bf16(cfg):
 
 if __name__ == "__main__" and "g3bf16" in sys.argv[1:]:
     g3_bf16(synth.TINY)
+if __name__ == "__main__" and "g3bf16_dh128" in sys.argv[1:]:
+    g3_bf16(synth.MID, "_dh128")

@@ -15,6 +15,9 @@ VOCAB = 32101
 
 TINY = dict(D=128, H=2, L=2, FFN=256, clip_d=64, clip_heads=1, clip_layers=3, clip_mlp=128,
             image=224, patch=14, frames=100, vocab=VOCAB)
+# the same family at the PRODUCTION head size (dh = D / H = 128, the causal dh-128 attention path of Vicuna-7B/13B): the
+# end-to-end fixtures g3_forward_dh128 / g3_bf16_dh128 / g6_sample_dh128 are written from the reference on this config
+MID = dict(TINY, D=256, FFN=512)
 
 
 def _rs(seed):

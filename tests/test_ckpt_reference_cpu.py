@@ -109,3 +109,21 @@ def test_safetensors_variant_and_adapter_override(tmp_path, monkeypatch):
     got = out.logits.float()[:, ::7, ::251][valid[:, ::7]]
     assert rel(got, exp["logits_slice_adapter"][valid[:, ::7].numpy()]) < 1.5e-2
     assert rel(got, exp["logits_slice"][valid[:, ::7].numpy()]) > 5e-2            # the adapter did change the output
+
+
+def test_load_state_probe_order_is_transformers(tmp_path):
+    """A directory holding BOTH a stale pytorch_model.bin and a model.safetensors (re-saved by a newer transformers) loads
+    the safetensors file — the order transformers' from_pretrained (called by handsonvlm/model/builder.py:93,158) probes a
+    local directory in: model.safetensors, model.safetensors.index.json, pytorch_model.bin, pytorch_model.bin.index.json."""
+    import torch
+    from safetensors.torch import save_file
+    from hvlm import checkpoint
+    torch.save({"w": torch.zeros(3)}, tmp_path / "pytorch_model.bin")
+    save_file({"w": torch.ones(3)}, str(tmp_path / "model.safetensors"))
+    assert torch.equal(checkpoint.load_state(str(tmp_path))["w"], torch.ones(3))
+    (tmp_path / "model.safetensors").unlink()
+    assert torch.equal(checkpoint.load_state(str(tmp_path))["w"], torch.zeros(3))
+    (tmp_path / "pytorch_model.bin").unlink()
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_state(str(tmp_path))

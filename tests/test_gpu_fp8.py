@@ -208,7 +208,7 @@ def test_gemm_fp8_e4m3_output_with_row_bounds(ops, M, N, K, act):
     assert ratio < 64.0, ratio                     # how far above the true row maximum the bound sits (binades lost: log2)
 
 
-@pytest.mark.parametrize("rows,D", [(333, 4096), (17, 2048)])
+@pytest.mark.parametrize("rows,D", [(333, 4096), (17, 2048), (77, 5120)])
 def test_rmsnorm_fp8_equals_rmsnorm_then_rowwise_quantise(ops, rows, D):
     g = torch.Generator(device="cuda").manual_seed(D + rows)
     x = (torch.randn(rows, D, device="cuda", generator=g) * 2.1).to(BF)

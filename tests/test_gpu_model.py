@@ -24,10 +24,13 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def tiny_model(training=True, **cfg_kw):
+FAMILIES = {"": synth.TINY, "_dh128": synth.MID}     # fixture tag -> config: dh = 64, and the production head size dh = 128
+
+
+def tiny_model(training=True, family=None, **cfg_kw):
     from hvlm.config import CLIPVisionConfig, HandsOnVLMConfig
     from hvlm.model import HandsOnVLMForCausalLM
-    c = synth.TINY
+    c = family or synth.TINY
     cfg = HandsOnVLMConfig(hidden_size=c["D"], intermediate_size=c["FFN"], num_hidden_layers=c["L"],
                            num_attention_heads=c["H"], mm_hidden_size=c["clip_d"],
                            vision=CLIPVisionConfig(hidden_size=c["clip_d"], intermediate_size=c["clip_mlp"],
@@ -48,10 +51,13 @@ def tiny_batch():
     return ids, labels, mask, images, fh, fv
 
 
+@pytest.mark.parametrize("tag", list(FAMILIES))
 @pytest.mark.parametrize("project_after_pool", [True, False])
-def test_forward_backward_vs_reference_golden(golden, project_after_pool):
-    g3 = golden("g3_forward.npz")
-    m, cfg = tiny_model(project_after_pool=project_after_pool)
+def test_forward_backward_vs_reference_golden(golden, project_after_pool, tag):
+    """tag "_dh128": the same end-to-end check on synth.MID (D = 256, H = 2 -> dh = 128): the causal dh-128 attention forward /
+    backward kernels of the 7B / 13B decoder inside a REFERENCE-pinned end-to-end run, with the same envelope assertion."""
+    g3 = golden(f"g3_forward{tag}.npz")
+    m, cfg = tiny_model(project_after_pool=project_after_pool, family=FAMILIES[tag])
     ids, labels, mask, images, fh, fv = tiny_batch()
     out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh.clone(),
             contact_point=torch.zeros(2, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(2),
@@ -77,19 +83,19 @@ def test_forward_backward_vs_reference_golden(golden, project_after_pool):
     hp = dict(m.hand_traj_decoder.named_parameters())
     r["g_cvae_enc"] = rel(hp["hand_traj_decoder.cvae.enc_MLP.0.weight"].grad[::8, ::4], g3["g_cvae_enc"])
     r["g_cvae_dec2"] = rel(hp["hand_traj_decoder.cvae.dec_MLP.2.weight"].grad, g3["g_cvae_dec2"])
-    REPORT[f"g3_pap{int(project_after_pool)}"] = r
+    REPORT[f"g3{tag}_pap{int(project_after_pool)}"] = r
     print(json.dumps(r, indent=1))
     # Parity statement (north_star: <= 1e-3 rel in bf16 — reachable per op, tests/test_gpu_ops.py; end to end the yardstick is
     # what bf16 itself costs on this path): g3_bf16.npz is the REFERENCE run bf16-eager (LLM bf16, tower fp16, as it trains;
     # oracle/gen_golden.py::g3_bf16) on the same inputs; its distance from the fp32 golden is the envelope.  The HIP path
     # must sit within 1.25x of that envelope per tensor, and under absolute caps at 1.5x the round-1 measurements.
-    env = golden("g3_bf16.npz")
+    env = golden(f"g3_bf16{tag}.npz")
     envelope = {"hidden_rel": rel(T(env["hidden"])[valid], g3["hidden"][valid.numpy()]),
                 "logits_rel": rel(T(env["logits_slice"])[valid[:, ::7]], g3["logits_slice"][valid[:, ::7].numpy()])}
     for k in ("g_proj_w", "g_proj_b", "g_q0", "g_down1", "g_ln0", "g_norm", "g_embed_hand", "g_embed_rows", "g_lm_head_rows"):
         envelope[k] = rel(T(env[k]), g3[k])
     r["bf16_eager_reference_envelope"] = envelope
-    REPORT[f"g3_pap{int(project_after_pool)}"] = r
+    REPORT[f"g3{tag}_pap{int(project_after_pool)}"] = r
     assert abs(r["loss"] - r["loss_ref"]) / r["loss_ref"] < 2e-3           # bf16-eager reference: 6.3e-3
     for k, e in envelope.items():
         assert r[k] <= 1.25 * e, (k, r[k], e)
@@ -127,12 +133,14 @@ def test_mixed_text_only_batch_backward_vs_oracle():
         assert rel(named[ours], p[theirs].grad) < 3e-2, (ours, rel(named[ours], p[theirs].grad))
 
 
+@pytest.mark.parametrize("tag", list(FAMILIES))
 @pytest.mark.parametrize("use_kv_cache", [True, False])
-def test_sample_vs_reference_golden(golden, use_kv_cache):
+def test_sample_vs_reference_golden(golden, use_kv_cache, tag):
     """The reference's sample() re-runs the whole prefix per token (use_cache=False); both our cache-less loop and the
-    KV-cached loop (prefill + single-token decode kernels) must reproduce its trace."""
-    g = golden("g6_sample.npz")
-    m, cfg = tiny_model(training=False)
+    KV-cached loop (prefill + single-token decode kernels) must reproduce its trace.  tag "_dh128": the reference's trace on
+    synth.MID — sample() pinned at the production head size (dh = 128 decode attention / GEMV kernels)."""
+    g = golden(f"g6_sample{tag}.npz")
+    m, cfg = tiny_model(training=False, family=FAMILIES[tag])
     ids, labels, mask, images, fh, fv = tiny_batch()
     forced = [int(t) for t in g["forced"]]
     n0 = g["prompt"].shape[1]
@@ -148,7 +156,7 @@ def test_sample_vs_reference_golden(golden, use_kv_cache):
     assert np.array_equal(so.sequences.cpu().numpy(), g["sequences"])
     assert so.pred_hands.shape == (1, 2, 4, 2)
     r = rel(so.pred_hands, g["pred_hands"])
-    REPORT[f"g6_pred_hands_rel_kv{int(use_kv_cache)}"] = r
+    REPORT[f"g6{tag}_pred_hands_rel_kv{int(use_kv_cache)}"] = r
     print("pred_hands rel", r, so.pred_hands.flatten().tolist(), g["pred_hands"].flatten().tolist())
     assert r < 5e-2     # bf16 hidden state feeding an fp32 head
     # "eval traj ADE/FDE parity" (BASELINE.json metric): the metrics of the HIP trajectory vs those of the
@@ -158,13 +166,16 @@ def test_sample_vs_reference_golden(golden, use_kv_cache):
     valid = np.ones((1, 2), np.float32)
     ours = evaluate_traj_stochastic(so.pred_hands.cpu().numpy()[:, None], gt, valid)
     ref = R.evaluate_traj_stochastic(g["pred_hands"][:, None], gt, valid)
-    REPORT[f"g6_ade_fde_wde_kv{int(use_kv_cache)}"] = dict(hip=[float(x) for x in ours], reference=[float(x) for x in ref])
+    REPORT[f"g6{tag}_ade_fde_wde_kv{int(use_kv_cache)}"] = dict(hip=[float(x) for x in ours], reference=[float(x) for x in ref])
     np.testing.assert_allclose(ours, ref, rtol=1e-2)
 
 
-def test_cvae_head_bit_exact_given_identical_inputs(golden):
-    """north_star: trajectory coords bit-exact in fp32 — meaningful given identical head inputs
-    (SURVEY.md §7): the PyTorch head on the GPU vs the reference's CPU output."""
+def test_cvae_head_on_gpu_within_ulps_of_reference_given_identical_inputs(golden):
+    """north_star asks for trajectory coordinates bit-exact in fp32.  That holds on a CPU (tests/test_abi_and_host.py::
+    test_cvae_head_matches_reference_golden_cpu: array_equal with the reference's output).  On the GPU the head's three
+    nn.Linear run on hipBLASLt, whose fp32 summation order over K = 2304 / 512 differs from the CPU GEMM's, so bit equality
+    with a CPU-generated golden is unreachable through the vendor library; what is asserted is an ULP bound: every decoded
+    coordinate within 32 ulp of the LARGEST coordinate's magnitude (2^-18 relative to max |x|), the loss sums within 2e-6."""
     from hvlm.traj_decoder import CVAETrajDecoder
     g = golden("g5_cvae.npz")
     dec = CVAETrajDecoder(token_dim=2048)
@@ -173,10 +184,13 @@ def test_cvae_head_bit_exact_given_identical_inputs(golden):
     dec = dec.cuda()
     emb = T(g["emb"]).float().cuda()
     loss = dec(emb, T(g["fh"]).cuda(), T(g["fv"]).cuda(), 1.0, 1e-3, eps=T(g["eps_noise"]).cuda())
-    inf = dec.inference(emb[:, :, :1], T(g["z"]).cuda())
-    np.testing.assert_allclose(loss["traj_loss"].item(), g["traj_loss"], rtol=2e-5)
-    np.testing.assert_allclose(loss["traj_kl_loss"].item(), g["kl_loss"], rtol=2e-5)
-    np.testing.assert_allclose(inf.detach().cpu().numpy(), g["inference"], rtol=1e-4, atol=1e-5)
+    inf = dec.inference(emb[:, :, :1], T(g["z"]).cuda()).detach().cpu().numpy()
+    np.testing.assert_allclose(loss["traj_loss"].item(), g["traj_loss"], rtol=2e-6)
+    np.testing.assert_allclose(loss["traj_kl_loss"].item(), g["kl_loss"], rtol=2e-6)
+    err = np.abs(inf - g["inference"]).max()
+    ulp32 = 2.0 ** -18 * np.abs(g["inference"]).max()
+    REPORT["g5_cvae_gpu_max_err_over_ulp_of_max"] = float(err / (2.0 ** -23 * np.abs(g["inference"]).max()))
+    assert err <= ulp32, (err, ulp32)
 
 
 def test_dedup_frames_identical():
@@ -236,6 +250,7 @@ def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
     """The decode step replayed from ONE captured hipGraph (position on the device, hvlm_llama_decode_step_dev) against the
     eagerly launched step (hvlm_llama_decode_step): hidden states and the KV rows it writes bit-identical over several
     tokens, across a restart at an earlier position (next sample), with the cache's last row untouched by the capture."""
+    from hvlm import _lib
     m, cfg = tiny_model(training=False)
     st, D = m.stack, cfg.hidden_size
     cache = st.new_cache(64)
@@ -250,7 +265,7 @@ def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
     for mode in ("0", "1", "unfused"):
         # "unfused": RoPE and the combine of the key splits as separate launches (the fused attention kernel is the default)
         monkeypatch.setenv("HVLM_DECODE_GRAPH", "0" if mode == "unfused" else mode)
-        monkeypatch.setenv("HVLM_DECODE_UNFUSED", "1" if mode == "unfused" else "0")
+        _lib.configure("decode_unfused", 1 if mode == "unfused" else 0)
         for c, s0 in zip(cache, snap):
             c.copy_(s0)
         hs = [st.decode_step(x1, 20 + i, cache).clone() for i, x1 in enumerate(xs)]
@@ -258,6 +273,7 @@ def test_graph_replayed_decode_bit_identical_to_eager(monkeypatch):
         hs.append(st.decode_step(xs[1], 20, cache).clone())          # a new sample restarts at an earlier position
         hs.append(st.decode_step(xs[2], 21, cache).clone())
         res[mode] = (hs, rows, [c[63].clone() for c in cache])
+    _lib.configure("decode_unfused", 0)
     assert st._dec_graph is not None
     D3 = 2 * D                                                       # compare the K and V parts of the rows (q is scratch)
     for other in ("1", "unfused"):

@@ -494,11 +494,8 @@ def test_gemm_dynamic_scheduling_under_contention(ops):
         busy = ops.gemm_nt(a, b, bias=bias)
         torch.cuda.synchronize()
         assert torch.equal(busy, quiet), occ
-    os.environ["HVLM_GEMM_STATIC"] = "1"
-    try:
+    with _lib.configured(gemm_static=1):
         static = ops.gemm_nt(a, b, bias=bias)
-    finally:
-        del os.environ["HVLM_GEMM_STATIC"]
     assert torch.equal(static, quiet)
     ref = a.float() @ b.float().t() + bias.float()
     assert rel(quiet, ref.to(BF)) <= 1e-3

@@ -73,11 +73,9 @@ def test_clip_resident_attention_many_items_per_workgroup(ops, B, H):
     lse_ref = torch.logsumexp((x[0] @ x[1].transpose(-1, -2)) * dh ** -0.5, -1)
     assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-2
     # the streaming kernel (the fallback for S > 288) on the same data: same function, different kernel
-    os.environ["HVLM_ATTN_NO_RESIDENT"] = "1"
-    try:
+    from hvlm import _lib
+    with _lib.configured(attn_no_resident=1):
         o2, _ = ops.attn_fwd(qkv, B, S, H, dh, False, dh ** -0.5)
-    finally:
-        del os.environ["HVLM_ATTN_NO_RESIDENT"]
     assert rel(o2, o) <= 4e-3
 
 

@@ -136,3 +136,39 @@ def test_text_only_sample_gets_zero_projector_gradient(monkeypatch):
     gw, gb = grads(ids1)
     monkeypatch.undo()
     assert torch.isfinite(gw.float()).all() and torch.isfinite(gb.float()).all() and gw.float().abs().sum() > 0
+
+
+def test_checkpoint_marker_is_written_last_and_fp8_copies_follow_the_weights(tmp_path, monkeypatch):
+    """(i) a checkpoint directory becomes visible to latest_checkpoint() only through mark_complete(), which rank 0 calls after
+    every rank has written its files (hvlm/train.py::save); a missing per-rank RNG file is reported on resume;
+    (ii) any in-place rewrite of the bf16 weights by the optimizer (step / load_group / reload_from_model) drops the e4m3 copies
+    an fp8 evaluation made from them, so the next fp8 call re-quantises the NEW weights."""
+    import warnings
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from hvlm import checkpoint
+    from hvlm.optim import AdamW
+    from hvlm.train import latest_checkpoint
+    m, _ = _tiny()
+    opt = AdamW(m, lr=1e-3)
+    path = tmp_path / "out" / "checkpoint-3"
+    checkpoint.save_pretrained(m, str(path))
+    checkpoint.save_training_state(opt, str(path), 3, 0, rank=0, write_marker=False)
+    assert latest_checkpoint(str(tmp_path / "out")) is None                 # optimizer shards on disk, marker not yet
+    checkpoint.mark_complete(str(path), 3, 0)
+    assert latest_checkpoint(str(tmp_path / "out")) == str(path)
+    assert not os.path.exists(path / (checkpoint.TRAINER_STATE + ".tmp"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        checkpoint.load_training_state(opt, str(path), rank=1)               # rank 1 never wrote an RNG file
+    assert any("rng_state_1.pth" in str(x.message) for x in w)
+    # (ii)
+    m.stack._fp8_rw = ["stale"]
+    opt.load_group("layers.0", torch.load(path / "optimizer" / "layers.0.pt", weights_only=True))
+    assert m.stack._fp8_rw is None
+    m.stack._fp8_rw = ["stale"]
+    opt.reload_from_model()
+    assert m.stack._fp8_rw is None
+    m.stack._fp8_rw = ["stale"]
+    opt.step()
+    assert m.stack._fp8_rw is None

@@ -74,7 +74,8 @@ def group_sweep():
         out = torch.empty(M, N, dtype=BF, device=dev)
         row = {}
         for gm in (1, 2, 4, 8, 16, 64):
-            os.environ["HVLM_GEMM_GROUP_M"] = str(gm)
+            from hvlm import _lib as _hl
+            _hl.configure("gemm_group_m", gm)
             ms = min(timeit(lambda: ops.gemm_nt(a, b, out=out), iters=8, warmup=2) for _ in range(2))
             row[gm] = round(2.0 * M * N * K / ms / 1e9, 1)
         print(f"group {M}x{N}x{K}", row, flush=True)

@@ -35,8 +35,8 @@ print(f"rmsnorm_bwd(+add, +reduce) {R}x{D}: {ms*1e3:.0f} us  {4*R*D*2/ms/1e6:.0f
 B, S, H, dh = 400, 257, 16, 64
 qkv = (torch.randn(B * S, 3 * H * dh, device=dev) * 0.5).to(BF)
 for name, env, ks in (("resident", None, "2"), ("streaming", "1", "1")):
-    if env: os.environ["HVLM_ATTN_NO_RESIDENT"] = env
-    else: os.environ.pop("HVLM_ATTN_NO_RESIDENT", None)
+    from hvlm import _lib as _hl
+    _hl.configure("attn_no_resident", 1 if env else 0)
     os.environ["HVLM_ATTN_KSTEP"] = ks
     ms = timeit(lambda: ops.attn_fwd(qkv, B, S, H, dh, False, dh ** -0.5))
     print(f"CLIP attention fwd {name} B={B} S={S} H={H}: {ms*1e3:.0f} us  {4*S*S*dh*H*B/ms/1e9:.0f} TF/s (algorithmic)")
