@@ -167,22 +167,28 @@ class GemmEvents:
 def pmc_traffic(ev, args):
     """roofline.traffic: L2-miss (fabric / HBM side) bytes per GEMM launch from PMC counters.  A `--pmc` pass cannot wrap
     the ~3000-dispatch step on this pool, so the counters were collected per distinct GEMM shape in isolation
-    (tools/gemm_traffic.py: FETCH_SIZE and WRITE_SIZE alone in their passes, FETCH_SIZE x2 on gfx950) and are committed in
-    profiles/r02i_gemm_traffic.json; here they are weighted by the launches of THIS run.  null when the run contains a
-    shape that was not measured (other model / batch)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02i_gemm_traffic.json")
-    if not ev.pairs or not os.path.exists(path):
-        return None, "no PMC table (profiles/r02i_gemm_traffic.json)"
-    table = {(r["M"], r["N"], r["K"]): r["fetch_bytes"] + r["write_bytes"] for r in json.load(open(path))["per_shape"]}
-    tot = algo = 0.0
-    for _, _, _, shp in ev.pairs:
-        if shp not in table:
-            return None, f"GEMM shape {shp} of this run is not in profiles/r02i_gemm_traffic.json"
-        tot += table[shp]
-        algo += 2.0 * (shp[0] * shp[2] + shp[1] * shp[2] + shp[0] * shp[1])
-    return tot / ev.kernels, ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, collected per GEMM shape in isolation, all kernel launches of a "
-                              "call summed (tools/gemm_traffic.py -> profiles/r02i_gemm_traffic.json), weighted by this run's calls and "
-                              f"divided by its kernel launches; algorithmic operand+output bytes per launch: {algo / ev.kernels / 1e9:.2f} GB")
+    (tools/gemm_traffic_all.py: FETCH_SIZE and WRITE_SIZE alone in their passes, FETCH_SIZE x2 on gfx950) and are committed as
+    profiles/r*_gemm_traffic.json; the newest table that holds every shape of THIS run is weighted by this run's launches.
+    null when no table covers the run (other model / batch)."""
+    import glob
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    if not ev.pairs:
+        return None, "no GEMM events"
+    shapes = {shp for _, _, _, shp in ev.pairs}
+    missing = None
+    for path in sorted(glob.glob(os.path.join(pdir, "r*_gemm_traffic.json")), reverse=True):      # newest round first
+        table = {(r["M"], r["N"], r["K"]): r["fetch_bytes"] + r["write_bytes"] for r in json.load(open(path))["per_shape"]}
+        lack = sorted(shapes - set(table))
+        if lack:
+            missing = missing or (os.path.basename(path), lack[0])
+            continue
+        tot = sum(table[shp] for _, _, _, shp in ev.pairs)
+        algo = sum(2.0 * (shp[0] * shp[2] + shp[1] * shp[2] + shp[0] * shp[1]) for _, _, _, shp in ev.pairs)
+        name = os.path.basename(path)
+        return tot / ev.kernels, ("PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, collected per GEMM shape in isolation, all kernel launches of a "
+                                  f"call summed (tools/gemm_traffic_all.py -> profiles/{name}), weighted by this run's calls and "
+                                  f"divided by its kernel launches; algorithmic operand+output bytes per launch: {algo / ev.kernels / 1e9:.2f} GB")
+    return None, (f"GEMM shape {missing[1]} of this run is not in profiles/{missing[0]}" if missing else "no PMC table under profiles/")
 
 
 def _physical_cores():
@@ -355,7 +361,46 @@ def eval_leg(model, cfg, T, device):
         torch.cuda.synchronize()
         dtb = time.perf_counter() - t0
         res["batched"] = {"batch": Bb, "samples_per_s": Bb / dtb, "ms_per_batch": dtb * 1e3, "hands_decoded": ob.num_hands[0],
-                          "note": "lock-step generation of 32 samples, CLIP on all 100 frames of each (bench.py --fp8-eval: fp8 prefill, de-dup)"}
+                          "note": "lock-step generation of 32 samples, CLIP on all 100 frames of each, bf16 (fp16 tower)"}
+        # BASELINE config 5 on the same resident model and batch: e4m3 CLIP-tower GEMMs, e4m3 decoder prefill (per-token / per-channel
+        # scales), e4m3-weight decode steps.  Its own roofline: the e4m3 prefill GEMM launches against the 5 PFLOP/s dense fp8 peak.
+        from hvlm import ops
+        ev8 = GemmEvents()
+        prev_hook = ops._gemm_hook
+        try:
+            def run_b8():
+                return model.sample_batch(idb, logits_processor=[force_b], max_length=T + len(forced), eos_token_id=2, image=imgb,
+                                          fp8=True, fp8_decode=True, fp8_clip=True)
+            o8 = run_b8()                                  # warm-up: quantises the weights once, captures the e4m3 decode graph
+            torch.cuda.synchronize()
+            ops.set_gemm_hook(ev8)
+            ev8.enabled = True
+            t0 = time.perf_counter()
+            o8 = run_b8()
+            torch.cuda.synchronize()
+            dt8 = time.perf_counter() - t0
+            ev8.enabled = False
+            S = T + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
+            pre = [(a, b, f) for a, b, f, shp in ev8.pairs if shp[0] == Bb * S and shp[1] != cfg.vocab_padded]
+            ms8 = sum(a.elapsed_time(b) for a, b, _ in pre)
+            fl8 = sum(f for _, _, f in pre)
+            tf8 = fl8 / (ms8 * 1e-3) / 1e12 if ms8 > 0 else None
+            res["batched_fp8"] = {"batch": Bb, "samples_per_s": Bb / dt8, "ms_per_batch": dt8 * 1e3, "hands_decoded": o8.num_hands[0],
+                                  "sequences_equal_bf16": bool(torch.equal(o8.sequences, ob.sequences)),
+                                  "pred_hands_max_abs_dev_vs_bf16": float((o8.pred_hands.float() - ob.pred_hands.float()).abs().max()),
+                                  "dtype": "fp8 e4m3 (CLIP layer GEMMs + decoder prefill W8A8, decode steps W8A16) + bf16",
+                                  "workload": f"eval_batch{Bb}_T{T}_S{S}_{cfg.num_frames}frames_12new_tokens_4hands_fp8 (BASELINE config 5; "
+                                              "10 distinct frames per sample tiled to 100, CLIP on all of them)",
+                                  "roofline": {"bound": "mfma", "kernel": "gemm_pp4_fp8_kernel (decoder prefill launches)", "achieved": tf8,
+                                               "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": None if tf8 is None else tf8 / MFMA_FP8_PEAK_TFLOPS, "traffic": None,
+                                               "launches": len(pre), "avg_launch_us": ms8 / max(1, len(pre)) * 1e3,
+                                               "avg_launch_gflop": fl8 / max(1, len(pre)) / 1e9}}
+        except Exception as ex:  # noqa
+            res["batched_fp8"] = {"error": str(ex)[:200]}
+        finally:
+            ops.set_gemm_hook(prev_hook)
+        model.stack.invalidate_fp8()
         model.stack._kv_cache_b = None
     except Exception as ex:  # noqa
         res["batched"] = {"error": str(ex)[:200]}
@@ -524,12 +569,19 @@ def main():
     if not args.no_gemm_events:
         ops.set_gemm_hook(ev)
 
+    tails = []                                     # (backward-end event, step-end event) of every timed step
+
     def step():
+        buckets.begin_step()
         out = model(**batch)
         opt.begin_step(grad_scale=1.0 / world)     # per-bucket updates start as the buckets become final in backward
         model.backward()
         buckets.wait()
         opt.step()
+        if ev.enabled:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            tails.append((buckets.backward_end_event, end))
         return out
 
     def barrier():
@@ -558,6 +610,11 @@ def main():
         with open("gpurun_out/gemm_by_shape.json", "w") as f:
             json.dump([dict(M=r[0], N=r[1], K=r[2], launches=r[3], total_ms=r[4], tflops=r[5]) for r in ev.by_shape()], f, indent=0)
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    # time from the last backward kernel to the end of the step on the compute stream: the tail bucket's all-reduce (N > 1), the
+    # updates ordered behind it, and any earlier all-reduce still in flight — what the overlap did NOT hide.  At N = 1 the same
+    # interval holds only the tail bucket's AdamW + the join of the optimizer stream: the difference is the exposed communication.
+    tail_ms = [a.elapsed_time(b) for a, b in tails[-args.steps:] if a is not None]
+    tail_ms = float(np.mean(tail_ms)) if tail_ms else None
 
     if rank == 0:
         nv1 = cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
@@ -583,10 +640,15 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": f"sft_step_{args.model}_b{B}_T{T if lens is None else 'U' + args.varlen.replace(':', '-')}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
-                                   + ("_dedupclip" if args.dedup else "_refequiv") + ("_packed" if args.pack else "")
+                                   + ("_dedupclip" if args.dedup else "_refequiv") + ("_poolproj" if cfg.project_after_pool else "")
+                                   + ("_packed" if args.pack else "")
                                    + ("_recompute" if args.recompute else ""),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        "frames_through_clip_per_sample": n_frames // B,
+                       "projector_rows_per_sample": (nv1 + 1) if cfg.project_after_pool else cfg.num_frames * (nv1 + 1 - cfg.num_frames),
+                       "projector_note": ("mm_projector applied AFTER the temporal/spatial pooling (Linear commutes with the means: 356 rows per "
+                                          "sample instead of the reference's 25 600; its skipped FLOPs are not counted as work)"
+                                          if cfg.project_after_pool else "mm_projector on all patch tokens, as the reference"),
                        "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "clip_tower_dtype": args.clip_dtype, "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
                        "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",
                        "packed_rows": bool(args.pack)},
@@ -596,6 +658,17 @@ def main():
             "loss": loss,
             "peak_mem_gib": peak_mem,
         }
+        res["step_tail_ms"] = tail_ms
+        if buckets.active:
+            res["comm"] = {"backend": torch.distributed.get_backend(), "world": buckets.world,
+                           "collectives_per_step": buckets.n_collectives, "bytes_allreduced_per_step": buckets.bytes,
+                           "buckets": f"{cfg.num_hidden_layers} decoder layers (one flat bf16 bucket each, reduced from the layer's backward hook) + "
+                                      "lm_head (before the decoder backward) + tail (final norm, embed_tokens, mm_projector, CVAE head)",
+                           "exposed_ms": tail_ms,
+                           "exposed_ms_definition": "HIP-event time on the compute stream from the last backward kernel (tail hook) to the end of "
+                                                    "the step (last all-reduce complete + last AdamW update joined); `step_tail_ms` of the N = 1 "
+                                                    "line is the same interval without communication",
+                           "ring_bytes_per_gpu": 2.0 * (buckets.world - 1) / max(1, buckets.world) * buckets.bytes}
         if args.layers is not None:
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)

@@ -43,6 +43,22 @@ class GradBuckets:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("HVLM_FORCE_DIST", "0") == "1")
         self.handles: List = []
+        # communication accounting of the CURRENT step (bench.py's `comm` object): collectives issued, bytes handed to them,
+        # and the event recorded on the compute stream when the last backward kernel had been enqueued (the "tail" hook)
+        self.n_collectives = 0
+        self.bytes = 0
+        self.backward_end_event = None
+
+    def begin_step(self):
+        self.n_collectives, self.bytes, self.backward_end_event = 0, 0, None
+
+    def mark_backward_end(self):
+        """Called by the tail hook BEFORE it issues the last all-reduces: everything after this event on the step's critical
+        path (tail-bucket all-reduce, the updates that wait for it, whatever earlier all-reduces are still in flight) is
+        exposed, i.e. not hidden under backward compute."""
+        if torch.cuda.is_available():
+            self.backward_end_event = torch.cuda.Event(enable_timing=True)
+            self.backward_end_event.record()
 
     def reduce_async(self, *tensors: torch.Tensor) -> List:
         """Starts the all-reduces; returns their work handles (empty when not distributed)."""
@@ -50,6 +66,8 @@ class GradBuckets:
             return []
         hs = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for t in tensors]
         self.handles.extend(hs)
+        self.n_collectives += len(tensors)
+        self.bytes += sum(t.numel() * t.element_size() for t in tensors)
         return hs
 
     def wait(self):
@@ -74,6 +92,7 @@ def attach(model, buckets: GradBuckets, opt=None):
             # under the whole backward instead of leaving it exposed at the end of the step.
             ready("head", buckets.reduce_async(model.lm_head_g))
         if which == "tail":
+            buckets.mark_backward_end()
             hs = buckets.reduce_async(stack.norm_g, model.embed_g, model.proj_w_g, model.proj_b_g)
             for p in model.hand_traj_decoder.parameters():
                 if p.grad is not None:

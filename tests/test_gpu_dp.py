@@ -87,6 +87,35 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 4
     assert np.isfinite(res["value"]) and res["value"] > 0
+    _check_comm(res, 2)
+
+
+def _check_comm(res, world, layers=2):
+    """The `comm` object of an N > 1 (or forced-distributed) bench line: one collective per decoder-layer bucket + lm_head + the
+    tail's tensors, the bytes handed to them, and the exposed tail in HIP-event milliseconds."""
+    c = res["comm"]
+    assert c["world"] == world and c["collectives_per_step"] >= layers + 1 + 4
+    assert c["bytes_allreduced_per_step"] > 2 * 32101 * 128 * 2          # at least embed_tokens + lm_head gradients (bf16)
+    assert c["exposed_ms"] is not None and c["exposed_ms"] > 0 and c["exposed_ms"] == res["step_tail_ms"]
+    assert abs(c["ring_bytes_per_gpu"] - 2.0 * (world - 1) / world * c["bytes_allreduced_per_step"]) < 1.0
+
+
+def test_bench_world8_sharing_one_device(tmp_path):
+    """`bench.py --gpus 8` end to end on this 1-GPU box: eight rank processes on device 0 over gloo (HVLM_SHARE_DEVICE=1) — the
+    spawn path, the rendezvous, 8-way bucketed all-reduces from the backward hooks, the overlapped optimizer, the barrier and the
+    MAX over ranks of the timing, rank 0's single JSON line with global batch 8 x 2 and the `comm` object."""
+    import json
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--model", "tiny", "--batch", "2", "--text-len", "32",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-eval"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=dict(os.environ, HVLM_SHARE_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["config"]["parallelism"] == "dp8" and res["config"]["global_batch"] == 16
+    assert np.isfinite(res["value"]) and res["value"] > 0 and np.isfinite(res["loss"])
+    _check_comm(res, 8)
 
 
 def test_bench_under_torch_distributed_run(tmp_path):
@@ -127,4 +156,6 @@ def test_bench_rccl_backend_world1(tmp_path):
         assert len(lines) == 1, r.stdout[-1000:]
         res[tag] = json.loads(lines[0])
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
+    _check_comm(res["rccl"], 1)
+    assert "comm" not in res["plain"] and res["plain"]["step_tail_ms"] > 0
     assert res["rccl"]["loss"] == res["plain"]["loss"], (res["rccl"]["loss"], res["plain"]["loss"])
