@@ -387,7 +387,8 @@ def eval_leg(model, cfg, T, device):
             tf8 = fl8 / (ms8 * 1e-3) / 1e12 if ms8 > 0 else None
             res["batched_fp8"] = {"batch": Bb, "samples_per_s": Bb / dt8, "ms_per_batch": dt8 * 1e3, "hands_decoded": o8.num_hands[0],
                                   "sequences_equal_bf16": bool(torch.equal(o8.sequences, ob.sequences)),
-                                  "pred_hands_max_abs_dev_vs_bf16": float((o8.pred_hands.float() - ob.pred_hands.float()).abs().max()),
+                                  "pred_hands_rel_l2_vs_bf16": float((o8.pred_hands.float() - ob.pred_hands.float()).norm()
+                                                                     / (ob.pred_hands.float().norm() + 1e-30)),
                                   "dtype": "fp8 e4m3 (CLIP layer GEMMs + decoder prefill W8A8, decode steps W8A16) + bf16",
                                   "workload": f"eval_batch{Bb}_T{T}_S{S}_{cfg.num_frames}frames_12new_tokens_4hands_fp8 (BASELINE config 5; "
                                               "10 distinct frames per sample tiled to 100, CLIP on all of them)",
