@@ -131,12 +131,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 struct Config {
   int gemm_group_m = 4;       // row panels per group of the XCD-aware tile order
   int gemm_static = 0;        // 1: static tile assignment even when there are >= 3 tiles per workgroup
-  int gemm_tail_half = 1;     // 1: the last, partial round of tiles of an XCD's chunk runs as half-tile units (gemm_pp.hip)
-  int gemm_epi_swap = 1;      // 1: register-exchange epilogue (v_permlane swaps), 0: through the wave-private LDS buffers
   int attn_no_resident = 0;   // 1: CLIP attention on the streaming kernel instead of the resident-K/V kernel
   int decode_unfused = 0;     // 1: RoPE and the split combine of the native decode step as separate launches
   int skinny_per = 0;         // weight-streaming GEMM: forced K-slice length (x 256 k), 0 = balance model
   // --- variants that exist in DEV builds only ---
+  int gemm_tail_half = 0;     // 1: the last, partial round of tiles of an XCD's chunk runs as half-tile units (gemm_pp.hip)
+  int gemm_epi_swap = 0;      // 1: register-exchange GEMM epilogue (v_permlane swaps) instead of the wave-private LDS buffers
   int gemm_dbg = 0;           // K-loop ablations of the ping-pong kernel (WRONG RESULTS by construction; timing / PMC only)
   int gemm_seg4 = 1;          // 0: 8-phase schedule for the K-contiguous kernels
   int gemm_m16 = 1;           // 0: 32x32x16 MFMAs instead of 16x16x32

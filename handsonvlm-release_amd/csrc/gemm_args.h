@@ -15,6 +15,8 @@ struct GemmArgs {
   size_t slab;                  // elements between fp32 slabs
   int dyn;                      // gemm_pp: 0 = static tile assignment, s+1 = dynamic scheduling on state slot s (pp_sched_slot)
   int dbg;                      // development ablations (HVLM_GEMM_DBG), 0 in production
+  int epi_swap = 0;             // gemm_pp, development builds: 1 = register-exchange epilogue (v_permlane swaps)
+  int tail_half = 0;            // gemm_pp, dynamic scheduling: 1 = an XCD chunk's last partial round of tiles runs as half-tile units
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
   const float* row_scale = nullptr;   // fp8 kernel only, optional: C[m, :] *= row_scale[m]  (per-token activation de-scale)
   const float* col_scale = nullptr;   // fp8 kernel only, optional: C[:, n] *= col_scale[n]  (per-output-channel weight de-scale)

@@ -118,11 +118,16 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // register count: a 32x32 accumulator fragment is simply held as four 16x16 quadrants (registers 4t..4t+3 = quadrant
 // t = 2*(column half) + (row half)), so only the fragment lane mapping, the MFMA calls and the (row, column) a register
 // stands for in the epilogue change.
-template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false, bool M16 = false>
+template <bool TN, bool FP8, bool SEG4 = false, bool DBG = false, bool F16 = false, bool M16 = false, bool EPI_SWAP = false>
 __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   static_assert(!M16 || (SEG4 && !TN), "the 16x16 form exists for the K-contiguous 4-segment kernels (16-bit: 16x16x32, fp8: 16x16x128)");
   static_assert(!(TN && FP8), "fp8 operands must be K-contiguous");
   static_assert(!(F16 && (TN || FP8)), "the fp16 instantiation (CLIP tower) is K-contiguous, 16-bit");
+#ifdef HVLM_DEV
+  constexpr bool HALF_OK = SEG4 && !TN && !DBG;     // half-tile tail units (development builds, gemm_tail_half = 1; see fetch_unit)
+#else
+  constexpr bool HALF_OK = false;                   // production: every unit is a whole tile, the code below folds away
+#endif
   using EL = E16<F16>;                      // 16-bit element type of A / B / C / bias / residual: bfloat16 or IEEE half
   constexpr int ES = FP8 ? 1 : 2;          // operand element size in bytes
   constexpr int NKS = FP8 ? 2 : 4;         // MFMA k-steps per K-tile
@@ -141,7 +146,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   const int ch_q = nwg >> 3, ch_r = nwg & 7;
   auto chunk_start = [&](int x) { return x < ch_r ? x * (ch_q + 1) : ch_r * (ch_q + 1) + (x - ch_r) * ch_q; };
   auto swz_of = [&](int vb) { return chunk_start(vb & 7) + (vb >> 3); };
+  // A unit is a tile or — dynamic scheduling, the last partial round of an XCD's chunk — one HALF of a tile: the unit code keeps
+  // the swizzled tile index in bits 0..27 and, in bits 28..29, 0 = the whole tile, 1 / 2 = its rows 0-127 / 128-255 only.
+  constexpr int UNIT_MASK = 0x0fffffff;
   auto tile_coords = [&](int swz, int& m0_, int& n0_, int& ksl_) {
+    swz &= UNIT_MASK;
     ksl_ = swz / ntile;
     swz -= ksl_ * ntile;
     const int gsz = p.group_m * p.tiles_n;
@@ -158,12 +167,33 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   const bool dyn = p.dyn != 0;
   PPSched& g_pp = g_pp_all[dyn ? p.dyn - 1 : 0];
   const int my_xcd = (int)blockIdx.x & 7;
+  // HALF-TILE TAIL (p.tail_half): all tiles cost the same, so an XCD's chunk of cnt tiles on its W workgroups is floor(cnt / W)
+  // full rounds and one partial round of t = cnt % W tiles during which W - t CUs idle (880 tiles on 256 CUs: 3.44 rounds, the
+  // N = 4096 GEMMs of the decoder).  When t <= W / 2 those last t tiles are handed out as 2 t half-tile units (the K loop of a
+  // half unit issues only the MFMA segment of its 128 rows; staging and barriers are unchanged), so the partial round costs about
+  // two thirds of a tile-time instead of a whole one.  Every output element is still computed by one workgroup in the same
+  // order: results are bit-identical (tests/test_gpu_ops.py).  MEASURED AND NOT ADOPTED (profiles/r03c_gemm_tail_half_ab.txt):
+  // o_proj 13872x4096x4096 +3.6 %, qkv +1.7 %, every other shape within +-1 %, the SFT step unchanged — a half unit is not
+  // cheaper than a whole tile, because the ping-pong schedule hides one group's load phase (ds_reads + LDS-DMA issue, ~500
+  // cycles) under the OTHER group's 512-cycle MFMA segment: with one of the two MFMA segments gone the load phases are exposed
+  // and the K-tile takes its four barrier-to-barrier phases all the same.  Kept in development builds only.
+  const int wg_x = (int)gridDim.x >> 3;
+  auto chunk_tail = [&](int cnt) {
+    if (!(HALF_OK && p.tail_half && p.splits == 1 && wg_x > 0)) return 0;
+    const int t = cnt % wg_x;
+    return (t > 0 && 2 * t <= wg_x) ? t : 0;
+  };
   auto fetch_unit = [&]() -> int {          // one lane
     for (int a = 0; a < 8; ++a) {
       const int x = (my_xcd + a) & 7;
       const int cnt = ch_q + (x < ch_r ? 1 : 0);
+      const int tl = chunk_tail(cnt), full = cnt - tl;
       const unsigned i = __hip_atomic_fetch_add(&g_pp.ctr[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int)i < cnt) return chunk_start(x) + (int)i;
+      if ((int)i < full) return chunk_start(x) + (int)i;
+      if ((int)i < full + 2 * tl) {
+        const int v = (int)i - full;
+        return (chunk_start(x) + full + (v >> 1)) | ((1 + (v & 1)) << 28);
+      }
     }
     return -1;
   };
@@ -382,9 +412,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   auto qrow = [&](int g) { return M16 ? ((g & 1) * 16 + l15) : l31; };
   auto qcol = [&](int g) { return M16 ? ((g >> 1) * 16 + 4 * q4) : (8 * g + 4 * hi); };
   auto col_of = [&](int n0, int j, int g) { return n0 + wn * 64 + j * 32 + qcol(g); };
-  auto epilogue_generic = [&](int m0, int n0, size_t c_slab) {
+  auto epilogue_generic = [&](int m0, int n0, size_t c_slab, int i_lo, int i_hi) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (i < i_lo || i >= i_hi) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -448,12 +479,122 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   const int t_row = l >> 2, t_c = l & 3;                       // transposed layout: row (0..15) + 16*q, columns 8*t_c..+7
   const bool fast_ok = !p.out_f32 && (p.ldc & 7) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
                        (!p.res || ((p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0));
-  auto epilogue = [&](int m0, int n0, size_t c_slab) {
+  // Register-exchange epilogue (EPI_SWAP; development builds, gemm_epi_swap = 1): the LDS round trip of the fast path below
+  // replaced by lane swaps.  Measured bit-identical and 0.4 - 2.7 % SLOWER than the LDS path on every shape of the SFT step
+  // (profiles/r03b_gemm_epilogue_swap_ab.txt): the epilogue is bound by VALU issue and by the 128 store instructions of a tile
+  // (1 KB each against the CU's 64 B / clk store path), not by the LDS round trip, which the software-pipelined LDS path hides.
+  // After bias / activation / residual and the 16-bit packing a lane holds, for one output row, two 4-column groups that are 16
+  // (16x16x32 layout: quadrants g and g + 2) or 4 (32x32x16 layout: quads 2k and 2k + 1, other half-wave) columns apart; ONE
+  // v_permlane16_swap (resp. v_permlane32_swap) per dword exchanges them with the partner lane so that every lane ends up with
+  // 8 CONSECUTIVE columns = one 16-byte store, rows x 64 (32) contiguous bytes per instruction — the store shape of the
+  // LDS-transposed path without its 4 ds_write_b64 + 2 ds_read_b128 + waits per fragment.  The residual is loaded in the store
+  // layout (16 B per lane) and brought to the accumulator layout by the same swap (it is an involution), so the add stays in
+  // fp32 before the single rounding: bit-identical to the LDS path.
+  //   16x16x32: pair pr = row half: quads (pr, pr + 2), row pr*16 + (l & 15); v_permlane16_swap(vdst = quad pr, src = quad pr + 2)
+  //             swaps vdst's odd 16-lane rows with src's even ones -> lane (l15, q4) holds columns (q4 & 1)*16 + (q4 >> 1)*8 .. + 7
+  //   32x32x16: pair pr = quads (2 pr, 2 pr + 1), row l & 31; v_permlane32_swap -> lane (l31, hi) holds columns 16 pr + 8 hi .. + 7
+  auto lane_swap = [&](unsigned& a, unsigned& b) {
+    if constexpr (M16) { const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false); a = r[0]; b = r[1]; }
+  };
+  auto epilogue_swap = [&](int m0, int n0, int i_lo, int i_hi) {
+    const int nb0 = n0 + wn * 64;
+    // bias in the accumulator layout: 4 columns per quad g (the same columns for every row fragment)
+    u32x2 bias_q[2][4];
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) bias_q[j][g4] = *reinterpret_cast<const u32x2*>(p.bias + col_of(n0, j, g4));
+    }
+    auto srow = [&](int pr) { return M16 ? (pr * 16 + l15) : l31; };                                    // row inside the 32-row fragment
+    auto scol = [&](int pr) { return M16 ? ((q4 & 1) * 16 + (q4 >> 1) * 8) : (16 * pr + 8 * hi); };       // first of the lane's 8 columns
+    const bool has_res = p.res != nullptr;
+    u32x4 res_n[2][2];                        // residual of the NEXT row fragment, store layout: [j][pr]
+    auto load_res = [&](int i, u32x4 (&dst)[2][2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int mc = min(m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + srow(pr), p.M - 1);
+          dst[j][pr] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + nb0 + j * 32 + scol(pr));
+        }
+    };
+    if (has_res) load_res(i_lo, res_n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < i_lo || i >= i_hi) continue;
+      u32x4 res_r[2][2];
+      if (has_res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) res_r[j][pr] = res_n[j][pr];
+        if (i + 1 < i_hi) load_res(i + 1, res_n);
+      }
+      float osc[2] = {1.f, 1.f};              // e4m3 output: 1 / out_inv of the lane's rows
+      if constexpr (FP8) {
+        if (p.out_inv) {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+            osc[pr] = __builtin_amdgcn_rcpf(p.out_inv[min(m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + srow(pr), p.M - 1)]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int ga = M16 ? pr : 2 * pr, gb = M16 ? pr + 2 : 2 * pr + 1;
+          float va[4], vb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] = acc[j][i][4 * ga + e]; vb[e] = acc[j][i][4 * gb + e]; }
+          if (p.bias) {
+            const u32x2 ba = bias_q[j][ga], bb = bias_q[j][gb];
+            va[0] += EL::lo(ba[0]); va[1] += EL::hi(ba[0]); va[2] += EL::lo(ba[1]); va[3] += EL::hi(ba[1]);
+            vb[0] += EL::lo(bb[0]); vb[1] += EL::hi(bb[0]); vb[2] += EL::lo(bb[1]); vb[3] += EL::hi(bb[1]);
+          }
+          if (p.act == HVLM_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = quick_gelu_pp(va[e]); vb[e] = quick_gelu_pp(vb[e]); }
+          }
+          if (has_res) {
+            u32x4 rr = res_r[j][pr];
+            asm volatile("" : "+v"(rr));       // consume the load on every path: nothing tracked stays pending into the K loop
+            unsigned r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
+            lane_swap(r0, r2);                 // store layout -> accumulator layout (the swap is its own inverse)
+            lane_swap(r1, r3);
+            va[0] += EL::lo(r0); va[1] += EL::hi(r0); va[2] += EL::lo(r1); va[3] += EL::hi(r1);
+            vb[0] += EL::lo(r2); vb[1] += EL::hi(r2); vb[2] += EL::lo(r3); vb[3] += EL::hi(r3);
+          }
+          unsigned a0 = EL::pack2(va[0], va[1]), a1 = EL::pack2(va[2], va[3]);
+          unsigned b0 = EL::pack2(vb[0], vb[1]), b1 = EL::pack2(vb[2], vb[3]);
+          lane_swap(a0, b0);
+          lane_swap(a1, b1);
+          const u32x4 o = {a0, a1, b0, b1};
+          const int m = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + srow(pr);
+          const int nc = nb0 + j * 32 + scol(pr);
+          bool done8 = false;
+          if constexpr (FP8) {
+            if (p.out_inv) {
+              if (m < p.M) store8_untracked(reinterpret_cast<unsigned char*>(p.C) + (size_t)m * p.ldc + nc, bf16x8_to_e4m3(o, osc[pr]));
+              done8 = true;
+            }
+          }
+          if (!done8 && m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nc, o);
+        }
+      }
+    }
+  };
+  auto epilogue = [&](int m0, int n0, size_t c_slab, int i_lo, int i_hi) {   // row fragments i_lo .. i_hi - 1 (a half-tile unit: 2 of 4)
     if (!fast_ok || n0 + BN > p.N) {
-      epilogue_generic(m0, n0, c_slab);
+      epilogue_generic(m0, n0, c_slab, i_lo, i_hi);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // tracked stores must not be pending at the top of the K loop (see above)
       return;
     }
+    if constexpr (EPI_SWAP) {
+      epilogue_swap(m0, n0, i_lo, i_hi);
+      return;
+    } else {
     const int ncol0 = n0 + wn * 64 + 8 * t_c;
     if (!p.res) {
       // no residual: bias / activation in the accumulator layout, bf16 through LDS.  Two 2 KiB buffers (64-B rows, the
@@ -481,10 +622,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         }
       }
       u32x4 o_prev[2];
+      const int f_lo = 2 * i_lo, f_hi = 2 * i_hi;       // fragments of this unit (a half-tile unit: 4 of the 8)
 #pragma unroll
       for (int f = 0; f <= 8; ++f) {
         const int i = f >> 1, j = f & 1;
-        if (f < 8) {
+        if (f < f_lo || f > f_hi) continue;
+        if (f < f_hi) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float v[4];
@@ -503,7 +646,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             *reinterpret_cast<u32x2*>(epi + (f & 1) * 2048 + qr * 64 + (((qc >> 3) ^ ((qr >> 1) & 3)) << 4) + ((qc >> 2) & 1) * 8) = o;
           }
         }
-        if (f > 0) {
+        if (f > f_lo) {
           const int ip = (f - 1) >> 1, jp = (f - 1) & 1;
           const int mrow0 = m0 + (ip >> 1) * 128 + grp * 64 + (ip & 1) * 32 + t_row;
 #pragma unroll
@@ -521,7 +664,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             if (!done8 && m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + jp * 32, o_prev[q]);
           }
         }
-        if (f < 8) {
+        if (f < f_hi) {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int r = t_row + 16 * q;
@@ -553,16 +696,17 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           dst[j][q] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + ncol0 + j * 32);
         }
     };
-    load_res(0, res_n);
+    load_res(i_lo, res_n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (i < i_lo || i >= i_hi) continue;
       const int mrow0 = m0 + (i >> 1) * 128 + grp * 64 + (i & 1) * 32 + t_row;   // + 16*q
       u32x4 res_r[2][2];          // p.res != 0 on this path: loads and uses stay unconditional (see store16_untracked)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int q = 0; q < 2; ++q) res_r[j][q] = res_n[j][q];
-      if (i + 1 < 4) load_res(i + 1, res_n);
+      if (i + 1 < i_hi) load_res(i + 1, res_n);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // accumulator layout -> LDS: row l31, 16-B chunk (2g + hi) at chunk position (2g + hi) ^ (l31 & 7)
@@ -600,6 +744,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         }
       }
     }
+    }   // !EPI_SWAP
   };
 
   // ---- prologue: K-tile 0 (4 half-tiles) and A0,B0 of K-tile 1 in flight -------------------------
@@ -744,6 +889,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
     if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+    // hm = 0: the whole tile; 1 / 2: a half-tile unit — only MFMA segment A (rows 0-127) / B (rows 128-255) and its fragment
+    // reads are issued, everything else (staging, barriers, cursors) is the same code.  Three copies of the loop, so that the
+    // whole-tile loop is compiled exactly as before.
+    auto run_k = [&](auto hm_tag) {
+    constexpr int HM = decltype(hm_tag)::value;
     for (int kt = 0; kt < nk; ++kt, ++g) {
       const unsigned cb = g & 1u, ob = cb ^ 1u;
       const unsigned sb = cb * STAGE_BYTES;
@@ -755,10 +905,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         // half 1 (8 reads) and stages A0, B0, B1 of K-tile g+2 into the slots segment A just read.  Every DMA piece
         // has four segments to land; the counted wait stays vmcnt(8) at both syncs.
         read_b(sb, T0{}, fb0);
-        read_a(sb, T0{}, fa0);
+        if constexpr (HM != 2) read_a(sb, T0{}, fa0);
         __builtin_amdgcn_sched_barrier(0);
         read_b(sb, T1{}, fb1);
-        read_a(sb, T1{}, fa1);
+        if constexpr (HM != 2) read_a(sb, T1{}, fa1);
         if (!(DBG && (p.dbg & 2))) stage_a(ob, 1, c1);
         HVLM_PHASE_SYNC();
         if constexpr (TN) {   // the transpose reads are inline asm (untracked): retire them here, fragments as operands
@@ -766,9 +916,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
                        "+v"(fb1[2]), "+v"(fb1[3]), "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
                        "+v"(fa1[2]), "+v"(fa1[3]));
         }
-        if constexpr (M16) HVLM_MFMA_OCT16(0, fa0, fa1); else HVLM_MFMA_OCT(0, fa0, fa1);
+        if constexpr (HM != 2) { if constexpr (M16) HVLM_MFMA_OCT16(0, fa0, fa1); else HVLM_MFMA_OCT(0, fa0, fa1); }
         __builtin_amdgcn_s_barrier();
-        if (!(DBG && (p.dbg & 8))) {           // dbg 8: a third of the fragment reads gone (stale A fragments of half 0)
+        if (HM != 1 && !(DBG && (p.dbg & 8))) {           // dbg 8: a third of the fragment reads gone (stale A fragments of half 0)
           read_a(sb, T2{}, fa0);
           read_a(sb, T3{}, fa1);
         }
@@ -782,7 +932,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0[0]), "+v"(fa0[1]), "+v"(fa0[2]), "+v"(fa0[3]), "+v"(fa1[0]), "+v"(fa1[1]),
                        "+v"(fa1[2]), "+v"(fa1[3]));
         }
-        if constexpr (M16) HVLM_MFMA_OCT16(2, fa0, fa1); else HVLM_MFMA_OCT(2, fa0, fa1);
+        if constexpr (HM != 1) { if constexpr (M16) HVLM_MFMA_OCT16(2, fa0, fa1); else HVLM_MFMA_OCT(2, fa0, fa1); }
       } else {
       // phase 0: quadrant (rows 0-63, cols 0-31) — reads A0, B0; stages B1 of K-tile g+1
       const unsigned adb = lds0 + sb + tb_off, ada0 = lds0 + sb + ta_off[0], ada1 = lds0 + sb + ta_off[1];   // TN
@@ -831,6 +981,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         advance(c2);
       }
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
+    }
+    };   // run_k
+    const int half = HALF_OK ? (t_cur >> 28) : 0;          // (wave-uniform: t_cur is)
+    if constexpr (HALF_OK) {
+      if (half == 0) run_k(T0{}); else if (half == 1) run_k(T1{}); else run_k(T2{});
+    } else {
+      run_k(T0{});
     }
     int m0, n0, ksl;
     tile_coords(t_cur, m0, n0, ksl);
@@ -881,7 +1038,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             for (int e = 0; e < 4; ++e) acc[j][i][4 * g4 + e] *= rs * csv[j][g4][e];
           }
     }
-    epilogue(m0, n0, (size_t)ksl * p.slab);
+    epilogue(m0, n0, (size_t)ksl * p.slab, half == 2 ? 2 : 0, half == 1 ? 2 : 4);
     int t_aft = -1;
     asm volatile("" : "+v"(t_aft_v));       // retire the slot load here: left pending, it puts a vmcnt(0) into the K loop
     if (dyn) {
@@ -936,6 +1093,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp4_kernel(GemmArgs p) { gemm_pp_
 __global__ __launch_bounds__(512, 2) void gemm_pp4_f16_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4_dbg_kernel(GemmArgs p) { gemm_pp_body<false, false, true, true>(p); }
 __global__ __launch_bounds__(512, 2) void gemm_pp4m_fp8_kernel(GemmArgs p) { gemm_pp_body<false, true, true, false, false, true>(p); }   // 16x16x128
+// the production kernels with the register-exchange epilogue (v_permlane swaps) instead of the LDS round trip: gemm_epi_swap = 1
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_swapepi_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, false, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4m_f16_swapepi_kernel(GemmArgs p) { gemm_pp_body<false, false, true, false, true, true, true>(p); }
+__global__ __launch_bounds__(512, 2) void gemm_pp4_fp8_swapepi_kernel(GemmArgs p) { gemm_pp_body<false, true, true, false, false, false, true>(p); }
 #endif
 
 template <void (*kfn)(GemmArgs)>
@@ -972,6 +1133,7 @@ static bool use_m16() { return config().gemm_m16 != 0; }
 int launch_gemm_pp_f16(const GemmArgs& p, int grid, hipStream_t stream) {
 #ifdef HVLM_DEV
   if (!use_m16()) return launch_pp<gemm_pp4_f16_kernel>(p, grid, stream);
+  if (p.epi_swap) return launch_pp<gemm_pp4m_f16_swapepi_kernel>(p, grid, stream);
 #endif
   return launch_pp<gemm_pp4m_f16_kernel>(p, grid, stream);
 }
@@ -980,6 +1142,7 @@ int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream) {
   if (p.dbg) return launch_pp<gemm_pp4_dbg_kernel>(p, grid, stream);
   if (!use_seg4()) return launch_pp<gemm_pp_kernel>(p, grid, stream);
   if (!use_m16()) return launch_pp<gemm_pp4_kernel>(p, grid, stream);
+  if (p.epi_swap) return launch_pp<gemm_pp4m_swapepi_kernel>(p, grid, stream);
 #endif
   return launch_pp<gemm_pp4m_kernel>(p, grid, stream);
 }
@@ -996,6 +1159,7 @@ int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
 #ifdef HVLM_DEV
   if (!use_seg4()) return launch_pp<gemm_pp_fp8_kernel>(p, grid, stream);
   if (config().gemm_fp8_m16 == 1) return launch_pp<gemm_pp4m_fp8_kernel>(p, grid, stream);
+  if (p.epi_swap) return launch_pp<gemm_pp4_fp8_swapepi_kernel>(p, grid, stream);
 #endif
   return launch_pp<gemm_pp4_fp8_kernel>(p, grid, stream);
 }

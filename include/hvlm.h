@@ -49,11 +49,10 @@ int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
 /* Library switches.  Every A/B switch of the library is one named integer: initialised ONCE, at the library's first use, from
  * the environment variable HVLM_<KEY IN CAPITALS>, changed at run time through hvlm_configure; no entry point reads the
  * environment.  Production switches: "gemm_group_m" (row panels per group of the XCD-aware tile order, default 4),
- * "gemm_static" (1: static tile assignment), "gemm_tail_half" (1: the last partial round of GEMM tiles runs as half-tile
- * units), "gemm_epi_swap" (1: register-exchange GEMM epilogue), "attn_no_resident" (1: CLIP attention on the streaming kernel),
+ * "gemm_static" (1: static tile assignment), "attn_no_resident" (1: CLIP attention on the streaming kernel),
  * "decode_unfused" (1: RoPE / split combine of the native decode step as separate launches), "skinny_per" (forced K-slice of
  * the weight-streaming GEMM).  Switches that select a superseded kernel variant or the K-loop ablation kernel ("gemm_dbg",
- * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "attn_dkv_fused") exist in development builds only
+ * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "gemm_epi_swap", "gemm_tail_half", "attn_dkv_fused") exist in development builds only
  * (`make DEV=1`; hvlm_is_dev_build() == 1): a production build returns HVLM_ERR_UNSUPPORTED for any non-default value, and
  * does not contain those kernels.  Not thread-safe against concurrent launches (set switches before issuing work). */
 int hvlm_configure(const char* key, int value);

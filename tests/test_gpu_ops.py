@@ -522,3 +522,49 @@ def test_gemm_tail_rows_as_splitk(ops, M, N, K):
     assert torch.equal(c1, c2)
     assert rel(c1, ref.to(BF)) <= 1e-3 and rel(c0, ref.to(BF)) <= 1e-3
     assert rel(c1, c0) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,dt,epi", [(13872, 4096, 512, "bf16", "res"), (13872, 4096, 256, "f16", "bias_gelu"),
+                                          (14000, 4096, 256, "bf16", "none"), (13872, 4352, 384, "f16", "bias_res"),
+                                          (13872, 4096, 512, "fp8", "res")])
+def test_gemm_half_tile_tail_units_bit_identical(ops, M, N, K, dt, epi):
+    """Dynamic scheduling can hand the last, partial round of an XCD's tiles out as HALF-tile units (gemm_tail_half = 1, DEV builds):
+    880 tiles = 110 per XCD = 3 rounds of 32 + 14 -> 28 half units.  Every element is still computed by one workgroup in the
+    same order, so the output must equal the whole-tile schedule bit for bit — every epilogue form (bias / QuickGELU /
+    residual, 16-bit and e4m3 operands), a ragged last row panel (M = 13872 = 54 x 256 + 48; 14000) and a ragged column tile
+    (N = 4352 = 17 x 256) — and the oracle."""
+    from hvlm import _lib
+    if not _lib.load().hvlm_is_dev_build():
+        pytest.skip("half-tile tail units are compiled into development builds only (measured, not adopted: "
+                    "profiles/r03c_gemm_tail_half_ab.txt); run with HVLM_LIB=.../libhvlm_hip_dev.so")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    tdt = torch.float16 if dt == "f16" else BF
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(tdt)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.5).to(tdt)
+    bias = torch.randn(N, device="cuda", generator=g).to(tdt) if "bias" in epi else None
+    res = torch.randn(M, N, device="cuda", generator=g).to(tdt) if "res" in epi else None
+    act = ops.ACT_QUICK_GELU if "gelu" in epi else ops.ACT_NONE
+
+    def run():
+        if dt == "fp8":
+            a8, ia = ops.quantize_fp8_rowwise(a)
+            b8, ib = ops.quantize_fp8_rowwise(b)
+            return ops.gemm_fp8_nt_scaled(a8, b8, ia, ib, residual=res)
+        fn = ops.gemm_f16_nt if dt == "f16" else ops.gemm_nt
+        return fn(a, b, bias=bias, residual=res, act=act)
+    with _lib.configured(gemm_tail_half=1):
+        halves = run()
+        assert torch.equal(halves, run())
+    whole = run()
+    with _lib.configured(gemm_static=1):
+        static = run()
+    assert torch.equal(halves, whole) and torch.equal(halves, static)
+    if dt != "fp8":
+        ref = a.float() @ b.float().t()
+        if bias is not None:
+            ref = ref + bias.float()
+        if act:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        if res is not None:
+            ref = ref + res.float()
+        assert rel(halves, ref.to(tdt)) <= 1.5e-3
