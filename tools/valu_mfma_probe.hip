@@ -63,11 +63,25 @@ __global__ __launch_bounds__(512) void probe(const _Float16* __restrict__ src, f
   for (int r = 0; r < 32; ++r) s[r] = (float)src[(t * 32 + r) & 4095];
 #pragma unroll
   for (int r = 0; r < 16; ++r) pk[r] = 0;
-  const bool do_m = mode == 0 || (mode == 2 && w < 4) || mode >= 3;
-  const bool do_v = mode == 1 || (mode == 2 && w >= 4) || mode >= 3;
+  const bool split = mode == 2 || mode == 6 || mode == 7;
+  const bool do_m = mode == 0 || (split && w < 4) || (mode >= 3 && !split);
+  const bool do_v = mode == 1 || (split && w >= 4) || (mode >= 3 && !split);
+  if (mode == 6 && w >= 4) __builtin_amdgcn_s_setprio(3);      // the VALU wave outranks the MFMA wave
+  if (mode == 7 && w < 4) __builtin_amdgcn_s_setprio(3);       // the MFMA wave outranks the VALU wave
   __syncthreads();
   const long long t0 = __builtin_readcyclecounter();
-  if (do_m && do_v) {
+  if (mode == 5 || mode == 8) {
+    // one stream, interleave FORCED: one MFMA, then a dozen VALU instructions, sixteen times per iteration
+    for (int it = 0; it < iters; ++it) {
+      mfma_block(acc, a, b);
+      valu_block(s, m, sum, 0.125f, pk);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
+    }
+  } else if (do_m && do_v) {
     for (int it = 0; it < iters; ++it) {
       mfma_block(acc, a, b);
       valu_block(s, m, sum, 0.125f, pk);
@@ -97,11 +111,13 @@ int main() {
   srand(1);
   for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
   hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-  const char* names[5] = {"MFMA only, 1 wave/SIMD", "VALU only, 1 wave/SIMD", "MFMA wave + VALU wave per SIMD", "one wave/SIMD, both in one stream",
-                          "two waves/SIMD, both in one stream each"};
-  double base[5];
-  for (int mode = 0; mode < 5; ++mode) {
-    const int threads = (mode == 2 || mode == 4) ? 512 : 256;
+  const char* names[9] = {"MFMA only, 1 wave/SIMD", "VALU only, 1 wave/SIMD", "MFMA wave + VALU wave per SIMD", "one wave/SIMD, both in one stream",
+                          "two waves/SIMD, both in one stream each", "one wave/SIMD, one stream, 1 MFMA : 12 VALU forced",
+                          "MFMA wave + VALU wave, VALU wave at s_setprio 3", "MFMA wave + VALU wave, MFMA wave at s_setprio 3",
+                          "two waves/SIMD, forced interleave each"};
+  double base[9];
+  for (int mode = 0; mode < 9; ++mode) {
+    const int threads = (mode == 2 || mode == 4 || mode >= 6) ? 512 : 256;
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(probe, dim3(1), dim3(threads), 0, 0, src, out, cyc, iters, mode);
       hipDeviceSynchronize();
@@ -116,6 +132,9 @@ int main() {
     printf("\n");
   }
   printf("per iteration: 16 MFMA 32x32x16 (= 512 matrix-core cycles at 1 MFMA / 32 clk) and the softmax VALU mix of a 64-key step\n");
+  printf("forced interleave: T_one' / max(T_m, T_v) = %.2f   two waves: T_two' / (2 max) = %.2f   prio VALU: %.2f x (T_m + T_v)   prio MFMA: %.2f x\n",
+         base[5] / (base[0] > base[1] ? base[0] : base[1]), base[8] / (2 * (base[0] > base[1] ? base[0] : base[1])),
+         base[6] / (base[0] + base[1]), base[7] / (base[0] + base[1]));
   printf("T_mix / (T_m + T_v) = %.2f   T_mix / max(T_m, T_v) = %.2f   T_one / (T_m + T_v) = %.2f   T_two / (2 (T_m + T_v)) = %.2f\n",
          base[2] / (base[0] + base[1]), base[2] / (base[0] > base[1] ? base[0] : base[1]), base[3] / (base[0] + base[1]),
          base[4] / (2 * (base[0] + base[1])));
