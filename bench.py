@@ -727,6 +727,9 @@ def main():
                            "collectives_per_step": buckets.n_collectives, "bytes_allreduced_per_step": buckets.bytes,
                            "buckets": f"{cfg.num_hidden_layers} decoder layers (one flat bf16 bucket each, reduced from the layer's backward hook) + "
                                       "lm_head (before the decoder backward) + tail (final norm, embed_tokens, mm_projector, CVAE head)",
+                           "embed_rows_allreduced": (getattr(buckets, "embed_rows", None).rows_last if getattr(buckets, "embed_rows", None) else None),
+                           "embed_rows_note": "rows of the [32101, D] embedding gradient that were all-reduced (the union of the token ids of all "
+                                              "ranks' minibatches; null = the dense buffer, used when the union exceeds half the vocabulary)",
                            "exposed_ms": tail_ms,
                            "exposed_ms_definition": "HIP-event time on the compute stream from the last backward kernel (tail hook) to the end of "
                                                     "the step (last all-reduce complete + last AdamW update joined); `step_tail_ms` of the N = 1 "

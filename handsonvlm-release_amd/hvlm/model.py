@@ -117,6 +117,7 @@ class HandsOnVLMForCausalLM:
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self._ctx: Optional[dict] = None
         self.on_grads_ready: Optional[Callable[[str], None]] = None         # DP hook for the non-layer bucket
+        self.on_token_ids: Optional[Callable[[torch.Tensor], None]] = None  # DP hook: this step's distinct text-token ids (device int32)
 
     # ------------------------------------------------------------------------------------------
     # parameters / checkpoints
@@ -398,15 +399,22 @@ class HandsOnVLMForCausalLM:
         T = input_ids.shape[1]
 
         vis = kwargs.get("visual_tokens")
-        if vis is None:
-            vis = self.visual_tokens(image.to(dev), keep_for_backward=training_pass)
-        NV = vis.shape[1]
+        G = cfg.vision.image_size // cfg.vision.patch_size
+        NV = vis.shape[1] if vis is not None else image.shape[1] + G * G      # temporal + spatial tokens (356 at 224 px)
         n_hands = 0 if future_hands is None else future_hands.shape[2]
         # packed (unpadded) rows: training passes only, opt-in (config.pack_sequences); logits / hidden states are then
         # returned packed too ([M, ...] with out.cu_seqlens), everything else is unchanged
         pack = bool(cfg.pack_sequences) and training_pass
+        # the splice plan is host-only work on the token ids: built BEFORE the CLIP tower is enqueued, so that the data-parallel
+        # exchange of this step's token ids (dp.EmbedRows: which embedding-gradient rows need reducing at all) happens while the
+        # device is still busy with the previous step, not in the middle of this one
         plan = self.build_splice_plan(input_ids, labels, NV, n_hands, is_evaluate, future_hands is not None, pack=pack,
                                       attention_mask=attention_mask)
+        if training_pass and self.on_token_ids is not None and plan.seg is not None:
+            self.on_token_ids(plan.seg[2])
+        if vis is None:
+            vis = self.visual_tokens(image.to(dev), keep_for_backward=training_pass)
+        assert vis.shape[1] == NV, (vis.shape, NV)
         S = plan.S
         assert S <= cfg.max_position_embeddings, f"spliced length {S} exceeds max_position_embeddings"
         hands_dev = None

@@ -79,7 +79,7 @@ class AdamW:
         self._done = set()
         self._weights_changed()
 
-    def bucket_ready(self, key: str, after=()):
+    def bucket_ready(self, key: str, after=(), post=None):
         """The gradients of bucket `key` are final once the work handles in `after` (its all-reduces) complete, or —
         without handles — once the kernels enqueued so far on the current stream have run: update it on the optimizer
         stream.  No-op outside overlapped mode / outside begin_step()..step()."""
@@ -93,6 +93,8 @@ class AdamW:
                     h.wait()               # NCCL/RCCL work: orders THIS stream after the collective, the host does not block
             else:
                 self.stream.wait_stream(cur)
+            if post is not None:
+                post()                     # e.g. dp.EmbedRows.finish: scatter the reduced rows back, behind their all-reduce
             self._update(self.groups[key], lr, grad_scale)
         self._done.add(key)
 
