@@ -146,7 +146,7 @@ def _engine_worker(rank, world, port, ret):
     buckets.wait()
     summed = _grads(model)
     opt.step()
-    ret[rank] = dict(order=order, grads={k: v.float().numpy() for k, v in summed.items()},
+    ret[rank] = dict(order=order, embed_rows=buckets.embed_rows.rows_last, grads={k: v.float().numpy() for k, v in summed.items()},
                      weights={k: v.float().numpy() for k, v in _weights(model).items()}, loss=float(out.loss.detach()))
     dist.destroy_process_group()
 
@@ -164,6 +164,11 @@ def test_dp_world2_real_engine_equals_mean_of_single_rank_grads():
     L = 2
     want_order = ["head"] + [f"layers.{i}" for i in range(L - 1, -1, -1)] + ["tail"]
     assert r0["order"] == want_order and r1["order"] == want_order
+    # the embedding gradient went through the touched-rows path (dp.EmbedRows): the union of both ranks' distinct token ids
+    ids = set()
+    for rank in (0, 1):
+        ids |= set(int(t) for t in _tiny_model_and_batch(rank)[1]["input_ids"].flatten().tolist() if t >= 0)
+    assert r0["embed_rows"] == r1["embed_rows"] == len(ids) < 200
     # single-rank gradients of the two minibatches, in this process
     from hvlm.optim import AdamW
     single = []

@@ -21,6 +21,26 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[4], const f16x8 (&a)[4]
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + k) & 3], b[k], acc[i], 0, 0, 0);
 }
+// the same 16 MFMAs with the issuing wave put to sleep between them (s_nop: scalar-side wait states), so that it is never
+// parked in the vector issue stage waiting for the matrix core: PAD wait states after each MFMA (the 32x32x16 MFMA occupies
+// the matrix core for 32 cycles, 4 of them are its own issue)
+template <int PAD>
+__device__ __forceinline__ void mfma_block_padded(f32x16 (&acc)[4], const f16x8 (&a)[4], const f16x8 (&b)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + k) & 3], b[k], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PAD == 16) asm volatile("s_nop 15");
+      if constexpr (PAD == 2) asm volatile("s_nop 1");
+      if constexpr (PAD == 4) asm volatile("s_nop 3");
+      if constexpr (PAD == 6) asm volatile("s_nop 5");
+      if constexpr (PAD == 8) asm volatile("s_nop 7");
+      if constexpr (PAD == 10) asm volatile("s_nop 9");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+}
 // the softmax VALU mix of one 64-key x 32-query step: 32 scores per lane -> fma, max, exp2, add, cvt
 __device__ __forceinline__ void valu_block(float (&s)[32], float& m, float& sum, float scale, unsigned (&pk)[16]) {
   float mx = s[0];
@@ -63,7 +83,7 @@ __global__ __launch_bounds__(512) void probe(const _Float16* __restrict__ src, f
   for (int r = 0; r < 32; ++r) s[r] = (float)src[(t * 32 + r) & 4095];
 #pragma unroll
   for (int r = 0; r < 16; ++r) pk[r] = 0;
-  const bool split = mode == 2 || mode == 6 || mode == 7;
+  const bool split = mode == 2 || mode == 6 || mode == 7 || mode >= 9;
   const bool do_m = mode == 0 || (split && w < 4) || (mode >= 3 && !split);
   const bool do_v = mode == 1 || (split && w >= 4) || (mode >= 3 && !split);
   if (mode == 6 && w >= 4) __builtin_amdgcn_s_setprio(3);      // the VALU wave outranks the MFMA wave
@@ -86,6 +106,14 @@ __global__ __launch_bounds__(512) void probe(const _Float16* __restrict__ src, f
       mfma_block(acc, a, b);
       valu_block(s, m, sum, 0.125f, pk);
     }
+  } else if (do_m && mode == 9) {
+    for (int it = 0; it < iters; ++it) mfma_block_padded<2>(acc, a, b);
+  } else if (do_m && mode == 10) {
+    for (int it = 0; it < iters; ++it) mfma_block_padded<4>(acc, a, b);
+  } else if (do_m && mode == 11) {
+    for (int it = 0; it < iters; ++it) mfma_block_padded<6>(acc, a, b);
+  } else if (do_m && mode == 12) {
+    for (int it = 0; it < iters; ++it) mfma_block_padded<8>(acc, a, b);
   } else if (do_m) {
     for (int it = 0; it < iters; ++it) mfma_block(acc, a, b);
   } else if (do_v) {
@@ -111,12 +139,13 @@ int main() {
   srand(1);
   for (auto& v : h) v = (_Float16)((rand() % 2001 - 1000) / 1000.0f);
   hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-  const char* names[9] = {"MFMA only, 1 wave/SIMD", "VALU only, 1 wave/SIMD", "MFMA wave + VALU wave per SIMD", "one wave/SIMD, both in one stream",
+  const char* names[13] = {"MFMA only, 1 wave/SIMD", "VALU only, 1 wave/SIMD", "MFMA wave + VALU wave per SIMD", "one wave/SIMD, both in one stream",
                           "two waves/SIMD, both in one stream each", "one wave/SIMD, one stream, 1 MFMA : 12 VALU forced",
                           "MFMA wave + VALU wave, VALU wave at s_setprio 3", "MFMA wave + VALU wave, MFMA wave at s_setprio 3",
-                          "two waves/SIMD, forced interleave each"};
-  double base[9];
-  for (int mode = 0; mode < 9; ++mode) {
+                          "two waves/SIMD, forced interleave each", "MFMA wave + s_nop 1 per MFMA | VALU wave", "MFMA wave + s_nop 3 per MFMA | VALU wave",
+                          "MFMA wave + s_nop 5 per MFMA | VALU wave", "MFMA wave + s_nop 7 per MFMA | VALU wave"};
+  double base[13];
+  for (int mode = 0; mode < 13; ++mode) {
     const int threads = (mode == 2 || mode == 4 || mode >= 6) ? 512 : 256;
     for (int rep = 0; rep < 2; ++rep) {
       hipLaunchKernelGGL(probe, dim3(1), dim3(threads), 0, 0, src, out, cyc, iters, mode);
