@@ -63,7 +63,7 @@ static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg(); p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg(); p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half; p.sched = pp_sched_ws();
   p.group_m = config().gemm_group_m;
   int grid = p.tiles_m * p.tiles_n;
   static int pgrid = 0;
@@ -139,7 +139,7 @@ extern "C" int hvlm_gemm_bf16_nt_splitk(const void* A, const void* B, void* C, i
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = ws; p.bias = nullptr; p.res = nullptr;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N; p.ldr = 0; p.act = HVLM_ACT_NONE; p.out_f32 = 1;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg(); p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half;
+  p.splits = splits; p.k_split = K / splits; p.slab = (size_t)M * N; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg(); p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half; p.sched = pp_sched_ws();
   static int cus = 0;
   if (!cus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -341,7 +341,7 @@ static int gemm_fp8_impl(const void* A, const void* B, void* C, int M, int N, in
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.bias = (const bf16_t*)bias; p.res = (const bf16_t*)residual;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN); p.group_m = GROUP_M;
-  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0; p.dbg = 0; p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half;
+  p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = alpha; p.dyn = 0; p.dbg = 0; p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half; p.sched = pp_sched_ws();
   p.row_scale = row_scale; p.col_scale = col_scale; p.out_inv = out_inv;
   static int cus = 0;
   if (!cus) {

@@ -165,7 +165,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   // so a workgroup that starts late — CUs held by another stream, e.g. an RCCL all-reduce — simply takes fewer tiles.
   // With the static assignment (b, b+grid, ...) 8 busy CUs out of 256 cost this kernel 17-42 % (tools/contention_bench.py).
   const bool dyn = p.dyn != 0;
-  PPSched& g_pp = g_pp_all[dyn ? p.dyn - 1 : 0];
+  PPSched& g_pp = (p.sched ? reinterpret_cast<PPSched*>(p.sched) : g_pp_all)[dyn ? p.dyn - 1 : 0];
   const int my_xcd = (int)blockIdx.x & 7;
   // HALF-TILE TAIL (p.tail_half): all tiles cost the same, so an XCD's chunk of cnt tiles on its W workgroups is floor(cnt / W)
   // full rounds and one partial round of t = cnt % W tiles during which W - t CUs idle (880 tiles on 256 CUs: 3.44 rounds, the
@@ -1116,6 +1116,15 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
 
 }  // namespace
 
+// Caller-owned scheduler state, per device (hvlm_gemm_set_sched_ws): the library's own `__device__` block above is only the
+// default, so that a host which wants every byte the kernels touch to be its own allocation can have that.
+static void* g_sched_ws[64] = {nullptr};
+void* pp_sched_ws() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return g_sched_ws[dev];
+}
+
 int pp_sched_slot(hipStream_t stream) {
   static hipStream_t known[PP_NSCHED];
   static int n = 0;
@@ -1165,3 +1174,20 @@ int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
 }
 
 }  // namespace hvlm
+
+extern "C" size_t hvlm_gemm_sched_ws_bytes(void) { return sizeof(hvlm::PPSched) * hvlm::PP_NSCHED; }
+
+extern "C" int hvlm_gemm_set_sched_ws(void* ws, size_t bytes, void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { hvlm::set_error("gemm_set_sched_ws: no current device"); return HVLM_ERR_LAUNCH; }
+  if (ws == nullptr) { hvlm::g_sched_ws[dev] = nullptr; return HVLM_OK; }
+  HVLM_REQUIRE(bytes >= hvlm_gemm_sched_ws_bytes() && ((uintptr_t)ws & 255) == 0,
+               "gemm_set_sched_ws: need %zu bytes, 256-byte aligned", hvlm_gemm_sched_ws_bytes());
+  if (hipMemsetAsync(ws, 0, hvlm_gemm_sched_ws_bytes(), hvlm::as_stream(stream)) != hipSuccess) {
+    hvlm::set_error("gemm_set_sched_ws: hipMemsetAsync failed");
+    return HVLM_ERR_LAUNCH;
+  }
+  hvlm::g_sched_ws[dev] = ws;
+  return HVLM_OK;
+}
+

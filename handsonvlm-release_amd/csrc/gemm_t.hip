@@ -300,7 +300,7 @@ extern "C" int hvlm_gemm_bf16(const void* A, const void* B, void* C, int M, int 
     q.A = p.A; q.B = p.B; q.C = C; q.bias = p.bias; q.res = p.res;
     q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.ldr = ldr; q.act = act; q.out_f32 = out_f32;
     q.tiles_m = p.tiles_m; q.tiles_n = p.tiles_n; q.group_m = 4;
-    q.splits = 1; q.k_split = K; q.slab = 0; q.alpha = 1.f; q.dyn = 0; q.dbg = 0; q.epi_swap = config().gemm_epi_swap; q.tail_half = 0;
+    q.splits = 1; q.k_split = K; q.slab = 0; q.alpha = 1.f; q.dyn = 0; q.dbg = 0; q.epi_swap = config().gemm_epi_swap; q.tail_half = 0; q.sched = pp_sched_ws();
     q.dyn = ((K + BK - 1) / BK >= 3 && pgrid <= 512 && q.tiles_m * q.tiles_n >= 3 * pgrid && !config().gemm_static) ? 1 + pp_sched_slot(st) : 0;
     const int rc = launch_gemm_pp_tn(q, grid, st);
     if (rc) return rc;

@@ -74,6 +74,15 @@ int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K
                       int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
                       int out_f32, void* stream);
 
+/* Scheduler state of the persistent GEMM kernels (per-XCD tile counters + per-workgroup hand-over slots of the dynamic tile
+ * scheduling, one block per launching stream; 75 KiB).  By default it lives in the library's own device-side storage (one
+ * copy per device, as HIP module globals are).  A host that wants every byte the kernels write to be its own allocation
+ * installs a block for the CURRENT device: `ws` of hvlm_gemm_sched_ws_bytes() bytes, 256-byte aligned, zero-filled by the
+ * call on `stream` and owned by the caller for as long as GEMMs are launched on that device (NULL restores the default).
+ * Kernels of different streams use different slots of the block, so launches may overlap across streams as before. */
+size_t hvlm_gemm_sched_ws_bytes(void);
+int hvlm_gemm_set_sched_ws(void* ws, size_t bytes, void* stream);
+
 /* Split-K variant for skinny problems (few 256x256 output tiles, e.g. the batch-1 prefill, M = 867): `splits` K-slices
  * are computed by separate workgroups into fp32 slabs of `ws` (hvlm_gemm_splitk_ws_bytes) and summed, deterministically,
  * by a finalize pass that applies bias / activation / residual and writes bf16 C.  K % (64*splits) == 0, N % 4 == 0. */

@@ -241,6 +241,7 @@ def test_configure_switches_without_a_device(lib):
             lib.configure(key, lib.config_get(key))                               # the default value is always accepted
         syms = subprocess.run(["nm", str(lib.LIB_PATH)], capture_output=True, text=True).stdout
         assert "dbg" not in syms and "gemm_pp_kernel" not in syms and "attn_bwd_dkv_kernel" not in syms
+    assert l.hvlm_gemm_sched_ws_bytes() % 256 == 0 and l.hvlm_gemm_sched_ws_bytes() > 0      # (the setter itself needs a device)
     # no entry point reads the environment: the only getenv of the library is the one-time initialisation in runtime.hip
     import glob
     import os

@@ -568,3 +568,39 @@ def test_gemm_half_tile_tail_units_bit_identical(ops, M, N, K, dt, epi):
         if res is not None:
             ref = ref + res.float()
         assert rel(halves, ref.to(tdt)) <= 1.5e-3
+
+
+def test_gemm_scheduler_state_in_caller_memory(ops):
+    """hvlm_gemm_set_sched_ws: the dynamic tile scheduler's counters / hand-over slots live in a caller-provided block instead
+    of the library's own device storage — same tiles, same arithmetic: the result is bit-identical, on two streams at once, and
+    the block is left at rest (all counters zero) after every launch."""
+    import ctypes
+    from hvlm import _lib
+    lib = _lib.load()
+    M, N, K = 16384, 3328, 512            # 832 tiles >= 3 x 256: dynamic scheduling
+    a, b = rnd(M, K, seed=90).cuda(), rnd(N, K, seed=91).cuda()
+    base = ops.gemm_nt(a, b)
+    nbytes = lib.hvlm_gemm_sched_ws_bytes()
+    assert 16 * 1024 < nbytes < 1 << 20
+    ws = torch.full((nbytes + 256,), 0xAB, dtype=torch.uint8, device="cuda")
+    off = (-ws.data_ptr()) % 256
+    blk = ws[off:off + nbytes]
+    rc = lib.hvlm_gemm_set_sched_ws(ctypes.c_void_p(blk.data_ptr() + 8), nbytes, ops._stream())
+    assert rc == -1 and b"256-byte aligned" in lib.hvlm_last_error()
+    _lib.check(lib.hvlm_gemm_set_sched_ws(ctypes.c_void_p(blk.data_ptr()), nbytes, ops._stream()), "set_sched_ws")
+    try:
+        mine = ops.gemm_nt(a, b)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            other = ops.gemm_nt(a, b)
+        again = ops.gemm_nt(a, b)
+        torch.cuda.synchronize()
+        assert torch.equal(mine, base) and torch.equal(other, base) and torch.equal(again, base)
+        words = blk.view(torch.int32)
+        per = nbytes // 8 // 4                                  # int32 words per stream slot: ctr[8][32], done[32], slots[512][4]
+        for s in range(8):                                      # every stream slot: tile counters and completion count at rest
+            assert int(words[s * per: s * per + 8 * 32 + 32].abs().sum()) == 0
+    finally:
+        _lib.check(lib.hvlm_gemm_set_sched_ws(None, 0, ops._stream()), "reset sched_ws")
+    assert torch.equal(ops.gemm_nt(a, b), base)
