@@ -30,7 +30,23 @@ using namespace hvlm;
 static int gemm_dbg() { return config().gemm_dbg; }      // (always 0 in a production build: hvlm_configure refuses it)
 
 static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       const void* bias, const void* residual, int ldr, int act, int out_f32, bool f16, void* stream);
+                       const void* bias, const void* residual, int ldr, int act, int out_f32, bool f16, void* stream,
+                       float* stats_out = nullptr, const float* ln_stats = nullptr, const float* ln_c1 = nullptr);
+
+extern "C" size_t hvlm_ln_stats_parts(int N) { return (size_t)cdiv(N, BN) * 4; }
+
+extern "C" int hvlm_gemm_f16_nt_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                   const void* bias, const void* residual, int ldr, int act, float* stats_out,
+                                   const float* ln_stats, const float* ln_c1, void* stream) {
+  HVLM_REQUIRE(!stats_out || (residual && N % BN == 0 && ((uintptr_t)stats_out & 7) == 0),
+               "gemm_f16_nt_ln: stats_out needs a residual epilogue and N %% 256 == 0");
+  HVLM_REQUIRE((ln_stats == nullptr) == (ln_c1 == nullptr), "gemm_f16_nt_ln: ln_stats and ln_c1 come together");
+  HVLM_REQUIRE(!ln_stats || (!residual && N % BN == 0 && ((uintptr_t)ln_stats & 7) == 0 && ((uintptr_t)ln_c1 & 15) == 0),
+               "gemm_f16_nt_ln: the LayerNorm-fold epilogue takes no residual and needs N %% 256 == 0");
+  HVLM_REQUIRE(ldc % 8 == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)),
+               "gemm_f16_nt_ln: 16-byte aligned rows (the fast epilogue)");
+  return gemm16_impl(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, act, 0, true, stream, stats_out, ln_stats, ln_c1);
+}
 
 extern "C" int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda,
                                  int ldb, int ldc, const void* bias, const void* residual, int ldr,
@@ -45,7 +61,8 @@ extern "C" int hvlm_gemm_f16_nt(const void* A, const void* B, void* C, int M, in
 }
 
 static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
-                       const void* bias, const void* residual, int ldr, int act, int out_f32, bool f16, void* stream) {
+                       const void* bias, const void* residual, int ldr, int act, int out_f32, bool f16, void* stream,
+                       float* stats_out, const float* ln_stats, const float* ln_c1) {
   HVLM_REQUIRE(A && B && C, "gemm: null operand");
   HVLM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   HVLM_REQUIRE(K % BK == 0, "gemm: K=%d must be a multiple of %d", K, BK);
@@ -63,6 +80,7 @@ static int gemm16_impl(const void* A, const void* B, void* C, int M, int N, int 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.act = act; p.out_f32 = out_f32;
   p.tiles_m = cdiv(M, BM); p.tiles_n = cdiv(N, BN);
+  p.stats_out = stats_out; p.ln_stats = ln_stats; p.ln_c1 = ln_c1;
   p.splits = 1; p.k_split = K; p.slab = 0; p.alpha = 1.f; p.dyn = 0; p.dbg = gemm_dbg(); p.epi_swap = config().gemm_epi_swap; p.tail_half = config().gemm_tail_half; p.sched = pp_sched_ws();
   p.group_m = config().gemm_group_m;
   int grid = p.tiles_m * p.tiles_n;

@@ -21,6 +21,11 @@ struct GemmArgs {
   float alpha;                  // fp8 kernel only: C = alpha * (A B^T) before the epilogue (product of the tensor scales)
   const float* row_scale = nullptr;   // fp8 kernel only, optional: C[m, :] *= row_scale[m]  (per-token activation de-scale)
   const float* col_scale = nullptr;   // fp8 kernel only, optional: C[:, n] *= col_scale[n]  (per-output-channel weight de-scale)
+  // LayerNorm folded into the GEMMs of the frozen CLIP tower (fp16 kernel only; hvlm_gemm_f16_nt_ln):
+  float* stats_out = nullptr;         //   producer (residual epilogue): partial (sum, sum of squares) of every OUTPUT row over this wave's 64
+                                      //   columns, [M][tiles_n * 4][2] fp32, each entry written by exactly one wave (deterministic)
+  const float* ln_stats = nullptr;    //   consumer: (mean, rstd) of every A row [M][2]; C = rstd * (A B^T - mean * ln_c1) + bias (B = W (.) ln_w)
+  const float* ln_c1 = nullptr;       //   consumer: c1[n] = sum_k B[n, k] (fp32 [N])
   const float* out_inv = nullptr;     // fp8 kernel only, optional: C is e4m3 BYTES, C[m, n] = e4m3(clamp(bf16(v) / out_inv[m])) — the
                                       // next GEMM's A operand with row_scale = out_inv (no residual in this mode)
 };

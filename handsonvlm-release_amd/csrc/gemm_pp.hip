@@ -128,6 +128,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #else
   constexpr bool HALF_OK = false;                   // production: every unit is a whole tile, the code below folds away
 #endif
+  constexpr bool LNF = F16 && M16 && !EPI_SWAP && !TN && !FP8;   // LayerNorm-fold epilogue modes: the CLIP tower's fp16 kernel only
   using EL = E16<F16>;                      // 16-bit element type of A / B / C / bias / residual: bfloat16 or IEEE half
   constexpr int ES = FP8 ? 1 : 2;          // operand element size in bytes
   constexpr int NKS = FP8 ? 2 : 4;         // MFMA k-steps per K-tile
@@ -621,6 +622,32 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
               osc[ip][q] = p.out_inv[min(m0 + (ip >> 1) * 128 + grp * 64 + (ip & 1) * 32 + t_row + 16 * q, p.M - 1)];
         }
       }
+      // LayerNorm fold (consumer side): the A rows are the RAW residual stream and B = W (.) ln_w, so that
+      //   LN(x) W^T + b = rstd * (x B^T - mean * c1) + (b + W ln_b),  c1[n] = sum_k B[n, k]
+      // — the normalised operand is never written or read (CLIPEncoderLayer.layer_norm1 -> q|k|v, layer_norm2 -> fc1).  Per lane:
+      // (mean, rstd) of its 8 rows and c1 of its 16 columns, loaded once per tile.
+      float lmu[4][2], lrs[4][2], c1f[2][2][4];
+      bool lnf = false;
+      if constexpr (LNF) {
+        lnf = p.ln_stats != nullptr;
+        if (lnf) {
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int row = min(m0 + (ii >> 1) * 128 + grp * 64 + (ii & 1) * 32 + h * 16 + l15, p.M - 1);
+              const f32x2 mr = *reinterpret_cast<const f32x2*>(p.ln_stats + 2 * (size_t)row);
+              lmu[ii][h] = mr[0]; lrs[ii][h] = mr[1];
+            }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hc = 0; hc < 2; ++hc) {
+              const f32x4 cc = *reinterpret_cast<const f32x4*>(p.ln_c1 + col_of(n0, j, 2 * hc));
+              c1f[j][hc][0] = cc[0]; c1f[j][hc][1] = cc[1]; c1f[j][hc][2] = cc[2]; c1f[j][hc][3] = cc[3];
+            }
+        }
+      }
       u32x4 o_prev[2];
       const int f_lo = 2 * i_lo, f_hi = 2 * i_hi;       // fragments of this unit (a half-tile unit: 4 of the 8)
 #pragma unroll
@@ -633,6 +660,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
+            if constexpr (LNF) {
+              if (lnf) {
+                const float nmu = -lmu[i][g & 1], rs = lrs[i][g & 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(nmu, c1f[j][g >> 1][e], v[e]) * rs;
+              }
+            }
             if (p.bias) {
               const u32x2 bb = bias_q[j][g];
               v[0] += EL::lo(bb[0]); v[1] += EL::hi(bb[0]); v[2] += EL::lo(bb[1]); v[3] += EL::hi(bb[1]);
@@ -707,6 +741,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) res_r[j][q] = res_n[j][q];
       if (i + 1 < i_hi) load_res(i + 1, res_n);
+      float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};      // LayerNorm fold (producer side): sum / sum of squares of this lane's outputs
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // accumulator layout -> LDS: row l31, 16-B chunk (2g + hi) at chunk position (2g + hi) ^ (l31 & 7)
@@ -737,9 +772,38 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             for (int e = 0; e < 4; ++e) { v[2 * e] += EL::lo(rr[e]); v[2 * e + 1] += EL::hi(rr[e]); }
           }
           const int m = mrow0 + 16 * q;
-          if (m < p.M) {
-            const u32x4 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3]), EL::pack2(v[4], v[5]), EL::pack2(v[6], v[7])};
-            store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
+          const u32x4 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3]), EL::pack2(v[4], v[5]), EL::pack2(v[6], v[7])};
+          if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
+          if constexpr (LNF) {
+            if (p.stats_out) {                 // statistics of the values AS STORED (rounded to 16 bits): what the consumer reads
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a = EL::lo(o[e]), b = EL::hi(o[e]);
+                st1[q] += a + b;
+                st2[q] = __builtin_fmaf(a, a, st2[q]);
+                st2[q] = __builtin_fmaf(b, b, st2[q]);
+              }
+            }
+          }
+        }
+      }
+      if constexpr (LNF) {
+        if (p.stats_out) {
+          // the four lanes t_c = 0..3 of a row hold its 4 x 8 columns per j: quad reduction, lane 0 of the quad writes the wave's
+          // partial for (row, tile column, wave column block) — one writer per entry, fixed order: deterministic
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float s1 = st1[q], s2 = st2[q];
+            s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0xB1, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xB1, 0xF, 0xF, true));
+            s1 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s1), 0x4E, 0xF, 0xF, true));
+            s2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0x4E, 0xF, 0xF, true));
+            const int m = mrow0 + 16 * q;
+            if (t_c == 0 && m < p.M) {
+              const size_t part = (size_t)(n0 / BN) * 4 + wn;
+              const u32x2 sv = {__float_as_uint(s1), __float_as_uint(s2)};
+              store8_untracked(p.stats_out + ((size_t)m * (p.tiles_n * 4) + part) * 2, sv);
+            }
           }
         }
       }

@@ -528,6 +528,33 @@ extern "C" int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, fl
   return check_launch("rmsnorm_fwd_fp8");
 }
 
+namespace hvlm {
+namespace {
+// (mean, rstd) of every row from the per-wave partial sums the producer GEMM's epilogue wrote (hvlm_gemm_f16_nt_ln): one thread
+// per row, the n_parts partials added in index order — deterministic.  var = E[x^2] - mean^2 in fp32.
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int rows,
+                                                                int n_parts, float inv_d, float eps) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const f32x2* p = reinterpret_cast<const f32x2*>(part) + (size_t)r * n_parts;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < n_parts; ++i) { const f32x2 v = p[i]; s1 += v[0]; s2 += v[1]; }
+  const float mean = s1 * inv_d;
+  const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
+  const f32x2 o = {mean, rsqrtf(var + eps)};
+  reinterpret_cast<f32x2*>(stats)[r] = o;
+}
+}  // namespace
+}  // namespace hvlm
+
+extern "C" int hvlm_ln_stats_finalize(const float* part, float* stats, int rows, int n_parts, int D, float eps, void* stream) {
+  HVLM_REQUIRE(part && stats && rows > 0 && n_parts > 0 && D > 0, "ln_stats_finalize: bad args");
+  HVLM_REQUIRE(((uintptr_t)part & 7) == 0 && ((uintptr_t)stats & 7) == 0, "ln_stats_finalize: 8-byte alignment");
+  hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), part, stats, rows, n_parts,
+                     1.0f / (float)D, eps);
+  return check_launch("ln_stats_finalize");
+}
+
 extern "C" int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
                                       float bound_mul, float bound_add, int rows, int D, float eps, void* stream) {
   HVLM_REQUIRE(x && w && b && out8 && inv_scale, "layernorm_fwd_fp8: null pointer");

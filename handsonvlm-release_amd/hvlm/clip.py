@@ -23,6 +23,7 @@ from . import ops
 from .config import CLIPVisionConfig
 
 BF16 = torch.bfloat16
+_FOLD_LN = os.environ.get("HVLM_CLIP_FOLD_LN", "1") == "1"   # 0: explicit LayerNorm passes between the GEMMs of the fp16 tower (A/B)
 
 
 class CLIPVisionTower:
@@ -89,6 +90,7 @@ class CLIPVisionTower:
             p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = g(lp + "mlp.fc2.weight"), g(lp + "mlp.fc2.bias")
         self.p = p
         self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
+        self._pf = None                      # LayerNorm-folded copies (_fold_prepare) too
         self.is_loaded = True
         return self
 
@@ -112,8 +114,28 @@ class CLIPVisionTower:
             p[f"{i}.fc2_w"], p[f"{i}.fc2_b"] = rn(d, m), rn(d)
         self.p = p
         self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
+        self._pf = None
         self.is_loaded = True
         return self
+
+    # -- LayerNorm folded into q|k|v and fc1 (fp16 tower) ------------------------------------------
+    @torch.no_grad()
+    def _fold_prepare(self) -> None:
+        """The tower is frozen, so layer_norm1 / layer_norm2 can be folded into the GEMMs that consume them once, at load
+        time: LN(x) W^T + b = rstd (x (W (.) ln_w)^T - mean c1) + (b + W ln_b), c1 = row sums of W (.) ln_w.  The GEMM then
+        reads the RAW residual stream and applies (mean, rstd) per row in its epilogue (hvlm_gemm_f16_nt_ln); the statistics
+        come from the epilogue of the GEMM that wrote that stream.  The 268-us LayerNorm pass (and its 0.84 GB round trip)
+        between every pair of GEMMs of the tower disappears: 2 of the 47 passes of a forward remain."""
+        p, q = self.p, {}
+        for i in range(self.n_run):
+            for name, lnk in (("qkv", "ln1"), ("fc1", "ln2")):
+                W = p[f"{i}.{name}_w"].float()
+                ln_w, ln_b = p[f"{i}.{lnk}_w"].float(), p[f"{i}.{lnk}_b"].float()
+                Wf = (W * ln_w[None, :]).to(torch.float16).contiguous()
+                q[f"{i}.{name}_wf"] = Wf
+                q[f"{i}.{name}_c1"] = Wf.float().sum(1).contiguous()                       # of the ROUNDED folded weights: what the MFMA multiplies
+                q[f"{i}.{name}_c2"] = (p[f"{i}.{name}_b"].float() + W @ ln_b).to(torch.float16).contiguous()
+        self._pf = q
 
     # -- fp8 forward (BASELINE config 5) ----------------------------------------------------------
     @torch.no_grad()
@@ -172,6 +194,8 @@ class CLIPVisionTower:
         del pe
         x = ln(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
         scale = dh ** -0.5
+        if f16 and _FOLD_LN and d % 256 == 0 and cfg.intermediate_size % 256 == 0:
+            return self._forward_layers_folded(x, N, T, out)
         for i in range(self.n_run):
             y = ln(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
             qkv = mm(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
@@ -190,6 +214,44 @@ class CLIPVisionTower:
         elif out is not None:
             out.view(N * T, d).copy_(x)
             x = out
+        return x.view(N, T, d)
+
+    def _forward_layers_folded(self, x: torch.Tensor, N: int, T: int, out: Optional[torch.Tensor]) -> torch.Tensor:
+        """The encoder layers with layer_norm1 / layer_norm2 folded into q|k|v / fc1 (see _fold_prepare): per layer
+        q|k|v GEMM (LN fold) -> attention -> out_proj GEMM (+residual, row statistics) -> fc1 GEMM (LN fold, QuickGELU) ->
+        fc2 GEMM (+residual, row statistics).  Layer 0's layer_norm1 is the one explicit pass left (its input comes from
+        pre_layrnorm, not from a GEMM)."""
+        cfg, p = self.cfg, self.p
+        if getattr(self, "_pf", None) is None:
+            self._fold_prepare()
+        q = self._pf
+        d, heads = cfg.hidden_size, cfg.num_attention_heads
+        dh, M, eps = d // heads, x.shape[0], cfg.layer_norm_eps
+        scale = dh ** -0.5
+        nparts = ops.ln_stats_parts(d)
+        part = torch.empty((M, nparts, 2), dtype=torch.float32, device=x.device)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+        have = False
+        for i in range(self.n_run):
+            if not have:
+                y = ops.layernorm_fwd_f16(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], eps)
+                qkv = ops.gemm_f16_nt(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
+                del y
+            else:
+                qkv = ops.gemm_f16_nt_ln(x, q[f"{i}.qkv_wf"], bias=q[f"{i}.qkv_c2"], ln=(stats, q[f"{i}.qkv_c1"]))
+            a = ops.attn_fwd_f16(qkv, N, T, heads, dh, scale)
+            del qkv
+            x = ops.gemm_f16_nt_ln(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x, stats_out=part)
+            del a
+            ops.ln_stats_finalize(part, M, nparts, d, eps, out=stats)
+            hmid = ops.gemm_f16_nt_ln(x, q[f"{i}.fc1_wf"], bias=q[f"{i}.fc1_c2"], act=ops.ACT_QUICK_GELU, ln=(stats, q[f"{i}.fc1_c1"]))
+            last = i == self.n_run - 1
+            x = ops.gemm_f16_nt_ln(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x, stats_out=None if last else part)
+            del hmid
+            if not last:
+                ops.ln_stats_finalize(part, M, nparts, d, eps, out=stats)
+            have = True
+        x = ops.cast16(x, BF16, out=None if out is None else out.view(N * T, d))
         return x.view(N, T, d)
 
     def _forward_tokens_fp8(self, images: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:

@@ -729,6 +729,48 @@ def gemm_f16_nt(a, b, bias=None, residual=None, act: int = ACT_NONE, out=None):
     return out
 
 
+def gemm_f16_nt_ln(a, b, bias=None, residual=None, act: int = ACT_NONE, out=None, stats_out=None, ln=None):
+    """gemm_f16_nt with the LayerNorm-fold epilogues (hvlm_gemm_f16_nt_ln).  stats_out: fp32 [M, ln_stats_parts(N), 2] to receive
+    the per-row partial sums of the output (needs `residual`); ln = (stats [M, 2] fp32 = (mean, rstd) of a's rows, c1 fp32 [N])."""
+    _chk(a, F16, "gemm_f16_ln.a"); _chk(b, F16, "gemm_f16_ln.b")
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F16, device=a.device)
+    ldr = 0
+    if residual is not None:
+        _chk(residual, F16, "gemm_f16_ln.residual")
+        ldr = residual.stride(0)
+    st, c1 = (None, None) if ln is None else ln
+    if st is not None:
+        _chk(st, torch.float32, "gemm_f16_ln.stats"); _chk(c1, torch.float32, "gemm_f16_ln.c1")
+        assert st.shape == (M, 2) and st.is_contiguous() and c1.numel() == N
+    if stats_out is not None:
+        _chk(stats_out, torch.float32, "gemm_f16_ln.stats_out")
+        assert stats_out.is_contiguous() and stats_out.numel() == M * ln_stats_parts(N) * 2
+    hook = _gemm_hook
+    if hook is not None:
+        hook(M, N, K, True)
+    check(_lib.load().hvlm_gemm_f16_nt_ln(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0), out.stride(0), _p(bias), _p(residual),
+                                          ldr, act, _p(stats_out), _p(st), _p(c1), _stream()), "gemm_f16_nt_ln")
+    if hook is not None:
+        hook(M, N, K, False)
+    return out
+
+
+def ln_stats_parts(N: int) -> int:
+    return int(_lib.load().hvlm_ln_stats_parts(N))
+
+
+def ln_stats_finalize(part: torch.Tensor, rows: int, n_parts: int, D: int, eps: float, out=None) -> torch.Tensor:
+    """Per-wave partial (sum, sum of squares) [rows, n_parts, 2] -> (mean, rstd) [rows, 2] (fp32)."""
+    _chk(part, torch.float32, "ln_stats_finalize.part")
+    st = torch.empty((rows, 2), dtype=torch.float32, device=part.device) if out is None else out
+    check(_lib.load().hvlm_ln_stats_finalize(_p(part), _p(st), rows, n_parts, D, eps, _stream()), "ln_stats_finalize")
+    return st
+
+
 def layernorm_fwd_f16(x, w, b, eps: float, out=None):
     _chk(x, F16, "layernorm_f16.x")
     assert x.is_contiguous()

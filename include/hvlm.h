@@ -406,6 +406,21 @@ int hvlm_rmsnorm_fwd_fp8(const void* x, const void* w, void* out8, float* inv_sc
  * a GEMM that consumes this row and writes e4m3 itself (hvlm_gemm_fp8_nt_scaled_q8). */
 int hvlm_layernorm_fwd_fp8(const void* x, const void* w, const void* b, void* out8, float* inv_scale, float* next_inv,
                            float bound_mul, float bound_add, int rows, int D, float eps, void* stream);
+/* LayerNorm folded into the GEMMs around it (frozen CLIP tower, fp16): CLIPEncoderLayer computes layer_norm1 -> q|k|v and
+ * layer_norm2 -> fc1 (transformers modeling_clip, called from clip_encoder.py:48).  Since LN(x) W^T + b =
+ * rstd * (x (W (.) ln_w)^T - mean * c1) + (b + W ln_b) with c1[n] = sum_k (W (.) ln_w)[n, k], the normalised tensor never has to
+ * exist: the GEMM that PRODUCES the residual stream x (out_proj / fc2, residual epilogue) also writes, per row, the partial
+ * (sum, sum of squares) of its outputs as stored (`stats_out`: fp32 [M, hvlm_ln_stats_parts(N), 2], one writer per entry);
+ * hvlm_ln_stats_finalize turns them into (mean, rstd) [M, 2]; the GEMM that CONSUMES x (q|k|v / fc1: B = W (.) ln_w, bias =
+ * b + W ln_b prepared once by the host, `ln_c1` = c1 as fp32 [N], 16-byte aligned) applies them in its epilogue.  Differences from the reference's
+ * arithmetic: the normalised row is not rounded to fp16 before the product (more exact), variance = E[x^2] - mean^2 in fp32.
+ * stats_out requires a residual and N % 256 == 0; ln_stats / ln_c1 come together, take no residual, N % 256 == 0.
+ * With all three NULL this is hvlm_gemm_f16_nt. */
+size_t hvlm_ln_stats_parts(int N);
+int hvlm_gemm_f16_nt_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                        const void* bias, const void* residual, int ldr, int act, float* stats_out, const float* ln_stats,
+                        const float* ln_c1, void* stream);
+int hvlm_ln_stats_finalize(const float* part, float* stats, int rows, int n_parts, int D, float eps, void* stream);
 int hvlm_clip_embed_f16(const void* patch_out, const void* cls, const void* pos, void* tokens, int N, int NP, int D,
                         void* stream);
 int hvlm_attn_fwd_f16(const void* qkv, void* out, float* lse, void* ws, int B, int S, int H, int dh, int ld, int causal,

@@ -405,6 +405,43 @@ def gemm_f16_nt(a, b, bias=None, residual=None, act=ACT_NONE, out=None):
     return y
 
 
+def ln_stats_parts(N):
+    return (N + 255) // 256 * 4
+
+
+def gemm_f16_nt_ln(a, b, bias=None, residual=None, act=ACT_NONE, out=None, stats_out=None, ln=None):
+    """Stand-in of hvlm_gemm_f16_nt_ln: the same function (fp32 accumulation, one fp16 rounding), partial statistics of the
+    ROUNDED outputs per 64-column block."""
+    acc = a.float() @ b.float().t()
+    if ln is not None:
+        st, c1 = ln
+        acc = (acc - st[:, :1] * c1.float()[None, :]) * st[:, 1:2]
+    if bias is not None:
+        acc = acc + bias.float()
+    if act == ACT_QUICK_GELU:
+        acc = acc * torch.sigmoid(1.702 * acc)
+    if residual is not None:
+        acc = acc + residual.float()
+    y = acc.to(F16)
+    if stats_out is not None:
+        blocks = y.float().view(y.shape[0], -1, 64)
+        stats_out.view(y.shape[0], -1, 2).copy_(torch.stack([blocks.sum(-1), (blocks * blocks).sum(-1)], -1))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def ln_stats_finalize(part, rows, n_parts, D, eps, out=None):
+    s = part.view(rows, n_parts, 2).sum(1)
+    mean = s[:, 0] / D
+    st = torch.stack([mean, torch.rsqrt((s[:, 1] / D - mean * mean).clamp_min(0) + eps)], 1)
+    if out is not None:
+        out.copy_(st)
+        return out
+    return st
+
+
 def layernorm_fwd_f16(x, w, b, eps, out=None):
     y = F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps).to(F16)
     if out is not None:

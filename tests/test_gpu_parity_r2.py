@@ -383,11 +383,22 @@ def test_clip_tower_fp16_vit_l14_vs_oracle(px):
     tower = CLIPVisionTower(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
                                              num_attention_heads=16, image_size=px), "cuda:0", dtype=torch.float16)
     tower.load_state_dict(p)
+    from hvlm import clip as clip_mod
+    assert clip_mod._FOLD_LN                                               # the default: layer_norm1 / 2 folded into q|k|v / fc1
     got = tower(img.cuda())
+    assert tower._pf is not None                                           # (the folded path was the one taken)
     assert got.dtype == BF and got.shape == (3, (px // 14) ** 2, 1024)     # features cast back to the frames' dtype
     e_env, e_hip = rel(env.to(BF), ref), rel(got, ref)
-    print(f"ViT-L/14 tower fp16: HIP vs fp32 oracle {e_hip:.3e}; fp16-eager oracle (cast to bf16) vs fp32 oracle {e_env:.3e}")
+    clip_mod._FOLD_LN = False                                              # the explicit LayerNorm passes (HVLM_CLIP_FOLD_LN=0)
+    try:
+        got_ln = tower(img.cuda())
+    finally:
+        clip_mod._FOLD_LN = True
+    e_ln = rel(got_ln, ref)
+    print(f"ViT-L/14 tower fp16: HIP vs fp32 oracle {e_hip:.3e} (explicit LayerNorm passes: {e_ln:.3e}, fold vs explicit {rel(got, got_ln):.3e}); "
+          f"fp16-eager oracle (cast to bf16) vs fp32 oracle {e_env:.3e}")
     assert e_hip <= 1.25 * e_env and e_hip <= 6e-3, (e_hip, e_env)
+    assert e_ln <= 1.25 * e_env and rel(got, got_ln) <= 3e-3
 
 
 def test_swiglu_fused_transposed_outputs(ops):
@@ -424,3 +435,48 @@ def test_attention_backward_with_fused_inverse_rope_is_bit_identical(ops, lens, 
     got = ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu, rope=(cos, sin, pos))
     assert torch.equal(got, ref)
     assert not torch.equal(got[:, : H * dh], ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)[:, : H * dh])
+
+
+@pytest.mark.parametrize("M,K,N1", [(1000, 1024, 3072), (25700, 1024, 4096), (257, 256, 512)])
+def test_layernorm_fold_epilogues_vs_explicit_layernorm(ops, M, K, N1):
+    """hvlm_gemm_f16_nt_ln, the two halves of the LayerNorm fold of the frozen CLIP tower (CLIPEncoderLayer.layer_norm1 -> q|k|v,
+    layer_norm2 -> fc1): (i) the producer GEMM (out_proj / fc2: bias + residual) writes per-row partial (sum, sum of squares)
+    of its ROUNDED outputs, hvlm_ln_stats_finalize turns them into (mean, rstd) — equal to the statistics of the stored rows;
+    (ii) the consumer GEMM on the raw rows with W (.) ln_w, c1, b + W ln_b reproduces LayerNorm -> Linear (-> QuickGELU): checked
+    against the fp32 oracle arithmetic and against this library's own explicit path (LayerNorm kernel + GEMM), ragged M."""
+    g = torch.Generator(device="cuda").manual_seed(M + N1)
+    F16 = torch.float16
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(F16)
+    wo = (torch.randn(K, K, device="cuda", generator=g) * K ** -0.5).to(F16)
+    bo = (torch.randn(K, device="cuda", generator=g) * 0.1).to(F16)
+    res = (torch.randn(M, K, device="cuda", generator=g) * 2.0 + 0.7).to(F16)
+    res[:, 5] *= 25.0                                                      # an outlier channel, as CLIP's residual stream has
+    nparts = ops.ln_stats_parts(K)
+    part = torch.full((M, nparts, 2), float("nan"), dtype=torch.float32, device="cuda")
+    x = ops.gemm_f16_nt_ln(a, wo, bias=bo, residual=res, stats_out=part)
+    assert torch.equal(x, ops.gemm_f16_nt(a, wo, bias=bo, residual=res))    # the statistics ride along: the output is unchanged
+    st = ops.ln_stats_finalize(part, M, nparts, K, 1e-5)
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = torch.rsqrt(xf.var(1, unbiased=False) + 1e-5)
+    assert torch.allclose(st[:, 0], mean, rtol=1e-5, atol=1e-5) and torch.allclose(st[:, 1], rstd, rtol=2e-4)
+    assert torch.equal(st, ops.ln_stats_finalize(part, M, nparts, K, 1e-5))
+    # consumer
+    ln_w = (1.0 + 0.3 * torch.randn(K, device="cuda", generator=g)).to(F16)
+    ln_b = (0.2 * torch.randn(K, device="cuda", generator=g)).to(F16)
+    w1 = (torch.randn(N1, K, device="cuda", generator=g) * K ** -0.5).to(F16)
+    b1 = (torch.randn(N1, device="cuda", generator=g) * 0.1).to(F16)
+    wf = (w1.float() * ln_w.float()[None, :]).to(F16).contiguous()
+    c1 = wf.float().sum(1).contiguous()
+    c2 = (b1.float() + w1.float() @ ln_b.float()).to(F16).contiguous()
+    for act in (ops.ACT_NONE, ops.ACT_QUICK_GELU):
+        got = ops.gemm_f16_nt_ln(x, wf, bias=c2, act=act, ln=(st, c1))
+        y = torch.nn.functional.layer_norm(xf, (K,), ln_w.float(), ln_b.float(), 1e-5)
+        ref = y @ w1.float().t() + b1.float()
+        explicit = ops.gemm_f16_nt(ops.layernorm_fwd_f16(x, ln_w, ln_b, 1e-5), w1, bias=b1, act=act)
+        if act:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        e_fold, e_expl = rel(got, ref), rel(explicit, ref)
+        print(f"M={M} N={N1} act={act}: fold {e_fold:.2e}  explicit LayerNorm + GEMM {e_expl:.2e}")
+        assert torch.isfinite(got.float()).all()
+        assert e_fold <= 1e-3 and e_fold <= 1.2 * e_expl + 1e-4      # at least as close to the fp32 arithmetic as the explicit path
