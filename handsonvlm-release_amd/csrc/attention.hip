@@ -605,6 +605,62 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
             o[db] = E16<F16>::mfma32(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db]);
         }
     };
+    // The LAST compute wave when it holds ONE useful query (S = 32 (nw - 2) + 1: CLIP's 257 tokens = 8 x 32 + 1).  In the layout
+    // above it would run the whole softmax — 16 score registers per key block, 144 exponentials per lane — for a single valid
+    // lane pair, and it is the third wave of its SIMD: the kernel is VALU-issue-bound (DESIGN.md §3 "Attention, round 3"), so that
+    // SIMD, and with it every item, took 3 wave-loads where the others carry 2.  With the MFMA operands SWAPPED (S = Q K^T: A = the
+    // query fragment, all 32 rows the same clamped query, B = a K fragment) the LANES are the keys and every accumulator register
+    // holds the same row: one score register per 32-key block, 9 exponentials per lane instead of 144.  All nine blocks' scores
+    // fit in registers, so the softmax is a plain two-pass one (wave-wide max, then exp and sum); P goes through a 1-KiB
+    // wave-private LDS strip to reach the k-slot order of the V^T fragments, and P V is the usual MFMA (every column = the one query).
+    const bool solo = (w == nw - 2) && (S - w * 32 == 1);
+    if (solo) {
+      float s9[9];
+#pragma unroll
+      for (int kb = 0; kb < 9; ++kb) {
+        s9[kb] = -INFINITY;
+        if (kb < nkb) {
+          f32x16 sx;
+#pragma unroll
+          for (int ks = 0; ks < DH / 16; ++ks) {
+            const bf16x8 kf = lds_frag128(smem, base + k_off[ks] + (unsigned)(kb * 32) * ROWB);
+            sx = E16<F16>::mfma32(qf[ks], kf, ks == 0 ? zero16 : sx);
+          }
+          s9[kb] = (kb * 32 + l31 < S) ? sx[0] : -INFINITY;         // lane l31 (both half-waves alike) = key kb*32 + l31
+        }
+      }
+      float mx = s9[0];
+#pragma unroll
+      for (int kb = 1; kb < 9; ++kb) mx = fmaxf(mx, s9[kb]);
+      m = wave_max_dpp(mx) * scale_log2;
+      char* strip = smem + 2 * buf_bytes;                            // [nkb * 32] 16-bit probabilities, key order
+      float ls = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 9; ++kb) {
+        if (kb < nkb) {
+          const float pk = fast_exp2(__builtin_fmaf(s9[kb], scale_log2, -m));
+          ls += pk;
+          if (hi == 0) reinterpret_cast<bf16_t*>(strip)[kb * 32 + l31] = E16<F16>::from_f(pk);
+        }
+      }
+      lsum = wave_sum_dpp(ls) * 0.25f;        // both half-waves hold every key once: the wave-wide sum counts each probability twice, and
+                                              // the epilogue adds the other half-wave's lsum again (ltot = lsum + xlane32(lsum))
+#pragma unroll
+      for (int kb = 0; kb < 9; ++kb) {
+        if (kb < nkb) {
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            // k-slot j of this lane = key kb*32 + crow(8 sp + j, hi) = b + {0,1,2,3, 8,9,10,11}, b = kb*32 + 16 sp + 4 hi (the order
+            // in which the V^T fragments hold their keys, see v_off)
+            const unsigned b = (unsigned)(kb * 32 + 16 * sp + 4 * hi) * 2u;
+            const bf16x8 pf = lds_frag64x2(strip, b, b + 16u);
+#pragma unroll
+            for (int db = 0; db < DH / 32; ++db)
+              o[db] = E16<F16>::mfma32(v_frag(db, (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db]);
+          }
+        }
+      }
+    } else
     {
       const int nfull = S / 64;                     // key tiles without a tail
       int kb0 = 0;
@@ -1332,7 +1388,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
     // short sequences: K/V resident in LDS, one workgroup per (batch, head), no V^T pre-pass
     const int nkb = (S + 31) / 32;
     if (nkb <= 9 && !config().attn_no_resident) {
-      const int lds = 2 * 2 * nkb * 32 * DH * 2;       // two (K + V) buffers
+      const int lds = 2 * 2 * nkb * 32 * DH * 2 + 1024;   // two (K + V) buffers + the one-query wave's probability strip
       rc = set_lds(attn_fwd_resident_kernel<DH, F16>, lds, "attn_fwd_resident");
       if (rc) return rc;
       static int cus = 0;
