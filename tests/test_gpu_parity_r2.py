@@ -437,7 +437,7 @@ def test_attention_backward_with_fused_inverse_rope_is_bit_identical(ops, lens, 
     assert not torch.equal(got[:, : H * dh], ops.attn_bwd(qkv, o, do, lse, B, S, H, dh, True, dh ** -0.5, cu_seqlens=cu)[:, : H * dh])
 
 
-@pytest.mark.parametrize("M,K,N1", [(1000, 1024, 3072), (25700, 1024, 4096), (257, 256, 512)])
+@pytest.mark.parametrize("M,K,N1", [(1000, 1024, 3072), (25700, 1024, 4096), (257, 256, 512), (513, 768, 1024)])
 def test_layernorm_fold_epilogues_vs_explicit_layernorm(ops, M, K, N1):
     """hvlm_gemm_f16_nt_ln, the two halves of the LayerNorm fold of the frozen CLIP tower (CLIPEncoderLayer.layer_norm1 -> q|k|v,
     layer_norm2 -> fc1): (i) the producer GEMM (out_proj / fc2: bias + residual) writes per-row partial (sum, sum of squares)
