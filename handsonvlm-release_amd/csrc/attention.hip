@@ -454,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 //   9 x 32 by 9 x 32 (1.26x).  Same online-softmax body, 64 keys per step.
 // =================================================================================================
 
-template <int DH, bool F16 = false>
+template <int DH, bool F16 = false, int SC = 0>
 __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t* __restrict__ qkv,
                                                                    bf16_t* __restrict__ out,
                                                                    float* __restrict__ lse, int S, int H, int ld,
@@ -520,13 +520,23 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
   int item = blockIdx.x;
   if (loader) issue_kv(item, 0);
   else load_q(item, qf);
+#ifdef HVLM_ATTN_PROF
+  long long t_bar = 0, t_body = 0, t_epi = 0, t_qk = 0, t_sm = 0, t_pv = 0, t_all0 = __builtin_readcyclecounter();
+#endif
   for (unsigned it = 0; item < nitems; ++it, item += (int)gridDim.x) {
     const unsigned base = (it & 1u) * buf_bytes;
+#ifdef HVLM_ATTN_PROF
+    const long long c0 = __builtin_readcyclecounter();
+#endif
     // Loader: K/V of this item landed (a real S_WAITCNT, not inline asm: the compiler's wait-count pass must see it).
     // Compute waves wait for nothing here: their next Q fragments were moved into place before the output stores of
     // the previous item were issued, so those stores (write acknowledgements) are never waited for.
     if (loader) __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();                                     // everyone is done with the other buffer
+#ifdef HVLM_ATTN_PROF
+    const long long c1 = __builtin_readcyclecounter();
+    t_bar += c1 - c0;
+#endif
     const int nitem = item + (int)gridDim.x;
     if (loader) {
       if (nitem < nitems) issue_kv(nitem, buf_bytes - base);
@@ -605,6 +615,138 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
             o[db] = E16<F16>::mfma32(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db]);
         }
     };
+    // SC > 0 (the sequence length is a compile-time constant: CLIP's 257): the tile sequence is unrolled and software-pipelined BY
+    // HAND around the LDS latency.  Left to the compiler (tile_body above, 168-register budget) every ds_read sits right in front
+    // of the MFMA that consumes it — sixteen exposed LDS round trips per 64-key tile, ~ 1 900 cycles per tile and wave where the
+    // instruction mix needs ~ 850 (profiles/r03k_clip_attention_lds_pipeline.txt).  Here every batch of fragment reads has other
+    // work to land under:
+    //   QK^T: second half of the K fragments requested, MFMAs of the first half (requested during the previous tile's P V), MFMAs
+    //   of the second  ->  V^T fragments of the first key block requested  ->  softmax (VALU)  ->  V^T fragments of the second key
+    //   block and the first half of the NEXT tile's K fragments requested  ->  P V MFMAs.
+    // With kv0 a constant all LDS addresses are (4 + 4 per-item registers) + instruction offsets.
+    constexpr int KH = DH / 16;        // fragments per half K set: DH/32 k-steps x 2 key blocks
+    unsigned ka[DH / 16], va[DH / 32][2];
+    if constexpr (SC > 0) {
+#pragma unroll
+      for (int ks = 0; ks < DH / 16; ++ks) ka[ks] = base + k_off[ks];
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db) { va[db][0] = base + v_off[db][0]; va[db][1] = base + v_off[db][1]; }
+    }
+    auto k_issue = [&](auto kv0_tag, auto ks0_tag, bf16x8 (&kf)[KH]) {
+      constexpr unsigned kvb = (unsigned)decltype(kv0_tag)::value * ROWB;
+      constexpr int ks0 = decltype(ks0_tag)::value;
+#pragma unroll
+      for (int ks = 0; ks < DH / 32; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) kf[ks * 2 + kb] = lds_frag128(smem, ka[ks0 + ks] + kvb + (unsigned)(kb * 32) * ROWB);
+    };
+    auto v_frag_c = [&](int db, unsigned key_bytes) -> bf16x8 {
+      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][0] + key_bytes));
+      const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][1] + key_bytes));
+      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    // `kc`: first half of this tile's K fragments (in registers on entry); `kn`: receives the first half of the next tile's
+    auto tile_fixed = [&](auto kv0_tag, auto nkb_tag, auto prefetch_tag, const bf16x8 (&kc)[KH], bf16x8 (&kn)[KH]) {
+      constexpr int kv0 = decltype(kv0_tag)::value;
+      constexpr int NKB = decltype(nkb_tag)::value;
+      constexpr bool MASK = kv0 + NKB * 32 > SC;
+      constexpr unsigned kvb = (unsigned)kv0 * ROWB;
+      f32x16 sc[NKB];
+#ifdef HVLM_ATTN_PROF
+      const long long p0 = __builtin_readcyclecounter();
+#endif
+      {
+        bf16x8 kh[KH];
+        k_issue(kv0_tag, std::integral_constant<int, DH / 32>{}, kh);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ++ks)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) sc[kb] = E16<F16>::mfma32(kc[ks * 2 + kb], qf[ks], ks == 0 ? zero16 : sc[kb]);
+#pragma unroll
+        for (int ks = 0; ks < DH / 32; ++ks)
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) sc[kb] = E16<F16>::mfma32(kh[ks * 2 + kb], qf[DH / 32 + ks], sc[kb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef HVLM_ATTN_PROF
+      const long long p1 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      bf16x8 vf[NKB][2][DH / 32];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db) vf[0][sp][db] = v_frag_c(db, kvb + (unsigned)(16 * sp) * ROWB);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MASK) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kv0 + kb * 32 + crow(r, hi) >= SC) sc[kb][r] = -INFINITY;
+      }
+      float mx = sc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
+      mx = fmaxf(mx, xlane32(mx));
+      const float mnew = fmaxf(m, mx * scale_log2);
+      if (__builtin_amdgcn_ballot_w64(mnew > m)) {
+        const float alpha = fast_exp2(m - mnew);
+        lsum *= alpha;
+#pragma unroll
+        for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        m = mnew;
+      }
+      float psum0 = 0.f, psum1 = 0.f;
+      bf16x8 pf[NKB][2];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = fast_exp2(__builtin_fmaf(sc[kb][r], scale_log2, -m));
+          const float p1 = fast_exp2(__builtin_fmaf(sc[kb][r + 1], scale_log2, -m));
+          sc[kb][r] = p0; sc[kb][r + 1] = p1;
+          psum0 += p0; psum1 += p1;
+        }
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = sc[kb][8 * sp + j];
+          pf[kb][sp] = pack8<F16>(pv);
+        }
+      }
+      lsum += psum0 + psum1;
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef HVLM_ATTN_PROF
+      const long long p2 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if constexpr (NKB == 2) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db) vf[1][sp][db] = v_frag_c(db, kvb + (unsigned)(32 + 16 * sp) * ROWB);
+      }
+      if constexpr (decltype(prefetch_tag)::value) k_issue(std::integral_constant<int, kv0 + 64>{}, std::integral_constant<int, 0>{}, kn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+          for (int db = 0; db < DH / 32; ++db) o[db] = E16<F16>::mfma32(vf[kb][sp][db], pf[kb][sp], o[db]);
+#ifdef HVLM_ATTN_PROF
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NKB == 2) { t_qk += p1 - p0; t_sm += p2 - p1; t_pv += __builtin_readcyclecounter() - p2; }
+#endif
+    };
     // The LAST compute wave when it holds ONE useful query (S = 32 (nw - 2) + 1: CLIP's 257 tokens = 8 x 32 + 1).  In the layout
     // above it would run the whole softmax — 16 score registers per key block, 144 exponentials per lane — for a single valid
     // lane pair, and it is the third wave of its SIMD: the kernel is VALU-issue-bound (DESIGN.md §3 "Attention, round 3"), so that
@@ -615,6 +757,9 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
     // wave-private LDS strip to reach the k-slot order of the V^T fragments, and P V is the usual MFMA (every column = the one query).
     const bool solo = (w == nw - 2) && (S - w * 32 == 1);
     if (solo) {
+      // (the third wave of its SIMD and the youngest: with oldest-first issue it was served last and finished LAST — 16.3k cycles
+      // for a tenth of a normal wave's work, profiles/r03k; at raised priority it is out of the way early)
+      __builtin_amdgcn_s_setprio(3);
       float s9[9];
 #pragma unroll
       for (int kb = 0; kb < 9; ++kb) {
@@ -662,12 +807,28 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
       }
     } else
     {
+      if constexpr (SC > 0) {
+        static_assert(SC == 0 || (SC > 256 && SC <= 288), "the unrolled schedule below is four full tiles and a tail");
+        using T = std::true_type; using F = std::false_type;
+        bf16x8 kA[KH], kB[KH];
+        k_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kA);
+        tile_fixed(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, T{}, kA, kB);
+        tile_fixed(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{}, T{}, kB, kA);
+        tile_fixed(std::integral_constant<int, 128>{}, std::integral_constant<int, 2>{}, T{}, kA, kB);
+        tile_fixed(std::integral_constant<int, 192>{}, std::integral_constant<int, 2>{}, T{}, kB, kA);
+        tile_fixed(std::integral_constant<int, 256>{}, std::integral_constant<int, 1>{}, F{}, kA, kB);   // keys 256 .. SC-1: one block
+      } else {
       const int nfull = S / 64;                     // key tiles without a tail
       int kb0 = 0;
       for (; kb0 < 2 * nfull; kb0 += 2) tile_body(kb0 * 32, std::integral_constant<int, 2>{}, std::false_type{});
       if (kb0 + 1 < nkb) tile_body(kb0 * 32, std::integral_constant<int, 2>{}, std::true_type{});
       else if (kb0 < nkb) tile_body(kb0 * 32, std::integral_constant<int, 1>{}, std::true_type{});
+      }
     }
+#ifdef HVLM_ATTN_PROF
+    const long long c2 = __builtin_readcyclecounter();
+    t_body += c2 - c1;
+#endif
     const float ltot = lsum + xlane32(lsum);
     if (nitem < nitems) {                    // next item's Q: in place BEFORE the stores below (see the loop top)
 #pragma unroll
@@ -686,9 +847,23 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
                      E16<F16>::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv)};
           *reinterpret_cast<u32x2*>(op + d) = v;
         }
+#ifndef HVLM_ATTN_PROF
       if (lse && hi == 0) lse[((long)b * H + h) * S + qi] = m * LN2 + logf(ltot);
+#endif
     }
+#ifdef HVLM_ATTN_PROF
+    t_epi += __builtin_readcyclecounter() - c2;
+#endif
   }
+#ifdef HVLM_ATTN_PROF
+  // (development: -DHVLM_ATTN_PROF turns the `lse` argument into 8 cycle counters per wave — barrier wait, tile loop, epilogue,
+  // total, and the QK^T / softmax / P V phases of the full tiles — read by tools/clip_attn_phases.py)
+  if (lse && l == 0) {
+    long long* pr = reinterpret_cast<long long*>(lse) + ((long)blockIdx.x * 10 + w) * 8;
+    pr[0] = t_bar; pr[1] = t_body; pr[2] = t_epi; pr[3] = __builtin_readcyclecounter() - t_all0;
+    pr[4] = t_qk; pr[5] = t_sm; pr[6] = t_pv; pr[7] = 0;
+  }
+#endif
 }
 
 // delta[b,h,s] = sum_d O[b,s,h,d] * dO[b,s,h,d]   (one thread per 8 elements, dh/8-lane reduce).  Rows are token-major
@@ -1397,6 +1572,13 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
       }
       const int nitems = B * H;
+      if (S == 257) {                          // CLIP ViT-L/14 at 224 px: the unrolled, LDS-latency-pipelined schedule
+        rc = set_lds(attn_fwd_resident_kernel<DH, F16, 257>, lds, "attn_fwd_resident");
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_fwd_resident_kernel<DH, F16, 257>), dim3(nitems < cus ? nitems : cus), dim3(64 * (nkb + 1)), lds, st, qkv, out,
+                           lse, S, H, ld, nkb, nitems, scale * LOG2E);
+        return check_launch("attn_fwd_resident");
+      }
       hipLaunchKernelGGL((attn_fwd_resident_kernel<DH, F16>), dim3(nitems < cus ? nitems : cus), dim3(64 * (nkb + 1)), lds, st, qkv, out, lse,
                          S, H, ld, nkb, nitems, scale * LOG2E);
       return check_launch("attn_fwd_resident");
