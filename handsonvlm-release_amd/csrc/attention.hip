@@ -615,16 +615,17 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
             o[db] = E16<F16>::mfma32(v_frag(db, kvb + (unsigned)(kb * 32 + 16 * sp) * ROWB), pf, o[db]);
         }
     };
-    // SC > 0 (the sequence length is a compile-time constant: CLIP's 257): the tile sequence is unrolled and software-pipelined BY
-    // HAND around the LDS latency.  Left to the compiler (tile_body above, 168-register budget) every ds_read sits right in front
-    // of the MFMA that consumes it — sixteen exposed LDS round trips per 64-key tile, ~ 1 900 cycles per tile and wave where the
-    // instruction mix needs ~ 850 (profiles/r03k_clip_attention_lds_pipeline.txt).  Here every batch of fragment reads has other
-    // work to land under:
-    //   QK^T: second half of the K fragments requested, MFMAs of the first half (requested during the previous tile's P V), MFMAs
-    //   of the second  ->  V^T fragments of the first key block requested  ->  softmax (VALU)  ->  V^T fragments of the second key
-    //   block and the first half of the NEXT tile's K fragments requested  ->  P V MFMAs.
-    // With kv0 a constant all LDS addresses are (4 + 4 per-item registers) + instruction offsets.
-    constexpr int KH = DH / 16;        // fragments per half K set: DH/32 k-steps x 2 key blocks
+    // SC > 0 (the sequence length is a compile-time constant: CLIP's 257): the key blocks are unrolled and software-pipelined BY HAND,
+    // across blocks and around the LDS latency.  Two measurements shaped this (profiles/r03k_clip_attention_lds_pipeline.txt):
+    //  * left to the compiler (tile_body above, 168-register budget) every ds_read sits right in front of the MFMA that consumes
+    //    it: sixteen exposed LDS round trips per 64-key tile.  Here every batch of fragment reads is requested a phase early;
+    //    with the block index a constant all LDS addresses are (4 + 4 per-item registers) + instruction offsets.
+    //  * the two waves of a SIMD do not hide each other: while one wave's MFMAs occupy the matrix pipe the other's VALU does not
+    //    issue, a SIMD's time is the SUM of its waves' MFMA and VALU phases.  Matrix and vector work overlap only inside ONE
+    //    instruction stream — so each phase below carries, for 32-key blocks t-1, t, t+1:
+    //        P V of block t-1  |  softmax of block t (VALU)  |  QK^T of block t+1
+    //    on two score register sets and two P sets.  The rescale of O by exp2(m_old - m_new) is deferred to the start of the next
+    //    phase (P V of block t-1 still accumulates at the old maximum) and stays a wave-uniform branch.
     unsigned ka[DH / 16], va[DH / 32][2];
     if constexpr (SC > 0) {
 #pragma unroll
@@ -632,120 +633,111 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
 #pragma unroll
       for (int db = 0; db < DH / 32; ++db) { va[db][0] = base + v_off[db][0]; va[db][1] = base + v_off[db][1]; }
     }
-    auto k_issue = [&](auto kv0_tag, auto ks0_tag, bf16x8 (&kf)[KH]) {
-      constexpr unsigned kvb = (unsigned)decltype(kv0_tag)::value * ROWB;
-      constexpr int ks0 = decltype(ks0_tag)::value;
+    constexpr int NT = (SC + 31) / 32;                 // 32-key blocks
+    f32x16 sA, sB;                                     // scores of the even / odd blocks
+    bf16x8 kfr[DH / 16], vfr[2][DH / 32], pA[2], pB[2];
+    float alpha_p = 1.f;
+    bool pend = false;
+    auto k_read = [&](auto t_tag) {                    // K fragments of block t (one ds_read_b128 per 16 head dims)
+      constexpr unsigned off = (unsigned)(decltype(t_tag)::value * 32) * ROWB;
 #pragma unroll
-      for (int ks = 0; ks < DH / 32; ++ks)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) kf[ks * 2 + kb] = lds_frag128(smem, ka[ks0 + ks] + kvb + (unsigned)(kb * 32) * ROWB);
+      for (int ks = 0; ks < DH / 16; ++ks) kfr[ks] = lds_frag128(smem, ka[ks] + off);
     };
-    auto v_frag_c = [&](int db, unsigned key_bytes) -> bf16x8 {
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][0] + key_bytes));
-      const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][1] + key_bytes));
-      const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-      return __builtin_bit_cast(bf16x8, v);
-    };
-    // `kc`: first half of this tile's K fragments (in registers on entry); `kn`: receives the first half of the next tile's
-    auto tile_fixed = [&](auto kv0_tag, auto nkb_tag, auto prefetch_tag, const bf16x8 (&kc)[KH], bf16x8 (&kn)[KH]) {
-      constexpr int kv0 = decltype(kv0_tag)::value;
-      constexpr int NKB = decltype(nkb_tag)::value;
-      constexpr bool MASK = kv0 + NKB * 32 > SC;
-      constexpr unsigned kvb = (unsigned)kv0 * ROWB;
-      f32x16 sc[NKB];
-#ifdef HVLM_ATTN_PROF
-      const long long p0 = __builtin_readcyclecounter();
-#endif
-      {
-        bf16x8 kh[KH];
-        k_issue(kv0_tag, std::integral_constant<int, DH / 32>{}, kh);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < DH / 32; ++ks)
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) sc[kb] = E16<F16>::mfma32(kc[ks * 2 + kb], qf[ks], ks == 0 ? zero16 : sc[kb]);
-#pragma unroll
-        for (int ks = 0; ks < DH / 32; ++ks)
-#pragma unroll
-          for (int kb = 0; kb < NKB; ++kb) sc[kb] = E16<F16>::mfma32(kh[ks * 2 + kb], qf[DH / 32 + ks], sc[kb]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef HVLM_ATTN_PROF
-      const long long p1 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      bf16x8 vf[NKB][2][DH / 32];
+    auto v_read = [&](auto t_tag) {                    // V^T fragments of block t
+      constexpr int t = decltype(t_tag)::value;
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int db = 0; db < DH / 32; ++db) vf[0][sp][db] = v_frag_c(db, kvb + (unsigned)(16 * sp) * ROWB);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MASK) {
+        for (int db = 0; db < DH / 32; ++db) {
+          constexpr unsigned dummy = 0; (void)dummy;
+          const unsigned key_bytes = (unsigned)(t * 32 + 16 * sp) * ROWB;
+          const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][0] + key_bytes));
+          const s16x4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(smem + va[db][1] + key_bytes));
+          const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          vfr[sp][db] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+    auto qk = [&](f32x16& sx) {
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+      for (int ks = 0; ks < DH / 16; ++ks) sx = E16<F16>::mfma32(kfr[ks], qf[ks], ks == 0 ? zero16 : sx);
+    };
+    auto pv = [&](const bf16x8 (&pf)[2]) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (kv0 + kb * 32 + crow(r, hi) >= SC) sc[kb][r] = -INFINITY;
-      }
-      float mx = sc[0][0];
+      for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kb][r]);
-      mx = fmaxf(mx, xlane32(mx));
-      const float mnew = fmaxf(m, mx * scale_log2);
-      if (__builtin_amdgcn_ballot_w64(mnew > m)) {
-        const float alpha = fast_exp2(m - mnew);
-        lsum *= alpha;
+        for (int db = 0; db < DH / 32; ++db) o[db] = E16<F16>::mfma32(vfr[sp][db], pf[sp], o[db]);
+    };
+    auto rescale = [&]() {
+      if (pend) {
 #pragma unroll
         for (int db = 0; db < DH / 32; ++db)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        m = mnew;
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha_p;
       }
+    };
+    auto softmax_blk = [&](auto t_tag, f32x16& sx, bf16x8 (&pf)[2]) {
+      constexpr int t = decltype(t_tag)::value;
+      if constexpr (t * 32 + 32 > SC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 32 + crow(r, hi) >= SC) sx[r] = -INFINITY;
+      }
+      float mx = sx[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sx[r]);
+      mx = fmaxf(mx, xlane32(mx));
+      const float mnew = fmaxf(m, mx * scale_log2);
+      if constexpr (t > 0) {                           // (block 0: O and the row sum are still zero)
+        alpha_p = fast_exp2(m - mnew);
+        pend = __builtin_amdgcn_ballot_w64(mnew > m) != 0;
+        lsum *= alpha_p;
+      }
+      m = mnew;
+      // P is rounded to 16 bits pair by pair and the row sum is taken over the ROUNDED values (one v_dot2c per pair): the fp32
+      // probabilities die at the conversion, and the normaliser matches the P that enters P V exactly
       float psum0 = 0.f, psum1 = 0.f;
-      bf16x8 pf[NKB][2];
+      u32x4 pk[2];
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
+      for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float p0 = fast_exp2(__builtin_fmaf(sc[kb][r], scale_log2, -m));
-          const float p1 = fast_exp2(__builtin_fmaf(sc[kb][r + 1], scale_log2, -m));
-          sc[kb][r] = p0; sc[kb][r + 1] = p1;
-          psum0 += p0; psum1 += p1;
+        for (int j = 0; j < 4; ++j) {
+          const int r = 8 * sp + 2 * j;
+          const float p0 = fast_exp2(__builtin_fmaf(sx[r], scale_log2, -m));
+          const float p1 = fast_exp2(__builtin_fmaf(sx[r + 1], scale_log2, -m));
+          const unsigned int pp2 = E16<F16>::pack2(p0, p1);
+          pk[sp][j] = pp2;
+          if (j & 1) psum1 = E16<F16>::add_pair(pp2, psum1);
+          else psum0 = E16<F16>::add_pair(pp2, psum0);
         }
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          float pv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] = sc[kb][8 * sp + j];
-          pf[kb][sp] = pack8<F16>(pv);
-        }
-      }
       lsum += psum0 + psum1;
+      // (pinned: LLVM otherwise SINKS this block's exponentials into the next phase's basic block — past its rescale branch —
+      // next to their first use, and the phase boundary is gone)
+      asm volatile("" : "+v"(pk[0]), "+v"(pk[1]), "+v"(lsum), "+v"(m));
+      pf[0] = __builtin_bit_cast(bf16x8, pk[0]);
+      pf[1] = __builtin_bit_cast(bf16x8, pk[1]);
+    };
+    auto phase = [&](auto t_tag) {
+      constexpr int t = decltype(t_tag)::value;
+      f32x16& cur = (t & 1) ? sB : sA;
+      f32x16& nxt = (t & 1) ? sA : sB;
+      bf16x8 (&pc)[2] = (t & 1) ? pB : pA;
+      bf16x8 (&pp)[2] = (t & 1) ? pA : pB;
       __builtin_amdgcn_sched_barrier(0);
-#ifdef HVLM_ATTN_PROF
-      const long long p2 = __builtin_readcyclecounter();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if constexpr (NKB == 2) {
+      if constexpr (t > 1) rescale();                  // by the factor block t-1 found, before its P V joins O
+      // (program order: everything that is not the softmax first — the pin at the softmax's end orders the whole phase)
+      if constexpr (t > 0) pv(pp);                     // block t-1
+      if constexpr (t + 1 < NT) qk(nxt);               // block t+1
+      if constexpr (t > 0) v_read(t_tag);              // V^T of block t (into the registers P V of block t-1 was issued from)
+      if constexpr (t + 2 < NT) k_read(std::integral_constant<int, t + 2>{});
+      softmax_blk(t_tag, cur, pc);
+      // issue order of the phase: the (up to) eight MFMAs spread evenly through the softmax's ~ 75 VALU instructions, so that
+      // the matrix pipe works under the vector work of the SAME wave (left alone the scheduler bunches the QK^T chain at the end)
+      constexpr int NM = (t > 0 ? 4 : 0) + (t + 1 < NT ? 4 : 0);
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-          for (int db = 0; db < DH / 32; ++db) vf[1][sp][db] = v_frag_c(db, kvb + (unsigned)(32 + 16 * sp) * ROWB);
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NM == 8 ? 9 : 18, 0);
       }
-      if constexpr (decltype(prefetch_tag)::value) k_issue(std::integral_constant<int, kv0 + 64>{}, std::integral_constant<int, 0>{}, kn);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-          for (int db = 0; db < DH / 32; ++db) o[db] = E16<F16>::mfma32(vf[kb][sp][db], pf[kb][sp], o[db]);
-#ifdef HVLM_ATTN_PROF
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NKB == 2) { t_qk += p1 - p0; t_sm += p2 - p1; t_pv += __builtin_readcyclecounter() - p2; }
-#endif
     };
     // The LAST compute wave when it holds ONE useful query (S = 32 (nw - 2) + 1: CLIP's 257 tokens = 8 x 32 + 1).  In the layout
     // above it would run the whole softmax — 16 score registers per key block, 144 exponentials per lane — for a single valid
@@ -808,15 +800,23 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_resident_kernel(const bf16_t*
     } else
     {
       if constexpr (SC > 0) {
-        static_assert(SC == 0 || (SC > 256 && SC <= 288), "the unrolled schedule below is four full tiles and a tail");
-        using T = std::true_type; using F = std::false_type;
-        bf16x8 kA[KH], kB[KH];
-        k_issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kA);
-        tile_fixed(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, T{}, kA, kB);
-        tile_fixed(std::integral_constant<int, 64>{}, std::integral_constant<int, 2>{}, T{}, kB, kA);
-        tile_fixed(std::integral_constant<int, 128>{}, std::integral_constant<int, 2>{}, T{}, kA, kB);
-        tile_fixed(std::integral_constant<int, 192>{}, std::integral_constant<int, 2>{}, T{}, kB, kA);
-        tile_fixed(std::integral_constant<int, 256>{}, std::integral_constant<int, 1>{}, F{}, kA, kB);   // keys 256 .. SC-1: one block
+        static_assert(SC == 0 || (SC > 256 && SC <= 288), "nine key blocks, the last one partial");
+        k_read(std::integral_constant<int, 0>{});
+        v_read(std::integral_constant<int, 0>{});
+        qk(sA);
+        k_read(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
+        phase(std::integral_constant<int, 4>{});
+        phase(std::integral_constant<int, 5>{});
+        phase(std::integral_constant<int, 6>{});
+        phase(std::integral_constant<int, 7>{});
+        phase(std::integral_constant<int, 8>{});
+        __builtin_amdgcn_sched_barrier(0);
+        rescale();
+        pv((NT - 1) & 1 ? pB : pA);
       } else {
       const int nfull = S / 64;                     // key tiles without a tail
       int kb0 = 0;

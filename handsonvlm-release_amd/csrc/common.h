@@ -64,6 +64,13 @@ struct E16 {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // acc + lo(p) + hi(p) in one instruction (v_dot2c_f32_f16 / _bf16 against packed ones)
+  static __device__ __forceinline__ float add_pair(unsigned int p, float acc) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    if constexpr (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, p), __builtin_bit_cast(h2_t, 0x3c003c00u), acc, false);
+    else return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2_t, p), __builtin_bit_cast(b2_t, 0x3f803f80u), acc, false);
+  }
 };
 
 // ---- wave / block reductions (wave = 64) -----------------------------------------------------
