@@ -656,12 +656,16 @@ def main():
         out = step()
     barrier()
     ev.enabled = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = step()
+        marks[i + 1].record()                  # (no synchronisation: per-step GPU time for the `step_ms` diagnostic)
     barrier()
     dt = time.perf_counter() - t0
     ev.enabled = False
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if torch.distributed.is_initialized():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -722,6 +726,7 @@ def main():
             "peak_mem_gib": peak_mem,
         }
         res["step_tail_ms"] = tail_ms
+        res["step_ms"] = [round(v, 1) for v in step_ms]      # every timed step on the compute stream (one-time costs show up here)
         if buckets.active:
             res["comm"] = {"backend": torch.distributed.get_backend(), "world": buckets.world,
                            "collectives_per_step": buckets.n_collectives, "bytes_allreduced_per_step": buckets.bytes,
