@@ -37,7 +37,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)    # (the caching allocator settles during the first TWO steps: step_ms of a 1-warm-up run shows +60…90 ms on its first timed step)
     ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (scripts/finetune.sh:20)")
     ap.add_argument("--text-len", type=int, default=512, help="prompt tokens T; S = T + 355")
@@ -444,7 +444,7 @@ def other_configs(args):
     import subprocess
     runs = {
         "config2_7b_inference_336px_b1": ["--eval-only", "--image-size", "336"],
-        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "2", "--warmup", "1", "--no-eval",
+        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "2", "--warmup", "2", "--no-eval",
                                      "--no-cpu-baseline", "--no-gemm-events"],
     }
     out = {}
