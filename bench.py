@@ -657,6 +657,7 @@ def main():
     barrier()
     ev.enabled = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    segs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -727,6 +728,7 @@ def main():
         }
         res["step_tail_ms"] = tail_ms
         res["step_ms"] = [round(v, 1) for v in step_ms]      # every timed step on the compute stream (one-time costs show up here)
+        res["device_allocs_in_timed_region"] = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - segs0)   # hipMalloc calls of the caching allocator
         if buckets.active:
             res["comm"] = {"backend": torch.distributed.get_backend(), "world": buckets.world,
                            "collectives_per_step": buckets.n_collectives, "bytes_allreduced_per_step": buckets.bytes,
