@@ -79,6 +79,37 @@ def test_clip_resident_attention_many_items_per_workgroup(ops, B, H):
     assert rel(o2, o) <= 4e-3
 
 
+@pytest.mark.parametrize("f16", [False, True])
+def test_clip_resident_attention_late_maximum(ops, f16):
+    """The S = 257 kernel pipelines three key blocks per phase and DEFERS the rescale of O by exp2(m_old - m_new) to the next
+    phase (csrc/attention.hip, SC > 0).  Keys with a huge score late in the sequence — inside block 7, in the masked tail block
+    (key 256) and for the one-query wave's row 256 — make the running maximum jump after most of O has been accumulated; the
+    result must still match the full-tensor oracle, for every item of a workgroup's sequence (two buffers, both parities)."""
+    B, S, H, dh = 40, 257, 16, 64
+    qkv = grnd(B * S, 3 * H * dh, seed=77, scale=0.5).float().view(B, S, 3, H, dh)
+    for b in range(B):
+        h = b % H
+        qkv[b, 230, 1, h] = qkv[b, 100, 0, h] * 30.0          # k_230 aligned with q_100: block 7
+        qkv[b, 256, 1, h] = qkv[b, 5, 0, h] * 30.0            # k_256 aligned with q_5: the partial last block
+        qkv[b, 250, 1, (h + 1) % H] = qkv[b, 256, 0, (h + 1) % H] * 30.0      # the left-over query's row
+        qkv[b, 40, 1, (h + 2) % H] = qkv[b, 200, 0, (h + 2) % H] * 30.0       # early spike: no later rescale (control)
+    dt = torch.float16 if f16 else BF
+    q16 = qkv.view(B * S, 3 * H * dh).to(dt).contiguous()
+    o = ops.attn_fwd_f16(q16, B, S, H, dh, dh ** -0.5) if f16 else ops.attn_fwd(q16, B, S, H, dh, False, dh ** -0.5)[0]
+    assert torch.isfinite(o.float()).all()
+    x = q16.float().cpu().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    ref = R.softmax_attention(x[0], x[1], x[2], False, dh ** -0.5)
+    got = o.float().cpu().view(B, S, H, dh).permute(0, 2, 1, 3)
+    per_row = (got - ref).norm(dim=3) / ref.norm(dim=3).clamp_min(1e-6)        # [B, H, S]
+    tol = 2e-3 if f16 else 1.6e-2                      # one 16-bit rounding of P and of O per row
+    assert float(per_row.max()) <= tol, (float(per_row.max()), np.unravel_index(int(per_row.argmax()), per_row.shape))
+    for b in (0, 1, 39):                               # the spiked rows put (almost) all their weight on one key
+        h = b % H
+        assert rel(got[b, h, 100], x[2][b, h, 230]) <= 2e-2 and rel(got[b, h, 5], x[2][b, h, 256]) <= 2e-2
+        assert rel(got[b, (h + 1) % H, 256], x[2][b, (h + 1) % H, 250]) <= 2e-2
+
+
 def test_clip_attention_577_tokens_336px(ops):
     """336-px geometry (24x24 patches + CLS = 577 tokens, dh = 64, non-causal): the streaming kernel, 768 (b, h) items."""
     B, S, H, dh = 48, 577, 16, 64
