@@ -1,0 +1,60 @@
+"""Host logic of the LayerNorm fold of the frozen CLIP tower (hvlm/clip.py::_fold_prepare / _forward_layers_folded) on the ops
+stand-in (tests/cpu_ops.py): the folded tower must compute what the explicit one computes — CLIPEncoderLayer.layer_norm1 ->
+q|k|v, layer_norm2 -> fc1 (transformers modeling_clip, through llava/model/multimodal_encoder/clip_encoder.py:39-51) — and both
+must match the fp32 oracle.  The kernels themselves are tested on the GPU (tests/test_gpu_parity_r2.py)."""
+import os
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from oracle import synth
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).float().cpu(); b = torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("select_layer", [-2, -1])
+def test_folded_tower_equals_explicit_tower_and_oracle(monkeypatch, select_layer):
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from hvlm import clip as clip_mod
+    from hvlm.config import CLIPVisionConfig
+    c = dict(clip_d=256, clip_mlp=512, clip_layers=4, clip_heads=4, patch=14, image=28)
+    pnp = synth.clip_params(c, seed=5)
+    p = synth.to_torch(pnp)
+    # LayerNorm affines far from (1, 0) and an outlier channel, so that a wrong fold cannot hide
+    for k in list(p):
+        if "layer_norm" in k and k.endswith("weight"):
+            p[k] = p[k] * (1.0 + 0.5 * torch.sin(torch.arange(p[k].numel(), dtype=torch.float32)))
+        if "layer_norm" in k and k.endswith("bias"):
+            p[k] = p[k] + 0.3 * torch.cos(torch.arange(p[k].numel(), dtype=torch.float32))
+    img = synth.make_images(1, 5, 5, 28, seed=9)[0]                          # [5, 3, 28, 28]
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = R.clip_features(img, p, c["clip_layers"], c["clip_heads"], select_layer=select_layer) if select_layer != -2 \
+            else R.clip_features(img, p, c["clip_layers"], c["clip_heads"])
+    cfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4, image_size=28, patch_size=14)
+    outs = {}
+    for fold in (True, False):
+        monkeypatch.setattr(clip_mod, "_FOLD_LN", fold)
+        tower = clip_mod.CLIPVisionTower(cfg, "cpu", select_layer=select_layer, dtype=torch.float16)
+        tower.load_state_dict(p)
+        calls = {"ln": 0, "fold": 0}
+        from hvlm import ops
+        ln0, g0 = ops.layernorm_fwd_f16, ops.gemm_f16_nt_ln
+        monkeypatch.setattr(ops, "layernorm_fwd_f16", lambda *a, **k: (calls.__setitem__("ln", calls["ln"] + 1), ln0(*a, **k))[1])
+        monkeypatch.setattr(ops, "gemm_f16_nt_ln", lambda *a, **k: (calls.__setitem__("fold", calls["fold"] + 1), g0(*a, **k))[1])
+        outs[fold] = tower(img.to(torch.bfloat16)).float()
+        n_run = tower.n_run
+        if fold:       # pre_layrnorm + layer 0's layer_norm1 stay explicit; every other LayerNorm rides in a GEMM
+            assert calls["ln"] == 2 and calls["fold"] == 4 * n_run - 1, calls
+        else:
+            assert calls["ln"] == 1 + 2 * n_run and calls["fold"] == 0, calls
+        monkeypatch.setattr(ops, "layernorm_fwd_f16", ln0)
+        monkeypatch.setattr(ops, "gemm_f16_nt_ln", g0)
+    e_fold, e_expl, e_ab = rel(outs[True], ref), rel(outs[False], ref), rel(outs[True], outs[False])
+    print(f"select_layer {select_layer}: folded vs oracle {e_fold:.2e}, explicit vs oracle {e_expl:.2e}, folded vs explicit {e_ab:.2e}")
+    assert e_fold <= 1.5 * e_expl + 2e-4 and e_fold <= 1e-2 and e_ab <= 1e-2
