@@ -24,7 +24,8 @@ for w in $what; do case $w in
             python3 tools/rocpd_stats.py "$(ls gpurun_out/prof_$tag/*.db | head -1)" gpurun_out/${tag}_bench7b_kernel_stats.txt > /dev/null
             rm -rf gpurun_out/prof_$tag ;;
   pmc)      python bench.py --steps 2 --warmup 1 --gemm-table --no-cpu-baseline --no-eval > /dev/null 2>&1     # -> gpurun_out/gemm_by_shape.json
-            python3 tools/gemm_traffic.py > gpurun_out/${tag}_traffic.log 2>&1                                 # -> gpurun_out/gemm_traffic.json
+            python3 tools/gemm_traffic_all.py drive gpurun_out/gemm_by_shape.json gpurun_out/${tag}_gemm_traffic.json > gpurun_out/${tag}_traffic.log 2>&1
+            # (two rocprofv3 --pmc passes over all shapes; copy the .json to profiles/: bench.py picks the newest profiles/r*_gemm_traffic.json that covers its shapes)
             ;;
   probe)    tools/build/mfma_power_probe 0 > gpurun_out/${tag}_mfma_power_probe.txt; tools/build/mfma_power_probe 1 >> gpurun_out/${tag}_mfma_power_probe.txt ;;
 esac; done
