@@ -107,6 +107,9 @@ def test_rope_vs_oracle(ops):
                                               (1, 64, 1, 64, True), (1, 33, 2, 128, True), (1, 50, 2, 128, False),
                                               (2, 868, 2, 128, True), (1, 1, 1, 64, True), (3, 40, 2, 64, False), (1, 320, 2, 64, False),
                                               (1, 321, 1, 64, False), (1, 1, 2, 64, False),
+                                              # resident-K/V kernel, generic instantiation (S = 257 has its own): a one-query last wave at
+                                              # 2 and 8 key blocks, exactly 8 and 9 full blocks
+                                              (2, 33, 2, 64, False), (1, 225, 3, 64, False), (1, 256, 2, 64, False), (2, 288, 2, 64, False),
                                               # workgroup counts that are not multiples of the 8 XCDs (27, 50): the XCD-aware order's remainder chunks
                                               (3, 300, 3, 128, True), (5, 130, 5, 64, True)])
 def test_attention_fwd_bwd_vs_oracle(ops, B, S, H, dh, causal):
