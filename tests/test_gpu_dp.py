@@ -158,4 +158,7 @@ def test_bench_rccl_backend_world1(tmp_path):
     assert res["rccl"]["n_gpus"] == 1 and res["rccl"]["value"] > 0
     _check_comm(res["rccl"], 1)
     assert "comm" not in res["plain"] and res["plain"]["step_tail_ms"] > 0
+    for r in res.values():                      # per-step diagnostic: one entry per timed step, consistent with the wall-clock mean
+        assert len(r["step_ms"]) == 3 and all(v > 0 for v in r["step_ms"]) and r["device_allocs_in_timed_region"] >= 0
+        assert abs(sum(r["step_ms"]) / 3 - r["ms_per_step"]) <= 0.25 * r["ms_per_step"] + 1.0
     assert res["rccl"]["loss"] == res["plain"]["loss"], (res["rccl"]["loss"], res["plain"]["loss"])
