@@ -726,6 +726,12 @@ def main():
             "loss": loss,
             "peak_mem_gib": peak_mem,
         }
+        try:
+            dp = torch.cuda.get_device_properties(device)
+            res["device"] = {"name": dp.name, "arch": getattr(dp, "gcnArchName", None), "compute_units": dp.multi_processor_count,
+                             "memory_gib": round(dp.total_memory / 2 ** 30, 1)}      # (boxes of one pool differ by up to 7 % in sustained GEMM rate)
+        except Exception:  # noqa
+            pass
         res["step_tail_ms"] = tail_ms
         res["step_ms"] = [round(v, 1) for v in step_ms]      # every timed step on the compute stream (one-time costs show up here)
         res["device_allocs_in_timed_region"] = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - segs0)   # hipMalloc calls of the caching allocator
