@@ -655,6 +655,29 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
+    # Box calibration (outside the timed region): the decoder's largest GEMM, isolated, on this GPU right now.  The boxes of one pool
+    # differ by up to 7 % in the GEMM rate they sustain under the power cap; this one number lets two bench lines from different
+    # boxes be compared (the kernel is unchanged since round 2: 1383-1391 TFLOP/s on the boxes profiled then).
+    calib = None
+    if args.model in ("7b", "13b") and not args.no_gemm_events:
+        try:
+            ca = torch.randn(13872, 4096, device=device).to(torch.bfloat16)
+            cb = torch.randn(12288, 4096, device=device).to(torch.bfloat16)
+            cc = torch.empty(13872, 12288, device=device, dtype=torch.bfloat16)
+            for _ in range(3):
+                ops.gemm_nt(ca, cb, out=cc)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.gemm_nt(ca, cb, out=cc)
+            e1.record()
+            torch.cuda.synchronize()
+            calib = {"gemm_13872x12288x4096_bf16_tflops": 20 * 2.0 * 13872 * 12288 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
+                     "note": "20 isolated launches of the decoder's QKV-shaped GEMM right before the timed steps: the speed of THIS box"}
+            del ca, cb, cc
+        except Exception as ex:  # noqa
+            calib = {"error": str(ex)[:200]}
+    barrier()
     ev.enabled = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     segs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
@@ -732,6 +755,8 @@ def main():
                              "memory_gib": round(dp.total_memory / 2 ** 30, 1)}      # (boxes of one pool differ by up to 7 % in sustained GEMM rate)
         except Exception:  # noqa
             pass
+        if calib is not None:
+            res["box_calibration"] = calib
         res["step_tail_ms"] = tail_ms
         res["step_ms"] = [round(v, 1) for v in step_ms]      # every timed step on the compute stream (one-time costs show up here)
         res["device_allocs_in_timed_region"] = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - segs0)   # hipMalloc calls of the caching allocator
