@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--text-len", type=int, default=512, help="prompt tokens T; S = T + 355")
     ap.add_argument("--unique-frames", type=int, default=10, help="EK100 tiles 10 frames x10 -> 100")
     ap.add_argument("--dedup", action="store_true", help="encode unique frames once (reported separately)")
+    ap.add_argument("--full-logits", action="store_true",
+                    help="lm_head + cross-entropy on ALL rows like the reference's forward (default: only the rows that carry a "
+                         "target; the others have zero loss and zero gradient — config.lm_head_labelled_rows)")
     ap.add_argument("--image-size", type=int, default=224,
                     help="frame size: 224 = the only geometry the reference accepts (default); 336 = the build's generalisation "
                          "(24x24 patches, 676 visual tokens, S = T + 675)")
@@ -87,6 +90,7 @@ def make_config(args):
     if args.layers is not None:
         cfg.num_hidden_layers = args.layers
     cfg.dedup_frames = args.dedup
+    cfg.lm_head_labelled_rows = not args.full_logits
     if args.clip_chunk:
         cfg.clip_chunk_frames = args.clip_chunk
     cfg.vision_dtype = args.clip_dtype
@@ -716,6 +720,11 @@ def main():
         else:       # algorithmic work = the real tokens of every sample (padding rows are not work)
             flops_llm = 3.0 * sum(model.stack.flops_forward(1, int(n) + nv1, cfg.vocab_size) for n in lens)
         flops_clip = n_frames * model.tower.flops_per_frame()
+        # lm_head on labelled rows only: the rows it does not run on are NOT counted as work (forward + dX + dW = 3 x 2 D V per row)
+        rows_all = B * S if lens is None else int(sum(int(n) + nv1 for n in lens))
+        lab = batch["labels"]
+        rows_lbl = int((lab[:, 1:] != -100).sum()) if cfg.lm_head_labelled_rows else rows_all
+        flops_llm -= 3.0 * 2.0 * (rows_all - rows_lbl) * cfg.hidden_size * cfg.vocab_size
         step_flops = flops_llm + flops_clip
         res = {
             "metric": "SFT samples/sec HandsOnVLM-7B" if args.model == "7b" else f"SFT samples/sec HandsOnVLM-{args.model}",
@@ -732,6 +741,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"sft_step_{args.model}_b{B}_T{T if lens is None else 'U' + args.varlen.replace(':', '-')}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
                                    + ("_dedupclip" if args.dedup else "_refequiv") + ("_poolproj" if cfg.project_after_pool else "")
+                                   + ("_lblrows" if cfg.lm_head_labelled_rows else "")
                                    + ("_packed" if args.pack else "")
                                    + ("_recompute" if args.recompute else ""),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
@@ -740,6 +750,12 @@ def main():
                        "projector_note": ("mm_projector applied AFTER the temporal/spatial pooling (Linear commutes with the means: 356 rows per "
                                           "sample instead of the reference's 25 600; its skipped FLOPs are not counted as work)"
                                           if cfg.project_after_pool else "mm_projector on all patch tokens, as the reference"),
+                       "lm_head_rows_per_step": rows_lbl, "rows_per_step": rows_all,
+                       "lm_head_note": ("lm_head, cross-entropy and their backward run on the rows that carry a target (the synthetic batch masks "
+                                        "the first 40 % of the text like a prompt; visual-token rows never have one): zero-loss / zero-gradient "
+                                        "rows are skipped, loss and gradients are those of the full-logits pass (--full-logits), and the "
+                                        "skipped rows' FLOPs are not counted as work" if cfg.lm_head_labelled_rows else
+                                        "lm_head on all rows, as the reference's forward"),
                        "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "clip_tower_dtype": args.clip_dtype, "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
                        "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",
                        "packed_rows": bool(args.pack)},

@@ -56,6 +56,10 @@ class HandsOnVLMConfig:
     # build-specific knobs (no reference counterpart)
     project_after_pool: bool = True    # mm_projector commutes with the mean/avg pooling: 356 rows instead of 25 600
     dedup_frames: bool = False         # run CLIP once per unique frame (EK100 tiles 10 frames x10)
+    lm_head_labelled_rows: bool = False  # training passes: lm_head + cross-entropy only on rows whose shifted label is not IGNORE_INDEX
+                                         # (visual-token, prompt and padding rows have zero loss and zero gradient: handsonvlm.py:132-145
+                                         # computes their logits and CrossEntropyLoss(ignore_index=-100) drops them) — same loss and
+                                         # gradients; `out.logits` is None in such a pass unless keep_logits=True
     clip_chunk_frames: int = 1600      # frames per CLIP pass (bounds activation memory: ~11 GB of fp16 activations at 224 px).  One
                                        # pass for the 16 x 100 frames of the SFT batch: 6428 / 19284 / 25712 tiles per GEMM = 25-100 rounds
                                        # of 256 CUs with a 3-4 % tail, against 6.28 rounds (10 % tail) for the N = 1024 GEMMs of a 400-frame

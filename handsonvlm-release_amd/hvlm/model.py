@@ -74,6 +74,10 @@ class SplicePlan:
     cu: Optional[torch.Tensor] = None          # int32 [B+1] cu_seqlens
     pos: Optional[torch.Tensor] = None         # int32 [M] position of every row inside its sample
     row_sample: Optional[torch.Tensor] = None  # int32 [M]
+    # rows with a target (shifted label != IGNORE_INDEX), for config.lm_head_labelled_rows
+    rows_v: Optional[torch.Tensor] = None      # int64 [n_v] row indices into inputs_embeds
+    targets_v: Optional[torch.Tensor] = None   # int32 [n_v] = targets[rows_v]
+    n_v: int = 0
 
 
 class _EngineLoss(torch.autograd.Function):
@@ -307,6 +311,7 @@ class HandsOnVLMForCausalLM:
             tg = np.full((B, S), IGNORE_INDEX, dtype=np.int32)
             tg[:, :-1] = nl[:, 1:]
             targets = torch.from_numpy(tg.reshape(-1)).to(dev)
+            vidx = np.nonzero(tg.reshape(-1) != IGNORE_INDEX)[0]
             hr = np.full((B, 4), -1, dtype=np.int32)
             has_hand = np.zeros(B, dtype=bool)
             for b in range(B):
@@ -323,7 +328,15 @@ class HandsOnVLMForCausalLM:
                           hand_slot=torch.from_numpy(slot.reshape(-1)).to(dev),
                           hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets,
-                          hand_rows=hand_rows, has_hand=has_hand, lengths=lengths)
+                          hand_rows=hand_rows, has_hand=has_hand, lengths=lengths, **self._valid_rows(nl, vidx if nl is not None else None, tg if nl is not None else None))
+
+    def _valid_rows(self, nl, vidx, tg) -> dict:
+        """Rows that carry a target, resolved on the host with the rest of the plan (config.lm_head_labelled_rows)."""
+        if nl is None or vidx is None or not self.config.lm_head_labelled_rows:
+            return {}
+        dev = self.device
+        return dict(rows_v=torch.from_numpy(vidx.astype(np.int64)).to(dev),
+                    targets_v=torch.from_numpy(np.ascontiguousarray(tg.reshape(-1)[vidx])).to(dev), n_v=int(vidx.size))
 
     def _embed_segments(self, flat_src: np.ndarray):
         """Text rows grouped by token id in a FIXED order (stable sort): the embedding gradient is summed segment by
@@ -365,6 +378,7 @@ class HandsOnVLMForCausalLM:
                     hr[b] = cu[b] + p
                     has_hand[b] = True
             targets = torch.from_numpy(tg).to(dev)
+            vidx = np.nonzero(tg != IGNORE_INDEX)[0]
             hand_rows = torch.from_numpy(hr.reshape(-1)).to(dev)
             if getattr(self, "training", False):
                 seg = self._embed_segments(src)
@@ -372,7 +386,8 @@ class HandsOnVLMForCausalLM:
                           hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets, hand_rows=hand_rows,
                           has_hand=has_hand, lengths=lengths, seg=seg, cu=torch.from_numpy(cu).to(dev),
-                          pos=torch.from_numpy(pos).to(dev), row_sample=torch.from_numpy(row_sample).to(dev))
+                          pos=torch.from_numpy(pos).to(dev), row_sample=torch.from_numpy(row_sample).to(dev),
+                          **self._valid_rows(nl, vidx if has_labels else None, tg if has_labels else None))
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -435,12 +450,24 @@ class HandsOnVLMForCausalLM:
             self._last_hidden = hidden[rows].contiguous()                     # read by sample() on <hand_traj>
             logits_p = ops.gemm_nt(self._last_hidden, self.lm_head)
             logits = logits_p[:, : cfg.vocab_size].unsqueeze(1)
+        # labelled rows only (config.lm_head_labelled_rows, training passes that do not hand out the logits): the rows without a
+        # target — visual tokens, the prompt, padding — have zero loss and zero gradient, so lm_head, the cross-entropy and their
+        # backward run on the gathered [n_v, D] rows; same loss, same gradients, `out.logits` is None
+        compact = (training_pass and labels is not None and not last_only and plan.n_v > 0
+                   and not kwargs.get("keep_logits", False))
+        hidden_v = None
+        if last_only:
+            pass
+        elif compact:
+            hidden_v = hidden.index_select(0, plan.rows_v)
+            logits_p = ops.gemm_nt(hidden_v, self.lm_head)                   # [n_v, Vpad] bf16
+            logits = None
         else:
             logits_p = ops.gemm_nt(hidden, self.lm_head)                     # [M, Vpad] bf16
             logits = logits_p[:, : cfg.vocab_size] if pack else logits_p.view(B, S, -1)[:, :, : cfg.vocab_size]
         loss = comps = None
         if labels is not None:
-            acc, row_lse = ops.ce_fwd(logits_p, plan.targets, cfg.vocab_size)
+            acc, row_lse = ops.ce_fwd(logits_p, plan.targets_v if compact else plan.targets, cfg.vocab_size)
             loss_text = acc[0] / acc[1]
             # hand-token gather (:146-187); samples without hand labels get zeros and future_valid[b] = 0
             fv = future_valid
@@ -455,12 +482,12 @@ class HandsOnVLMForCausalLM:
             value = head_loss.detach() + loss_text
             comps = {"text loss": loss_text, "traj_loss": tl["traj_loss"].detach(), "traj_kl_loss": tl["traj_kl_loss"].detach()}
             if training_pass:
-                self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb,
+                self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb, hidden_v=hidden_v,
                                  head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1], M=plan.M)
                 loss = _EngineLoss.apply(self._anchor, self, value)
             else:
                 loss = value
-        if training_pass and kwargs.get("keep_logits", False):
+        if training_pass and kwargs.get("keep_logits", False) and logits is not None:
             logits = logits.clone()
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None,
                                      loss_components=comps, cu_seqlens=plan.cu)
@@ -486,9 +513,17 @@ class HandsOnVLMForCausalLM:
             grad_scale = torch.ones((), device=dev)
         grad_scale = grad_scale.to(dev, torch.float32).reshape(())
         gs = (grad_scale / c["n_valid"]).reshape(1).contiguous()
-        dlogits = ops.ce_bwd_(c["logits_p"], plan.targets, c["row_lse"], gs, cfg.vocab_size)
-        dhidden = ops.gemm_nt(dlogits, self.lm_head_t)                        # [M, D]
-        self.stack._dw(dlogits, c["hidden"], self.lm_head_g, mpad)
+        if c.get("hidden_v") is not None:         # labelled rows only: d(hidden) of every other row is exactly zero
+            dlogits = ops.ce_bwd_(c["logits_p"], plan.targets_v, c["row_lse"], gs, cfg.vocab_size)
+            dh_v = ops.gemm_nt(dlogits, self.lm_head_t)                       # [n_v, D]
+            dhidden = torch.zeros((M, self.token_dim), dtype=BF16, device=dev)
+            dhidden.index_copy_(0, plan.rows_v, dh_v)
+            self.stack._dw(dlogits, c["hidden_v"], self.lm_head_g, _round_up(plan.n_v, 64))
+            del dh_v
+        else:
+            dlogits = ops.ce_bwd_(c["logits_p"], plan.targets, c["row_lse"], gs, cfg.vocab_size)
+            dhidden = ops.gemm_nt(dlogits, self.lm_head_t)                    # [M, D]
+            self.stack._dw(dlogits, c["hidden"], self.lm_head_g, mpad)
         del dlogits
         c["logits_p"] = None
         # CVAE head (PyTorch autograd): grads of the head's own params + d(emb)

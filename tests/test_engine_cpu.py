@@ -232,3 +232,35 @@ def test_evaluate_traj_batched_plumbing(monkeypatch):
     a = E.evaluate_traj(Fake(), samples)
     b = E.evaluate_traj(Fake(), samples, batch_size=2)
     assert calls == [[3, 4], [5, 6], [7]] and a == b and a["n"] == 5 and np.isfinite(a["ade"])
+
+
+def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
+    """config.lm_head_labelled_rows: lm_head, the cross-entropy and their backward on the rows that carry a target.  The other rows
+    (visual tokens, prompt, padding) have zero loss and zero gradient in the reference (CrossEntropyLoss ignore_index = -100 over
+    ALL positions, handsonvlm.py:132-145), so loss and every gradient must equal the full-logits pass up to the fp32 order of the
+    sums over rows; padded and packed layouts; `out.logits` is None unless keep_logits=True."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    batch = _batch()
+    for pack in (False, True):
+        l0, g0, _, out0 = _run(_model(pack_sequences=pack), batch)
+        m1 = _model(pack_sequences=pack, lm_head_labelled_rows=True)
+        calls = []
+        from hvlm import ops
+        g_nt = ops.gemm_nt
+        monkeypatch.setattr(ops, "gemm_nt", lambda a, b, *k, **kw: (calls.append((a.shape[0], b.shape[0])), g_nt(a, b, *k, **kw))[1])
+        l1, g1, _, out1 = _run(m1, batch)
+        monkeypatch.setattr(ops, "gemm_nt", g_nt)
+        assert out0.logits is not None and out1.logits is None
+        Vp = m1.lm_head.shape[0]
+        rows = [r for r, n in calls if n == Vp]
+        n_valid = int((batch["labels"][:, 1:] != -100).sum())
+        assert rows == [n_valid], (rows, n_valid)                     # the lm_head GEMM ran on exactly the labelled rows
+        assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
+        for n in g0:
+            a, b = g0[n].float(), g1[n].float()
+            r = float((a - b).norm() / (a.norm() + 1e-30))
+            assert r < 2e-3, (pack, n, r)
+        # keep_logits=True hands out the full logits and takes the full path
+        b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        assert m1(**b2, keep_logits=True).logits is not None

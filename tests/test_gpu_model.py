@@ -105,6 +105,37 @@ def test_forward_backward_vs_reference_golden(golden, project_after_pool, tag):
         assert r[k] < 3e-2, (k, r[k])
 
 
+@pytest.mark.parametrize("pack", [False, True])
+def test_lm_head_labelled_rows_equals_full_logits_and_reference_gradients(golden, pack):
+    """config.lm_head_labelled_rows (bench.py's default): lm_head / cross-entropy / their backward only on the rows that carry a
+    target.  Same loss as the full-logits pass (fp32 sums over a different row count: <= 1e-6 rel), every gradient within the
+    bf16 noise of the full pass, and the gradients still inside the REFERENCE golden's bounds (handsonvlm.py:132-145 computes all
+    rows and lets CrossEntropyLoss drop the ignored ones).  Padded and packed layouts."""
+    g3 = golden("g3_forward.npz")
+    ids, labels, mask, images, fh, fv = tiny_batch()
+    res = {}
+    for flag in (False, True):
+        m, cfg = tiny_model(lm_head_labelled_rows=flag, pack_sequences=pack)
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh.clone(),
+                contact_point=torch.zeros(2, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(2),
+                cvae_eps=T(g3["eps_noise"]).cuda())
+        assert (out.logits is None) == flag
+        loss = float(out.loss)
+        out.loss.backward()
+        g = {n: gr.float().clone() for n, _, gr, _ in m.trainable_tensors()}
+        g.update({"head." + n: p.grad.float().clone() for n, p in m.hand_traj_decoder.named_parameters()})
+        res[flag] = (loss, g, cfg)
+    (l0, g0, cfg), (l1, g1, _) = res[False], res[True]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    for n in g0:
+        r = float((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-30))
+        assert r < 4e-3, (n, r)
+    assert abs(l1 - float(g3["loss"])) / float(g3["loss"]) < 2e-3
+    assert rel(g1["lm_head"][:32101][::1601], g3["g_lm_head_rows"]) < 3e-2
+    assert rel(g1["layers.1.down"], g3["g_down1"]) < 3e-2 and rel(g1["norm"], g3["g_norm"]) < 3e-2
+    assert rel(g1["embed"][32100], g3["g_embed_hand"]) < 3e-2
+
+
 def test_mixed_text_only_batch_backward_vs_oracle():
     """A text-only sample (no <image> token; handsonvlm.py:234-244) next to an image sample: its visual-token gradient
     rows are zero, so the projector gradient is that of the image sample alone — checked against the oracle's autograd on
