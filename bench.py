@@ -725,6 +725,8 @@ def main():
         lab = batch["labels"]
         rows_lbl = int((lab[:, 1:] != -100).sum()) if cfg.lm_head_labelled_rows else rows_all
         flops_llm -= 3.0 * 2.0 * (rows_all - rows_lbl) * cfg.hidden_size * cfg.vocab_size
+        # ... and the LAST decoder layer's o_proj + MLP, which run on the same rows only (LlamaStack.forward(last_rows=...))
+        flops_llm -= 3.0 * 2.0 * (rows_all - rows_lbl) * (cfg.hidden_size * cfg.hidden_size + 3 * cfg.hidden_size * cfg.intermediate_size)
         step_flops = flops_llm + flops_clip
         res = {
             "metric": "SFT samples/sec HandsOnVLM-7B" if args.model == "7b" else f"SFT samples/sec HandsOnVLM-{args.model}",
@@ -751,10 +753,11 @@ def main():
                                           "sample instead of the reference's 25 600; its skipped FLOPs are not counted as work)"
                                           if cfg.project_after_pool else "mm_projector on all patch tokens, as the reference"),
                        "lm_head_rows_per_step": rows_lbl, "rows_per_step": rows_all,
-                       "lm_head_note": ("lm_head, cross-entropy and their backward run on the rows that carry a target (the synthetic batch masks "
-                                        "the first 40 % of the text like a prompt; visual-token rows never have one): zero-loss / zero-gradient "
-                                        "rows are skipped, loss and gradients are those of the full-logits pass (--full-logits), and the "
-                                        "skipped rows' FLOPs are not counted as work" if cfg.lm_head_labelled_rows else
+                       "lm_head_note": ("lm_head, the cross-entropy, the LAST decoder layer's o_proj + MLP and their backward run on the rows "
+                                        "that carry a target (the synthetic batch masks the first 40 % of the text like a prompt; visual-token "
+                                        "rows never have one): the other rows' outputs there feed nothing — zero loss, zero gradient; loss and "
+                                        "gradients are those of the all-rows pass (--full-logits), and the skipped rows' FLOPs are not counted "
+                                        "as work" if cfg.lm_head_labelled_rows else
                                         "lm_head on all rows, as the reference's forward"),
                        "optimizer": "AdamW fp32 master", "grad_dtype": "bf16", "clip_tower_dtype": args.clip_dtype, "activation_recompute": ("all layers" if args.recompute < 0 else (f"first {args.recompute} layers" if args.recompute else False)),
                        "prompt_lengths": "fixed" if lens is None else f"U{{{args.varlen}}} (rank 0: mean {float(lens.mean()):.1f}, max {int(lens.max())})",

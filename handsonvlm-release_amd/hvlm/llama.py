@@ -250,8 +250,10 @@ class LlamaStack:
         _lib.check(rc, "llama_decode_step")
         return hidden
 
-    def _layer_forward(self, li: int, x: torch.Tensor, seq: "SeqInfo", save: bool, cache=None):
-        """One decoder layer.  Returns (output, saved-activation dict or None)."""
+    def _layer_forward(self, li: int, x: torch.Tensor, seq: "SeqInfo", save: bool, cache=None, rows=None):
+        """One decoder layer.  Returns (output, saved-activation dict or None).
+        rows (int64 [n], LAST layer of a training pass only): everything after the attention — o_proj, the MLP — runs on these rows
+        only and the output is [n, D]: the other rows' outputs of the last layer feed nothing (see forward(last_rows=...))."""
         lp = self.layers[li]
         eps, scale = self.cfg.rms_norm_eps, self.dh ** -0.5
         mm = (lambda a, k, residual=None: self._mm_fp8(li, k, a, residual)) if seq.fp8 else \
@@ -277,6 +279,9 @@ class LlamaStack:
                 else:
                     cache[li][:, :seq.S, self.D:].copy_(qkv.view(seq.B, seq.S, -1)[:, :, self.D:])
         ao, lse = ops.attn_fwd(qkv, seq.B, seq.S, self.H, self.dh, True, scale, need_lse=save, cu_seqlens=seq.cu)
+        ao_full, x_full, mrows = ao, x, seq.M
+        if rows is not None:
+            ao, x, mrows = ao.index_select(0, rows), x.index_select(0, rows), int(rows.numel())
         h = mm(ao, "o", residual=x)
         if fuse8:
             hn, rstd2 = ops.rmsnorm_fwd_fp8(h, lp.w["ln2"], eps), None
@@ -287,7 +292,7 @@ class LlamaStack:
         if save and _FUSED_T and self.F % 64 == 0:
             # the token-contiguous copy of act (operand of dW_down) is written by the SwiGLU kernel itself; the row-major
             # act is only needed by down_proj right below and is not kept
-            act, actT = ops.swiglu_fwd_t(gu, _round_up(seq.M, 64))
+            act, actT = ops.swiglu_fwd_t(gu, _round_up(mrows, 64))
         elif fuse8 and self.F % 8 == 0 and self.F <= 14336:
             act = ops.swiglu_fwd_fp8(gu)                  # e4m3 rows + scales: the down-projection's operand as it is
         else:
@@ -295,25 +300,34 @@ class LlamaStack:
         if probe is not None:
             probe[li].update(o=float(ao.abs().max()), gu=float(hn.abs().max()), down=float(act.abs().max()))
         xo = mm(act, "down", residual=h)
-        sv = dict(x=x, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao, h=h, rstd2=rstd2, hn=hn, gu=gu,
+        sv = dict(x=x_full, rstd1=rstd1, xn=xn, qkv=qkv, lse=lse, ao=ao_full, h=h, rstd2=rstd2, hn=hn, gu=gu,
                   act=None if actT is not None else act, actT=actT) if save else None
+        if sv is not None and rows is not None:
+            sv.update(rows=rows, ao_v=ao)
         return xo, sv
 
     def forward(self, x: torch.Tensor, B: int, S: int, save: Optional[bool] = None,
                 all_hidden: bool = False, cache: Optional[List[torch.Tensor]] = None,
-                cu_seqlens: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, fp8: bool = False):
-        """x [M, D] bf16 -> final-normed hidden [M, D].
+                cu_seqlens: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, fp8: bool = False,
+                last_rows: Optional[torch.Tensor] = None):
+        """x [M, D] bf16 -> final-normed hidden [M, D]  ([n, D] with last_rows, see below).
         Padded batch: M = B*S, sample b owns rows [b*S, (b+1)*S), positions arange(S) (right padding is harmless under the
         causal mask).  Packed batch (cu_seqlens int32 [B+1] on the device + pos int32 [M]): the B samples are stored end
         to end without padding rows, S = the longest sample — the unpadded contract of the reference's flash-attention
         patch (llama_flash_attn_monkey_patch.py:81-96), kept through the WHOLE decoder here, not only around attention.
-        Saves activations for backward when `save` (default: self.training); with self.recompute only each layer's input."""
+        Saves activations for backward when `save` (default: self.training); with self.recompute only each layer's input.
+        last_rows (int64 [n] row indices, training passes): the rows whose final hidden state is consumed (lm_head on labelled rows,
+        the <hand_traj> gather).  Every row feeds the K / V of every layer, but the LAST layer's o_proj and MLP outputs of the other
+        rows feed nothing — zero loss, zero gradient — so that layer gathers the n rows after its attention and the stack returns
+        [n, D]; backward() takes d(hidden) [n, D].  The reference (LlamaModel.forward) computes all rows."""
         save = self.training if save is None else save
         cfg = self.cfg
         M = x.shape[0]
         assert x.shape == (M, self.D) and x.dtype == BF16 and S <= cfg.max_position_embeddings
         assert (cu_seqlens is None and M == B * S) or (cu_seqlens is not None and pos is not None and pos.numel() == M)
         assert not (fp8 and save), "the fp8 GEMMs are an inference path (BASELINE config 5)"
+        assert last_rows is None or (save and not all_hidden and cache is None), "last_rows: training passes without all_hidden"
+        self.last_rows = last_rows
         if fp8 and getattr(self, "_fp8_rw", None) is None:
             self.fp8_prepare_rowwise()
         seq = SeqInfo(B=B, S=S, M=M, cu=cu_seqlens, pos=self._positions(B, S) if pos is None else pos, fp8=fp8)
@@ -321,7 +335,7 @@ class LlamaStack:
         hs = [x] if all_hidden else None
         for li in range(self.L):
             keep_all = save and li >= self.recompute
-            xo, sv = self._layer_forward(li, x, seq, keep_all, cache)
+            xo, sv = self._layer_forward(li, x, seq, keep_all, cache, rows=last_rows if li == self.L - 1 else None)
             if save:
                 self.saved.append(sv if keep_all else dict(x=x))
             x = xo
@@ -522,8 +536,9 @@ class LlamaStack:
         assert self.training and self.saved, "forward(save=True) must precede backward"
         seq = self.seq
         B, S, M, pos = seq.B, seq.S, seq.M, seq.pos
-        mpad = _round_up(M, 64)
+        mpad_full = _round_up(M, 64)
         scale = self.dh ** -0.5
+        last_rows = getattr(self, "last_rows", None)
         dx, dwn = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"])
         self.norm_g.copy_(dwn)
         for i in range(self.L - 1, -1, -1):
@@ -531,7 +546,9 @@ class LlamaStack:
             if i < self.recompute:
                 # activation recompute (the reference's gradient checkpointing, scripts/finetune.sh:36): only the layer input
                 # was kept; its forward is run again here, bit-identical to the first one (deterministic kernels)
-                sv = self._layer_forward(i, sv["x"], seq, True)[1]
+                sv = self._layer_forward(i, sv["x"], seq, True, rows=last_rows if i == self.L - 1 else None)[1]
+            rows = sv.get("rows")                        # last layer with last_rows: dx, the MLP and o_proj live on [n, D]
+            mpad = mpad_full if rows is None else _round_up(int(rows.numel()), 64)
             # ---- MLP ----
             dact = ops.gemm_nt(dx, lp.wt["down"])                      # [M,F] = dx @ Wd
             self._dw(dx, sv["act"], lp.g["down"], mpad, xT=sv.get("actT"))   # dWd[D,F]
@@ -548,7 +565,13 @@ class LlamaStack:
             lp.g["ln2"].copy_(dw2)
             # ---- attention ----
             dao = ops.gemm_nt(dh, lp.wt["o"])
-            self._dw(dh, sv["ao"], lp.g["o"], mpad)
+            self._dw(dh, sv["ao"] if rows is None else sv["ao_v"], lp.g["o"], mpad)
+            if rows is not None:                         # back to all M rows: the other rows' d(attention output) and residual
+                dao_v, dh_v = dao, dh                    # gradient are exactly zero
+                dao = torch.zeros((M, dao_v.shape[1]), dtype=dao_v.dtype, device=dao_v.device).index_copy_(0, rows, dao_v)
+                dh = torch.zeros((M, dh_v.shape[1]), dtype=dh_v.dtype, device=dh_v.device).index_copy_(0, rows, dh_v)
+                del dao_v, dh_v
+                mpad = mpad_full
             # (the inverse rotary of dq / dk rides in the attention backward's epilogues: no separate pass over dqkv)
             dqkv = ops.attn_bwd(sv["qkv"], sv["ao"], dao, sv["lse"], B, S, self.H, self.dh, True, scale, cu_seqlens=seq.cu,
                                 rope=(self.cos, self.sin, pos))

@@ -77,6 +77,7 @@ class SplicePlan:
     # rows with a target (shifted label != IGNORE_INDEX), for config.lm_head_labelled_rows
     rows_v: Optional[torch.Tensor] = None      # int64 [n_v] row indices into inputs_embeds
     targets_v: Optional[torch.Tensor] = None   # int32 [n_v] = targets[rows_v]
+    hand_rows_v: Optional[torch.Tensor] = None # int32 [B*4]: hand_rows as indices into rows_v (every hand row carries a target)
     n_v: int = 0
 
 
@@ -328,15 +329,22 @@ class HandsOnVLMForCausalLM:
                           hand_slot=torch.from_numpy(slot.reshape(-1)).to(dev),
                           hand_scale=torch.tensor(scales, dtype=torch.float32, device=dev),
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets,
-                          hand_rows=hand_rows, has_hand=has_hand, lengths=lengths, **self._valid_rows(nl, vidx if nl is not None else None, tg if nl is not None else None))
+                          hand_rows=hand_rows, has_hand=has_hand, lengths=lengths, **self._valid_rows(nl, vidx if nl is not None else None, tg if nl is not None else None, hr if nl is not None else None))
 
-    def _valid_rows(self, nl, vidx, tg) -> dict:
+    def _valid_rows(self, nl, vidx, tg, hr) -> dict:
         """Rows that carry a target, resolved on the host with the rest of the plan (config.lm_head_labelled_rows)."""
         if nl is None or vidx is None or not self.config.lm_head_labelled_rows:
             return {}
         dev = self.device
+        hf = hr.reshape(-1)
+        hv = np.full(hf.shape, -1, dtype=np.int32)
+        if vidx.size and (hf >= 0).any():
+            at = np.searchsorted(vidx, hf[hf >= 0])
+            assert (at < vidx.size).all() and (vidx[at] == hf[hf >= 0]).all(), "a <hand_traj> row without a target"
+            hv[hf >= 0] = at.astype(np.int32)
         return dict(rows_v=torch.from_numpy(vidx.astype(np.int64)).to(dev),
-                    targets_v=torch.from_numpy(np.ascontiguousarray(tg.reshape(-1)[vidx])).to(dev), n_v=int(vidx.size))
+                    targets_v=torch.from_numpy(np.ascontiguousarray(tg.reshape(-1)[vidx])).to(dev), n_v=int(vidx.size),
+                    hand_rows_v=torch.from_numpy(hv).to(dev))
 
     def _embed_segments(self, flat_src: np.ndarray):
         """Text rows grouped by token id in a FIXED order (stable sort): the embedding gradient is summed segment by
@@ -387,7 +395,7 @@ class HandsOnVLMForCausalLM:
                           labels=None if nl is None else torch.from_numpy(nl).to(dev), targets=targets, hand_rows=hand_rows,
                           has_hand=has_hand, lengths=lengths, seg=seg, cu=torch.from_numpy(cu).to(dev),
                           pos=torch.from_numpy(pos).to(dev), row_sample=torch.from_numpy(row_sample).to(dev),
-                          **self._valid_rows(nl, vidx if has_labels else None, tg if has_labels else None))
+                          **self._valid_rows(nl, vidx if has_labels else None, tg if has_labels else None, hr if has_labels else None))
 
     # ------------------------------------------------------------------------------------------
     # forward
@@ -439,27 +447,30 @@ class HandsOnVLMForCausalLM:
                                  hands_dev, plan.hand_scale if hands_dev is not None else None, B, S, self.token_dim,
                                  NV, max(n_hands, 1), row_sample=plan.row_sample)
         shape3 = (lambda t: t) if pack else (lambda t: t.view(B, S, -1))
+        last_only = kwargs.get("last_logits_only", False) and labels is None
+        # labelled rows only (config.lm_head_labelled_rows, training passes that do not hand out the logits): the rows without a
+        # target — visual tokens, the prompt, padding — have zero loss and zero gradient, so lm_head, the cross-entropy and their
+        # backward run on the gathered [n_v, D] rows; same loss, same gradients, `out.logits` is None.  Without
+        # output_hidden_states the LAST decoder layer's o_proj and MLP run on those rows only as well (`pruned`, LlamaStack.forward).
+        compact = (training_pass and labels is not None and not last_only and plan.n_v > 0
+                   and not kwargs.get("keep_logits", False))
+        pruned = compact and not output_hidden_states
         if output_hidden_states:
             hidden, hs = self.stack.forward(x, B, S, save=training_pass, all_hidden=True, cu_seqlens=plan.cu, pos=plan.pos)
             hs = tuple(shape3(h) for h in hs)
         else:
-            hidden, hs = self.stack.forward(x, B, S, save=training_pass, cu_seqlens=plan.cu, pos=plan.pos), None
-        last_only = kwargs.get("last_logits_only", False) and labels is None
+            hidden, hs = self.stack.forward(x, B, S, save=training_pass, cu_seqlens=plan.cu, pos=plan.pos,
+                                            last_rows=plan.rows_v if pruned else None), None
         if last_only:
             rows = torch.from_numpy((np.arange(B) * S + plan.lengths - 1).astype(np.int64)).to(dev)
             self._last_hidden = hidden[rows].contiguous()                     # read by sample() on <hand_traj>
             logits_p = ops.gemm_nt(self._last_hidden, self.lm_head)
             logits = logits_p[:, : cfg.vocab_size].unsqueeze(1)
-        # labelled rows only (config.lm_head_labelled_rows, training passes that do not hand out the logits): the rows without a
-        # target — visual tokens, the prompt, padding — have zero loss and zero gradient, so lm_head, the cross-entropy and their
-        # backward run on the gathered [n_v, D] rows; same loss, same gradients, `out.logits` is None
-        compact = (training_pass and labels is not None and not last_only and plan.n_v > 0
-                   and not kwargs.get("keep_logits", False))
         hidden_v = None
         if last_only:
             pass
         elif compact:
-            hidden_v = hidden.index_select(0, plan.rows_v)
+            hidden_v = hidden if pruned else hidden.index_select(0, plan.rows_v)      # (pruned: the stack returned [n_v, D])
             logits_p = ops.gemm_nt(hidden_v, self.lm_head)                   # [n_v, Vpad] bf16
             logits = None
         else:
@@ -473,7 +484,7 @@ class HandsOnVLMForCausalLM:
             fv = future_valid
             if not plan.has_hand.all():
                 fv[torch.from_numpy(~plan.has_hand).to(fv.device)] = 0      # in place, like the reference (:178)
-            emb = ops.hand_gather_fwd(hidden, plan.hand_rows, B, self.token_dim, torch.float32)
+            emb = ops.hand_gather_fwd(hidden, plan.hand_rows_v if pruned else plan.hand_rows, B, self.token_dim, torch.float32)
             emb.requires_grad_(training_pass)
             with torch.enable_grad():
                 tl = self.hand_traj_decoder(emb, future_hands.to(dev, torch.float32), fv.to(dev, torch.float32),
@@ -482,7 +493,7 @@ class HandsOnVLMForCausalLM:
             value = head_loss.detach() + loss_text
             comps = {"text loss": loss_text, "traj_loss": tl["traj_loss"].detach(), "traj_kl_loss": tl["traj_kl_loss"].detach()}
             if training_pass:
-                self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb, hidden_v=hidden_v,
+                self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb, hidden_v=hidden_v, pruned=pruned,
                                  head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1], M=plan.M)
                 loss = _EngineLoss.apply(self._anchor, self, value)
             else:
@@ -513,11 +524,15 @@ class HandsOnVLMForCausalLM:
             grad_scale = torch.ones((), device=dev)
         grad_scale = grad_scale.to(dev, torch.float32).reshape(())
         gs = (grad_scale / c["n_valid"]).reshape(1).contiguous()
+        hand_rows = plan.hand_rows
         if c.get("hidden_v") is not None:         # labelled rows only: d(hidden) of every other row is exactly zero
             dlogits = ops.ce_bwd_(c["logits_p"], plan.targets_v, c["row_lse"], gs, cfg.vocab_size)
             dh_v = ops.gemm_nt(dlogits, self.lm_head_t)                       # [n_v, D]
-            dhidden = torch.zeros((M, self.token_dim), dtype=BF16, device=dev)
-            dhidden.index_copy_(0, plan.rows_v, dh_v)
+            if c.get("pruned"):                   # the stack's last layer lives on these rows too: hand d(hidden) [n_v, D] over
+                dhidden, hand_rows = dh_v, plan.hand_rows_v
+            else:
+                dhidden = torch.zeros((M, self.token_dim), dtype=BF16, device=dev)
+                dhidden.index_copy_(0, plan.rows_v, dh_v)
             self.stack._dw(dlogits, c["hidden_v"], self.lm_head_g, _round_up(plan.n_v, 64))
             del dh_v
         else:
@@ -531,7 +546,7 @@ class HandsOnVLMForCausalLM:
             p.grad = None
         with torch.enable_grad():
             (c["head_loss"] * grad_scale).backward()
-        ops.hand_gather_bwd_(c["emb"].grad.contiguous(), plan.hand_rows, dhidden, B, self.token_dim)
+        ops.hand_gather_bwd_(c["emb"].grad.contiguous(), hand_rows, dhidden, B, self.token_dim)
         if self.on_grads_ready is not None:
             self.stack._join_side()              # lm_head's gradient was computed on the side stream
             self.on_grads_ready("head")

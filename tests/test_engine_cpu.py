@@ -264,3 +264,17 @@ def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
         # keep_logits=True hands out the full logits and takes the full path
         b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         assert m1(**b2, keep_logits=True).logits is not None
+
+
+def test_labelled_rows_with_activation_recompute_is_bit_identical(monkeypatch):
+    """The last layer's row-pruned form (o_proj and MLP on the labelled rows only) is re-run identically by the recompute path."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    batch = _batch()
+    l0, g0, k0, _ = _run(_model(lm_head_labelled_rows=True), batch)
+    l1, g1, k1, _ = _run(_model(lm_head_labelled_rows=True, activation_recompute=True), batch)
+    assert "rows" in k0[-1] and "ao_v" in k0[-1] and all("rows" not in k for k in k0[:-1])     # only the LAST layer is pruned
+    assert all(k == ["x"] for k in k1)
+    assert l0 == l1
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
