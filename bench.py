@@ -455,6 +455,9 @@ def other_configs(args):
         # runs the CLIP tower on all 100; hvlm matches frames by hash, verifies them bit for bit and encodes each distinct frame
         # once (what hvlm/train.py does) — identical features, a tenth of the tower's work.  Reported here, NOT as the headline.
         "variant_7b_sft_exact_frame_dedup": ["--dedup", "--steps", "3", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events"],
+        # the headline workload with lm_head and the last decoder layer on ALL rows, the reference's shapes (the headline runs them on
+        # the labelled rows only: same loss and gradients): what the labelled-rows switch is worth on THIS box
+        "variant_7b_sft_all_rows": ["--full-logits", "--steps", "3", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events"],
     }
     out = {}
     for name, flags in runs.items():
