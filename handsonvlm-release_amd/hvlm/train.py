@@ -140,6 +140,7 @@ def main():
     else:
         cfg = HandsOnVLMConfig.vicuna_7b() if a.model == "7b" else HandsOnVLMConfig.vicuna_13b()
     cfg.dedup_frames = True
+    cfg.lm_head_labelled_rows = True      # the trainer reads the loss only: lm_head and the last layer's MLP on labelled rows (exact)
     model = HandsOnVLMForCausalLM(cfg, device=torch.device("cuda", local), training=True).init_random(0)
     train(model, SyntheticEpicDataset(a.samples), a.output_dir, a.per_device_train_batch_size, a.num_train_epochs, a.steps,
           a.learning_rate)
