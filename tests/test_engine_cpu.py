@@ -264,6 +264,19 @@ def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
         # keep_logits=True hands out the full logits and takes the full path
         b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         assert m1(**b2, keep_logits=True).logits is not None
+        # output_hidden_states=True: every layer's full hidden state is handed out, so the last layer is NOT pruned — only lm_head and
+        # the cross-entropy run on the labelled rows; same loss and gradients again
+        b3 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        m3 = _model(pack_sequences=pack, lm_head_labelled_rows=True)
+        out3 = m3(**b3, output_hidden_states=True)
+        assert out3.logits is None and len(out3.hidden_states) == m3.config.num_hidden_layers + 1
+        assert all("rows" not in sv for sv in m3.stack.saved)
+        out3.loss.backward()
+        assert abs(float(out3.loss.detach()) - l0) <= 2e-6 * abs(l0)
+        g3 = {n: gr for n, _, gr, _ in m3.trainable_tensors()}
+        for n in g3:
+            a, b = g0[n].float(), g3[n].float()
+            assert float((a - b).norm() / (a.norm() + 1e-30)) < 2e-3, (pack, n)
 
 
 def test_labelled_rows_with_activation_recompute_is_bit_identical(monkeypatch):
