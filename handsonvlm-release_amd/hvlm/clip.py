@@ -127,14 +127,31 @@ class CLIPVisionTower:
         come from the epilogue of the GEMM that wrote that stream.  The 268-us LayerNorm pass (and its 0.84 GB round trip)
         between every pair of GEMMs of the tower disappears: 2 of the 47 passes of a forward remain."""
         p, q = self.p, {}
+        self.fold_fallbacks = []
         for i in range(self.n_run):
             for name, lnk in (("qkv", "ln1"), ("fc1", "ln2")):
                 W = p[f"{i}.{name}_w"].float()
                 ln_w, ln_b = p[f"{i}.{lnk}_w"].float(), p[f"{i}.{lnk}_b"].float()
-                Wf = (W * ln_w[None, :]).to(torch.float16).contiguous()
+                W32 = W * ln_w[None, :]
+                c2_32 = p[f"{i}.{name}_b"].float() + W @ ln_b
+                Wf = W32.to(torch.float16).contiguous()
+                # Range / precision check (a trained CLIP-L pairs outlier residual channels with very small or large ln_w): a
+                # folded column W[:, k] ln_w[k] that overflows fp16 or sinks into its subnormals (< 6.1e-5: fewer than 11 bits)
+                # would be multiplied with the RAW — possibly huge — channel k.  Per column, the rounded weights must reproduce
+                # the fp32 product to 1.5e-3 rel-L2 (normal fp16 rounding: ~3e-4); otherwise THIS GEMM keeps its explicit
+                # LayerNorm pass (_forward_layers_folded reads `{i}.{name}_ok`).
+                col_err = (Wf.float() - W32).norm(dim=0) / W32.norm(dim=0).clamp(min=1e-30)
+                ok = bool(torch.isfinite(Wf).all()) and float(W32.abs().max()) < 65504.0 and float(col_err.max()) <= 1.5e-3 \
+                    and float(c2_32.abs().max()) < 65504.0
+                q[f"{i}.{name}_ok"] = ok
+                if not ok:
+                    self.fold_fallbacks.append((i, name, float(col_err.max())))
+                    continue
                 q[f"{i}.{name}_wf"] = Wf
                 q[f"{i}.{name}_c1"] = Wf.float().sum(1).contiguous()                       # of the ROUNDED folded weights: what the MFMA multiplies
-                q[f"{i}.{name}_c2"] = (p[f"{i}.{name}_b"].float() + W @ ln_b).to(torch.float16).contiguous()
+                q[f"{i}.{name}_c2"] = c2_32.to(torch.float16).contiguous()
+        # (the unfolded q|k|v / fc1 weights stay resident next to the folded copies — 350 MB for ViT-L: the e4m3 tower, the
+        # HVLM_CLIP_FOLD_LN=0 A/B path and a fallback layer read them)
         self._pf = q
 
     # -- fp8 forward (BASELINE config 5) ----------------------------------------------------------
@@ -233,7 +250,7 @@ class CLIPVisionTower:
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
         have = False
         for i in range(self.n_run):
-            if not have:
+            if not have or not q[f"{i}.qkv_ok"]:
                 y = ops.layernorm_fwd_f16(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], eps)
                 qkv = ops.gemm_f16_nt(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
                 del y
@@ -244,7 +261,12 @@ class CLIPVisionTower:
             x = ops.gemm_f16_nt_ln(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x, stats_out=part)
             del a
             ops.ln_stats_finalize(part, M, nparts, d, eps, out=stats)
-            hmid = ops.gemm_f16_nt_ln(x, q[f"{i}.fc1_wf"], bias=q[f"{i}.fc1_c2"], act=ops.ACT_QUICK_GELU, ln=(stats, q[f"{i}.fc1_c1"]))
+            if q[f"{i}.fc1_ok"]:
+                hmid = ops.gemm_f16_nt_ln(x, q[f"{i}.fc1_wf"], bias=q[f"{i}.fc1_c2"], act=ops.ACT_QUICK_GELU, ln=(stats, q[f"{i}.fc1_c1"]))
+            else:                                                            # fold refused for this GEMM (_fold_prepare): explicit pass
+                y = ops.layernorm_fwd_f16(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], eps)
+                hmid = ops.gemm_f16_nt(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+                del y
             last = i == self.n_run - 1
             x = ops.gemm_f16_nt_ln(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x, stats_out=None if last else part)
             del hmid

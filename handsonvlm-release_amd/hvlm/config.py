@@ -59,7 +59,7 @@ class HandsOnVLMConfig:
     lm_head_labelled_rows: bool = False  # training passes: lm_head + cross-entropy only on rows whose shifted label is not IGNORE_INDEX
                                          # (visual-token, prompt and padding rows have zero loss and zero gradient: handsonvlm.py:132-145
                                          # computes their logits and CrossEntropyLoss(ignore_index=-100) drops them) — same loss and
-                                         # gradients; `out.logits` is None in such a pass unless keep_logits=True.  Without
+                                         # gradients; reading `out.logits` in such a pass raises unless keep_logits=True (model.LabelledRowsOutput).  Without
                                          # output_hidden_states the LAST decoder layer's o_proj and MLP run on those rows only, too
                                          # (every row still feeds every layer's K / V; LlamaStack.forward(last_rows=...))
     clip_chunk_frames: int = 1600      # frames per CLIP pass (bounds activation memory: ~11 GB of fp16 activations at 224 px).  One

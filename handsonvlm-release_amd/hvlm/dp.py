@@ -94,7 +94,10 @@ class EmbedRows:
       reduce(g)     at the tail hook: the union rows are gathered into a compact [n, D] buffer, that buffer is all-reduced, and
       finish()      copies it back (on the stream that waited for the collective).  Rows outside the union are zero on every
                     rank, so the result equals the dense all-reduce bit for bit.  Falls back to the dense all-reduce when the
-                    union covers more than half of the vocabulary (uniform synthetic ids at 8 ranks: ~86 %)."""
+                    union covers more than half of the vocabulary (uniform synthetic ids at 8 ranks: ~86 %).
+    OPT-IN (attach(embed_rows=True) / HVLM_DP_EMBED_ROWS=1): prepare() costs one host synchronisation per step, and whether that is
+    cheaper than ~1.5 ms of dense 263-MB all-reduce over xGMI has not been measured on an N > 1 RCCL box yet — until it has, the
+    dense all-reduce is the default."""
 
     def __init__(self, buckets: "GradBuckets", vocab: int):
         self.buckets, self.vocab = buckets, vocab
@@ -103,9 +106,14 @@ class EmbedRows:
         self.rows_last = None              # accounting: rows reduced in the last step (None: dense)
 
     def prepare(self, token_ids: torch.Tensor):
-        self.idx, self.rows_last = None, None
         if not self.buckets.active:
+            self.idx, self.rows_last = None, None
             return
+        # the blocking all-reduce below must not be issued between the async bucket all-reduces of a step that is still open (the
+        # ranks would disagree on the collective order): every step ends with buckets.wait(), which empties `handles`
+        assert not self.buckets.handles and self._pending is None, \
+            "EmbedRows.prepare: the previous step's all-reduces were not waited for (GradBuckets.wait())"
+        self.idx, self.rows_last = None, None
         mask = torch.zeros(self.vocab, dtype=torch.int32, device=token_ids.device)
         mask[token_ids.long()] = 1
         dist.all_reduce(mask, op=dist.ReduceOp.SUM, group=self.buckets.group)
@@ -128,16 +136,24 @@ class EmbedRows:
             embed_g, idx, compact = self._pending
             self._pending = None
             embed_g.index_copy_(0, idx, compact)
+            if compact.is_cuda:
+                # `compact` was allocated on the compute stream; with the overlapped optimizer this copy runs on the optimizer's
+                # stream: tell the caching allocator, or the block could be handed out again before the copy has executed
+                compact.record_stream(torch.cuda.current_stream())
 
 
-def attach(model, buckets: GradBuckets, opt=None):
+def attach(model, buckets: GradBuckets, opt=None, embed_rows: Optional[bool] = None):
     """Wires the model's backward hooks to the buckets: layer i -> its flat bucket; 'tail' -> embed, lm_head,
     projector, final norm and the CVAE head's PyTorch gradients.  With an overlapped optimizer (`opt`, optim.AdamW
-    with overlap=True) every bucket is also handed to it the moment it is final, ordered after its all-reduce."""
+    with overlap=True) every bucket is also handed to it the moment it is final, ordered after its all-reduce.
+    embed_rows: all-reduce the embedding gradient over the union of touched rows (EmbedRows; default: HVLM_DP_EMBED_ROWS=1,
+    else the dense buffer)."""
     stack = model.stack
     ready = opt.bucket_ready if opt is not None else (lambda key, after=(), post=None: None)
     rows = None
-    if hasattr(model, "on_token_ids") and getattr(model.embed_g, "dim", lambda: 0)() == 2:
+    if embed_rows is None:
+        embed_rows = os.environ.get("HVLM_DP_EMBED_ROWS", "0") == "1"
+    if embed_rows and hasattr(model, "on_token_ids") and getattr(model.embed_g, "dim", lambda: 0)() == 2:
         rows = EmbedRows(buckets, model.embed_g.shape[0])
         model.on_token_ids = rows.prepare
     buckets.embed_rows = rows

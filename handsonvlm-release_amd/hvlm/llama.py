@@ -327,7 +327,6 @@ class LlamaStack:
         assert (cu_seqlens is None and M == B * S) or (cu_seqlens is not None and pos is not None and pos.numel() == M)
         assert not (fp8 and save), "the fp8 GEMMs are an inference path (BASELINE config 5)"
         assert last_rows is None or (save and not all_hidden and cache is None), "last_rows: training passes without all_hidden"
-        self.last_rows = last_rows
         if fp8 and getattr(self, "_fp8_rw", None) is None:
             self.fp8_prepare_rowwise()
         seq = SeqInfo(B=B, S=S, M=M, cu=cu_seqlens, pos=self._positions(B, S) if pos is None else pos, fp8=fp8)
@@ -343,7 +342,8 @@ class LlamaStack:
                 hs.append(x)
         hidden, rstd_f = ops.rmsnorm_fwd(x, self.norm_w, cfg.rms_norm_eps, save_rstd=save)
         if save:
-            self.final = dict(x=x, rstd=rstd_f)
+            # (last_rows travels with the saved state of THIS forward: backward() reads it from here, never from a loose attribute)
+            self.final = dict(x=x, rstd=rstd_f, last_rows=last_rows)
             self.seq = seq
         if all_hidden:
             hs[-1] = hidden
@@ -538,7 +538,11 @@ class LlamaStack:
         B, S, M, pos = seq.B, seq.S, seq.M, seq.pos
         mpad_full = _round_up(M, 64)
         scale = self.dh ** -0.5
-        last_rows = getattr(self, "last_rows", None)
+        last_rows = self.final.get("last_rows")
+        n_want = M if last_rows is None else int(last_rows.numel())
+        assert dhidden.shape == (n_want, self.D), \
+            (f"backward: d(hidden) has {tuple(dhidden.shape)}, the forward returned [{n_want}, {self.D}]"
+             + (" (last_rows: the stack's last layer ran on the labelled rows only)" if last_rows is not None else ""))
         dx, dwn = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"])
         self.norm_g.copy_(dwn)
         for i in range(self.L - 1, -1, -1):
@@ -586,6 +590,7 @@ class LlamaStack:
             if self.on_layer_grad_ready is not None:
                 self.on_layer_grad_ready(i)
         self.saved = []
+        self.final = None
         return dx
 
     # -- bookkeeping ----------------------------------------------------------------------------

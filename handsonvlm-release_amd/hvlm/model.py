@@ -46,6 +46,30 @@ class CausalLMOutputWithPast:
                      if v is not None)[i]
 
 
+class LabelledRowsOutput(CausalLMOutputWithPast):
+    """Output of a training pass under config.lm_head_labelled_rows: the [B, S, V] logits of the reference's forward
+    (handsonvlm.py:204-210) were never computed — lm_head ran on the rows that carry a target only.  Reading `.logits` raises
+    with the names of the switches instead of handing back None; the compact logits are `.logits_rows` [n_v, V] (row i is
+    `.rows[i]` of the flattened [B*S] (padded) or [M] (packed) row space), valid until backward() overwrites them in place."""
+
+    def __init__(self, logits_rows=None, rows=None, **kw):
+        super().__init__(**kw)
+        self.logits_rows, self.rows = logits_rows, rows
+
+    @property
+    def logits(self):
+        raise RuntimeError("out.logits is not available: this training pass ran lm_head on the labelled rows only "
+                           "(config.lm_head_labelled_rows=True).  Use out.logits_rows / out.rows, pass keep_logits=True to "
+                           "forward(), or set config.lm_head_labelled_rows=False to get the reference's [B, S, V] logits.")
+
+    @logits.setter
+    def logits(self, value):
+        assert value is None
+
+    def __getitem__(self, i):
+        return tuple(v for v in (self.loss, self.past_key_values, self.hidden_states, self.attentions) if v is not None)[i]
+
+
 @dataclass
 class SampleDecoderOnlyOutput:
     sequences: torch.Tensor = None
@@ -500,6 +524,11 @@ class HandsOnVLMForCausalLM:
                 loss = value
         if training_pass and kwargs.get("keep_logits", False) and logits is not None:
             logits = logits.clone()
+        if compact and not last_only:
+            if return_dict is False:
+                raise RuntimeError("return_dict=False needs the full logits: set config.lm_head_labelled_rows=False or pass keep_logits=True")
+            return LabelledRowsOutput(logits_rows=logits_p[:, : cfg.vocab_size], rows=plan.rows_v, loss=loss, past_key_values=None,
+                                      hidden_states=hs, attentions=None, loss_components=comps, cu_seqlens=plan.cu)
         out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=None, hidden_states=hs, attentions=None,
                                      loss_components=comps, cu_seqlens=plan.cu)
         if return_dict is False:

@@ -37,6 +37,16 @@ def set_gemm_hook(hook):
     _gemm_hook = hook
 
 
+# Optional instrumentation of the HBM-bound kernels (bench.py `hbm` object): hook(kernel_name, algorithmic_bytes, True) before /
+# hook(kernel_name, algorithmic_bytes, False) after the launch, on the launch stream.
+_hbm_hook = None
+
+
+def set_hbm_hook(hook):
+    global _hbm_hook
+    _hbm_hook = hook
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -321,7 +331,12 @@ def transpose(x: torch.Tensor, r_pad: Optional[int] = None, out: Optional[torch.
     if out is None:
         out = torch.empty((C, r_pad), dtype=BF16, device=x.device)
     assert out.shape == (C, r_pad) and out.is_contiguous()
+    hk = _hbm_hook
+    if hk is not None:
+        hk("transpose_kernel", 2.0 * (R * C + C * r_pad), True)
     check(_lib.load().hvlm_transpose_bf16(_p(x), _p(out), R, C, x.stride(0), r_pad, _stream()), "transpose")
+    if hk is not None:
+        hk("transpose_kernel", 2.0 * (R * C + C * r_pad), False)
     return out
 
 
@@ -344,7 +359,12 @@ def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, save_rstd: bool = 
     rows = x.numel() // D
     y = torch.empty_like(x) if out is None else out
     rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if save_rstd else None
+    hk = _hbm_hook
+    if hk is not None:
+        hk("rmsnorm_fwd_kernel", 4.0 * rows * D, True)
     check(_lib.load().hvlm_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, D, eps, _stream()), "rmsnorm_fwd")
+    if hk is not None:
+        hk("rmsnorm_fwd_kernel", 4.0 * rows * D, False)
     return y, rstd
 
 
@@ -356,10 +376,16 @@ def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None):
     dx = torch.empty_like(x) if out is None else out
     part = torch.empty((NORM_BWD_BLOCKS, D), dtype=torch.float32, device=x.device)
     lib = _lib.load()
+    hk = _hbm_hook
+    nbytes = 2.0 * rows * D * (4 if add is not None else 3)          # dy, x (, add) read, dx written
+    if hk is not None:
+        hk("rmsnorm_bwd_kernel (+ reduce_rows)", nbytes, True)
     check(lib.hvlm_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(add), _p(dx), _p(part), rows, D, _stream()),
           "rmsnorm_bwd")
     dw = torch.empty((D,), dtype=BF16, device=x.device)
     check(lib.hvlm_reduce_rows_f32(_p(part), _p(dw), NORM_BWD_BLOCKS, D, 1, _stream()), "reduce_rows")
+    if hk is not None:
+        hk("rmsnorm_bwd_kernel (+ reduce_rows)", nbytes, False)
     return dx, dw
 
 
@@ -553,7 +579,12 @@ def swiglu_fwd_t(gu: torch.Tensor, r_pad: int):
     M, F2 = gu.shape
     act = torch.empty((M, F2 // 2), dtype=BF16, device=gu.device)
     actT = torch.empty((F2 // 2, r_pad), dtype=BF16, device=gu.device)
+    hk = _hbm_hook
+    if hk is not None:
+        hk("swiglu_fwd_t_kernel", 2.0 * (M * F2 + M * (F2 // 2) + (F2 // 2) * r_pad), True)
     check(_lib.load().hvlm_swiglu_fwd_t(_p(gu), _p(act), _p(actT), M, F2 // 2, r_pad, _stream()), "swiglu_fwd_t")
+    if hk is not None:
+        hk("swiglu_fwd_t_kernel", 2.0 * (M * F2 + M * (F2 // 2) + (F2 // 2) * r_pad), False)
     return act, actT
 
 
@@ -562,7 +593,12 @@ def swiglu_bwd_t(gu, dact, r_pad: int):
     M, F2 = gu.shape
     dgu = torch.empty_like(gu)
     dguT = torch.empty((F2, r_pad), dtype=BF16, device=gu.device)
+    hk = _hbm_hook
+    if hk is not None:
+        hk("swiglu_bwd_t_kernel", 2.0 * (M * F2 + M * (F2 // 2) + M * F2 + F2 * r_pad), True)
     check(_lib.load().hvlm_swiglu_bwd_t(_p(gu), _p(dact), _p(dgu), _p(dguT), M, F2 // 2, r_pad, _stream()), "swiglu_bwd_t")
+    if hk is not None:
+        hk("swiglu_bwd_t_kernel", 2.0 * (M * F2 + M * (F2 // 2) + M * F2 + F2 * r_pad), False)
     return dgu, dguT
 
 
@@ -682,8 +718,14 @@ def hand_gather_bwd_(dout: torch.Tensor, rows: torch.Tensor, dhidden: torch.Tens
 
 def adamw_step_(master, m, v, grad, w, wt, lr, beta1, beta2, eps, wd, grad_scale, step):
     R, C = (w.shape[0], w.shape[1]) if w.dim() == 2 else (1, w.numel())
+    hk = _hbm_hook
+    nbytes = float(R * C) * (30 if wt is not None else 28)      # fp32 master / m / v read + written, bf16 g read, bf16 w (and w^T) written
+    if hk is not None:
+        hk("adamw_kernel", nbytes, True)
     check(_lib.load().hvlm_adamw_step(_p(master), _p(m), _p(v), _p(grad), _p(w), _p(wt), R, C, lr, beta1, beta2, eps,
                                       wd, grad_scale, step, _stream()), "adamw_step")
+    if hk is not None:
+        hk("adamw_kernel", nbytes, False)
 
 
 def add(a, b, out=None):

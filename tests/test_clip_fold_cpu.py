@@ -58,3 +58,46 @@ def test_folded_tower_equals_explicit_tower_and_oracle(monkeypatch, select_layer
     e_fold, e_expl, e_ab = rel(outs[True], ref), rel(outs[False], ref), rel(outs[True], outs[False])
     print(f"select_layer {select_layer}: folded vs oracle {e_fold:.2e}, explicit vs oracle {e_expl:.2e}, folded vs explicit {e_ab:.2e}")
     assert e_fold <= 1.5 * e_expl + 2e-4 and e_fold <= 1e-2 and e_ab <= 1e-2
+
+
+def test_fold_refuses_columns_that_sink_into_fp16_subnormals_and_falls_back(monkeypatch):
+    """ADVICE r3 (clip.py::_fold_prepare): a trained CLIP-L pairs outlier residual channels with very small / large ln_w.  With an
+    ln_w spread of 1e-4 .. 10 and a x300 residual channel sitting on a small gain, the folded column W[:, k] ln_w[k] of layer 1's
+    q|k|v falls below fp16's normal range: that GEMM must keep its explicit LayerNorm pass (fold_fallbacks names it), every other
+    GEMM stays folded, and the tower still matches the fp32 oracle like the explicit tower does.  A spread of 0.05 .. 10 is folded
+    everywhere."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from hvlm import clip as clip_mod
+    from hvlm.config import CLIPVisionConfig
+    c = dict(clip_d=256, clip_mlp=512, clip_layers=4, clip_heads=4, patch=14, image=28)
+    cfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4, image_size=28, patch_size=14)
+    img = synth.make_images(1, 4, 4, 28, seed=19)[0]
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    for lo, expect_fallback in ((1e-4, True), (0.05, False)):
+        p = synth.to_torch(synth.clip_params(c, seed=6))
+        g = torch.Generator().manual_seed(1)
+        for k in list(p):
+            if "layer_norm" in k and k.endswith("weight"):
+                spread = torch.exp(torch.empty(256).uniform_(float(torch.log(torch.tensor(lo * 20))), float(torch.log(torch.tensor(10.0))), generator=g))
+                p[k] = spread
+        # an outlier channel (x300 in the residual stream, written by layer 0's fc2) read through a tiny gain by layer 1's LayerNorms
+        p["vision_model.encoder.layers.0.mlp.fc2.bias"][17] = 300.0
+        p["vision_model.encoder.layers.1.layer_norm1.weight"][17] = lo
+        with torch.no_grad():
+            ref = R.clip_features(img, p, 4, 4)
+        outs = {}
+        for fold in (True, False):
+            monkeypatch.setattr(clip_mod, "_FOLD_LN", fold)
+            tower = clip_mod.CLIPVisionTower(cfg, "cpu", dtype=torch.float16)
+            tower.load_state_dict(p)
+            outs[fold] = tower(img.to(torch.bfloat16)).float()
+            if fold:
+                fb = [(i, n) for i, n, _ in tower.fold_fallbacks]
+                assert ((1, "qkv") in fb) == expect_fallback, (lo, tower.fold_fallbacks)
+                assert len(fb) <= 2, fb                                     # the rest of the tower stays folded
+                assert all(tower._pf[f"{i}.{n}_ok"] for i in range(tower.n_run) for n in ("qkv", "fc1") if (i, n) not in fb)
+        e_fold, e_expl = rel(outs[True], ref), rel(outs[False], ref)
+        print(f"ln_w spread from {lo}: folded (+ fallbacks) vs oracle {e_fold:.2e}, explicit vs oracle {e_expl:.2e}")
+        assert torch.isfinite(outs[True]).all()
+        assert e_fold <= 1.5 * e_expl + 5e-4 and e_fold <= 2e-2

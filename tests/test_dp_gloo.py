@@ -135,7 +135,7 @@ def _engine_worker(rank, world, port, ret):
     dp.init_from_env(backend="gloo")
     model, batch = _tiny_model_and_batch(rank)
     opt = AdamW(model, lr=1e-2)
-    buckets = dp.attach(model, dp.GradBuckets(), opt)
+    buckets = dp.attach(model, dp.GradBuckets(), opt, embed_rows=True)
     order = []
     inner_layer, inner_named = model.stack.on_layer_grad_ready, model.on_grads_ready
     model.stack.on_layer_grad_ready = lambda i: (order.append(f"layers.{i}"), inner_layer(i))
@@ -143,10 +143,19 @@ def _engine_worker(rank, world, port, ret):
     out = model(**batch)
     opt.begin_step(grad_scale=1.0 / world)
     model.backward()
+    # a step whose all-reduces are still pending must not start the next one: EmbedRows.prepare (a BLOCKING all-reduce at the top
+    # of forward) would interleave with them — it refuses instead
+    guard = None
+    if buckets.handles:
+        try:
+            buckets.embed_rows.prepare(torch.tensor([5, 6], dtype=torch.int32))
+        except AssertionError as ex:
+            guard = str(ex)
     buckets.wait()
+    assert buckets.handles == [] and buckets.post == []
     summed = _grads(model)
     opt.step()
-    ret[rank] = dict(order=order, embed_rows=buckets.embed_rows.rows_last, grads={k: v.float().numpy() for k, v in summed.items()},
+    ret[rank] = dict(order=order, guard=guard, embed_rows=buckets.embed_rows.rows_last, grads={k: v.float().numpy() for k, v in summed.items()},
                      weights={k: v.float().numpy() for k, v in _weights(model).items()}, loss=float(out.loss.detach()))
     dist.destroy_process_group()
 
@@ -169,6 +178,7 @@ def test_dp_world2_real_engine_equals_mean_of_single_rank_grads():
     for rank in (0, 1):
         ids |= set(int(t) for t in _tiny_model_and_batch(rank)[1]["input_ids"].flatten().tolist() if t >= 0)
     assert r0["embed_rows"] == r1["embed_rows"] == len(ids) < 200
+    assert r0["guard"] and "not waited for" in r0["guard"] and r1["guard"]     # prepare() before wait(): refused on both ranks
     # single-rank gradients of the two minibatches, in this process
     from hvlm.optim import AdamW
     single = []

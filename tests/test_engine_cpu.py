@@ -4,6 +4,7 @@
   * packed (unpadded, cu_seqlens) batches (config.pack_sequences; the reference's flash-attn patch contract,
     llama_flash_attn_monkey_patch.py:81-96) give the padded batch's loss and gradients (up to fp32 summation order)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import synth
@@ -238,7 +239,8 @@ def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
     """config.lm_head_labelled_rows: lm_head, the cross-entropy and their backward on the rows that carry a target.  The other rows
     (visual tokens, prompt, padding) have zero loss and zero gradient in the reference (CrossEntropyLoss ignore_index = -100 over
     ALL positions, handsonvlm.py:132-145), so loss and every gradient must equal the full-logits pass up to the fp32 order of the
-    sums over rows; padded and packed layouts; `out.logits` is None unless keep_logits=True."""
+    sums over rows; padded and packed layouts; reading `out.logits` raises (naming the switch) unless keep_logits=True, and
+    `out.logits_rows` / `out.rows` are the compact logits."""
     import cpu_ops
     cpu_ops.install(monkeypatch)
     batch = _batch()
@@ -251,11 +253,14 @@ def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
         monkeypatch.setattr(ops, "gemm_nt", lambda a, b, *k, **kw: (calls.append((a.shape[0], b.shape[0])), g_nt(a, b, *k, **kw))[1])
         l1, g1, _, out1 = _run(m1, batch)
         monkeypatch.setattr(ops, "gemm_nt", g_nt)
-        assert out0.logits is not None and out1.logits is None
+        assert out0.logits is not None
+        with pytest.raises(RuntimeError, match="lm_head_labelled_rows"):
+            out1.logits
         Vp = m1.lm_head.shape[0]
         rows = [r for r, n in calls if n == Vp]
         n_valid = int((batch["labels"][:, 1:] != -100).sum())
         assert rows == [n_valid], (rows, n_valid)                     # the lm_head GEMM ran on exactly the labelled rows
+        assert out1.rows.numel() == n_valid and out1.logits_rows.shape == (n_valid, m1.config.vocab_size)
         assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
         for n in g0:
             a, b = g0[n].float(), g1[n].float()
@@ -269,7 +274,7 @@ def test_lm_head_on_labelled_rows_only_matches_full_logits(monkeypatch):
         b3 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         m3 = _model(pack_sequences=pack, lm_head_labelled_rows=True)
         out3 = m3(**b3, output_hidden_states=True)
-        assert out3.logits is None and len(out3.hidden_states) == m3.config.num_hidden_layers + 1
+        assert out3.logits_rows is not None and len(out3.hidden_states) == m3.config.num_hidden_layers + 1
         assert all("rows" not in sv for sv in m3.stack.saved)
         out3.loss.backward()
         assert abs(float(out3.loss.detach()) - l0) <= 2e-6 * abs(l0)

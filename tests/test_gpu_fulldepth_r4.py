@@ -1,0 +1,411 @@
+"""Full-depth end-to-end parity at the sizes bench.py runs — round-3 verdict item 1.
+
+The reference calls a 32-layer LlamaModel + lm_head (handsonvlm/model/language_model/handsonvlm.py:119-200); every other `-m gpu`
+parity test of the decoder stops at 2 layers of production width (or at D <= 512).  Here the WHOLE hot path runs once at the size of
+BASELINE configs 2 / 3 — CLIP ViT-L/14 on 100 frames (10 distinct, tiled like epic_dataset.py:90-95), projector, pooling, splice
+with 4 <hand_traj> tokens, 32 decoder layers at D = 4096 / H = 32 / F = 11008, S = 867, lm_head, shifted CE, hand gather, CVAE head,
+and the whole backward — against the CPU oracle (oracle/ref_cpu.py, fp32) on the GPU box's host cores:
+
+  (a) loss, final hidden states, a logits slice, and the gradients of layers.0 q|k|v, layers.31 down_proj, the final norm, the
+      projector and the <hand_traj> embedding row.  Yardstick: the oracle's OWN bf16-eager run (bf16 LLM, fp16 tower — the dtype
+      path the reference trains in, op by op) against the fp32 oracle; the HIP path must sit within 1.25x of that envelope per
+      quantity (+ absolute caps).  The weights are "trained-like": RMSNorm gains 1 +- 0.1 and outlier channels in the residual
+      stream (rows of two early down_proj matrices x40, the way massive activations arise in trained decoders).
+  (b) the same batch with lm_head_labelled_rows, packed rows and activation recompute: loss within 1e-6 rel of (a)'s, gradients
+      within bf16 noise.
+  (c) fp8 (BASELINE config 5) at depth on those outlier-channel weights: rel-L2 of the final hidden state of the e4m3 prefill
+      against bf16 and against the fp32 oracle, and the ADE / FDE / WDE shift of fp8-prefill / all-fp8 generation against bf16 with
+      pinned CVAE noise.
+  (d) 13B (L = 40, D = 5120, H = 40, F = 13824), S = 2048 (BASELINE config 4), forward-only loss and final hidden vs the oracle.
+
+Numbers go to gpurun_out/fulldepth_report.json (committed as profiles/r04*_fulldepth_report.json) and DESIGN.md §4."""
+import gc
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle import synth  # noqa: E402
+
+BF = torch.bfloat16
+REPORT = {}
+OUTLIER_CH = (7, 300, 1111, 2048, 3333, 4001)      # channels of the residual stream that carry massive activations
+OUTLIER_GAIN = 40.0
+HOST_THREADS = 32                                    # the GPU box's 256 hardware threads are slower than 32 on these GEMMs (bench.py)
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+class _threads:
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        torch.set_num_threads(max(1, min(HOST_THREADS, os.cpu_count() or 1)))
+
+    def __exit__(self, *a):
+        torch.set_num_threads(self.n)
+
+
+def _build(model_name, training, L=None):
+    from hvlm.config import HandsOnVLMConfig
+    from hvlm.model import HandsOnVLMForCausalLM
+    cfg = HandsOnVLMConfig.vicuna_7b() if model_name == "7b" else HandsOnVLMConfig.vicuna_13b()
+    L = L or (int(os.environ["HVLM_FULLDEPTH_L"]) if os.environ.get("HVLM_FULLDEPTH_L") else None)   # debugging aid: a shallow dry run
+    if L is not None:
+        cfg.num_hidden_layers = L
+    m = HandsOnVLMForCausalLM(cfg, device="cuda:0", training=training).init_random(seed=0, std=0.02)
+    D = cfg.hidden_size
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for lp in m.stack.layers:                                             # non-trivial RMSNorm gains
+            for k in ("ln1", "ln2"):
+                lp.w[k].copy_((1.0 + 0.1 * torch.randn(D, device="cuda", generator=g)).to(BF))
+        m.stack.norm_w.copy_((1.0 + 0.1 * torch.randn(D, device="cuda", generator=g)).to(BF))
+        ch = torch.tensor(OUTLIER_CH, device="cuda")
+        for li in (1, 2):                                                     # outlier channels, written by early MLPs
+            m.stack.layers[li].w["down"][ch] *= OUTLIER_GAIN
+            m.stack.layers[li].refresh_transposes()
+        m.proj_b.copy_((0.02 * torch.randn(D, device="cuda", generator=g)).to(BF))
+        # a head whose outputs are image coordinates (0.5 +- 0.1), like normalised hand positions
+        last = m.hand_traj_decoder.hand_traj_decoder.cvae.dec_MLP[2]
+        last.weight.mul_(0.1)
+        last.bias.fill_(0.5)
+    # ViT-L/14 tower with non-trivial LayerNorm gains / biases (synth.clip_params), loaded on both sides
+    c = dict(clip_d=1024, clip_mlp=4096, clip_layers=24, clip_heads=16, patch=14, image=224)
+    clip_np = synth.clip_params(c, seed=77)
+    m.tower.load_state_dict(synth.to_torch(clip_np))
+    return m, cfg, clip_np
+
+
+def _batch(B, T, seed, pad_tail=(5,)):
+    ids, labels, mask = synth.make_text_batch(B, T, seed=seed, n_hand=(4,), pad_tail=pad_tail)
+    r = np.random.RandomState(seed + 1)
+    base = torch.from_numpy(r.standard_normal((B, 10, 3, 224, 224)).astype(np.float32)).to(BF)
+    images = base[:, torch.arange(100) % 10].contiguous()                    # [f0..f9] x 10 (epic_dataset.py:90-95)
+    fh, fv = synth.make_hands(B, seed=seed + 2)
+    eps = torch.randn(B * 8, 256, generator=torch.Generator().manual_seed(seed + 3))
+    return dict(ids=ids, labels=labels, mask=mask, images=images, base=base, fh=fh, fv=fv, eps=eps)
+
+
+def _hip_pass(m, bt, **fw):
+    out = m(input_ids=bt["ids"], attention_mask=bt["mask"], labels=bt["labels"], image=bt["images"], future_hands=bt["fh"].clone(),
+            contact_point=torch.zeros(bt["ids"].shape[0], 2), future_valid=bt["fv"].clone(),
+            gt_label_valid=torch.ones(bt["ids"].shape[0]), cvae_eps=bt["eps"].cuda(), **fw)
+    return out
+
+
+GRAD_KEYS = ("g_qkv0", "g_down_last", "g_norm", "g_proj_w", "g_proj_b", "g_embed_hand", "g_embed_rows")
+
+
+def _hip_grads(m, cfg, bt):
+    L = cfg.num_hidden_layers
+    named = {n: g for n, w, g, wt in m.trainable_tensors()}
+    rows = bt["ids"][0, :5].clamp(min=0).cuda()
+    return {"g_qkv0": named["layers.0.qkv"].float().cpu(), "g_down_last": named[f"layers.{L - 1}.down"].float().cpu(),
+            "g_norm": named["norm"].float().cpu(), "g_proj_w": named["proj_w"].float().cpu(), "g_proj_b": named["proj_b"].float().cpu(),
+            "g_embed_hand": named["embed"][32100].float().cpu(), "g_embed_rows": named["embed"][rows].float().cpu()}
+
+
+def _oracle_params(m, clip_np, dtype, clip_dtype, grad_names):
+    """The HIP model's own (bf16-valued) weights on the host in `dtype`; requires_grad only where a gradient is compared, so the
+    oracle's backward computes activation gradients through all layers but no other weight gradient."""
+    p = {}
+    for k, v in m.state_dict().items():
+        t = v.detach().to("cpu").to(torch.float32 if k.startswith("hand_traj_decoder.") else dtype)
+        if k in grad_names:
+            t.requires_grad_(True)
+        p[k] = t
+    cp = synth.to_torch(clip_np, clip_dtype)
+    return p, cp
+
+
+def _oracle_pass(m, cfg, clip_np, bt, dtype, clip_dtype, backward=True):
+    L, H = cfg.num_hidden_layers, cfg.num_attention_heads
+    gnames = {"model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.weight", "model.layers.0.self_attn.v_proj.weight",
+              f"model.layers.{L - 1}.mlp.down_proj.weight", "model.norm.weight", "model.mm_projector.weight", "model.mm_projector.bias",
+              "model.embed_tokens.weight"} if backward else set()
+    t0 = time.perf_counter()
+    p, cp = _oracle_params(m, clip_np, dtype, clip_dtype, gnames)
+    B = bt["ids"].shape[0]
+    with _threads():
+        with torch.no_grad():
+            # the tower is frozen: features of the 10 distinct frames, tiled (identical to encoding all 100)
+            feats10 = R.clip_features(bt["base"].flatten(0, 1).to(clip_dtype), cp, 24, 16)          # [B*10, 256, 1024] in clip_dtype
+            feats = feats10.view(B, 10, 256, 1024)[:, torch.arange(100) % 10].to(dtype)           # cast like clip_encoder.py:48
+        t_clip = time.perf_counter() - t0
+        ctx = torch.enable_grad() if backward else torch.no_grad()
+        with ctx:
+            tok = torch.nn.functional.linear(feats.reshape(B * 100 * 256, 1024), p["model.mm_projector.weight"], p["model.mm_projector.bias"])
+            vis = R.temporal_spatial_pool(tok.view(B, 100, 256, -1))
+            ref = R.forward_loss(p, dict(n_layers=L, n_heads=H, cond_dtype=BF), bt["ids"], bt["labels"], bt["mask"], vis, bt["fh"], bt["fv"], bt["eps"])
+            if backward:
+                ref["loss"].backward()
+    out = {"loss": float(ref["loss"]), "loss_text": float(ref["loss_text"]), "traj_loss": float(ref["traj_loss"]), "kl_loss": float(ref["kl_loss"]),
+           "hidden": ref["hidden"].detach().float(), "logits_slice": ref["logits"].detach().float()[:, ::7, ::251].clone(),
+           "vis": vis.detach().float(), "wall_s": time.perf_counter() - t0, "clip_s": t_clip}
+    if backward:
+        D = cfg.hidden_size
+        g = lambda k: p[k].grad.detach().float()  # noqa: E731
+        rows = bt["ids"][0, :5].clamp(min=0)
+        out.update({"g_qkv0": torch.cat([g(f"model.layers.0.self_attn.{n}_proj.weight") for n in "qkv"], 0),
+                    "g_down_last": g(f"model.layers.{L - 1}.mlp.down_proj.weight"), "g_norm": g("model.norm.weight"),
+                    "g_proj_w": g("model.mm_projector.weight"), "g_proj_b": g("model.mm_projector.bias"),
+                    "g_embed_hand": g("model.embed_tokens.weight")[32100].clone(), "g_embed_rows": g("model.embed_tokens.weight")[rows].clone()})
+    del p, cp, ref
+    gc.collect()
+    return out
+
+
+@pytest.fixture(scope="module")
+def seven_b():
+    m, cfg, clip_np = _build("7b", training=True)
+    bt = _batch(1, 512, seed=40)
+    st = {"m": m, "cfg": cfg, "clip_np": clip_np, "bt": bt}
+    yield st
+    st.clear()
+    del m
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _default_pass(st):
+    """(a)'s HIP run, cached: reference shapes (all rows through lm_head, padded rows, no recompute)."""
+    if "hip" in st:
+        return st["hip"]
+    m, cfg, bt = st["m"], st["cfg"], st["bt"]
+    cfg.lm_head_labelled_rows, cfg.pack_sequences = False, False
+    m.stack.recompute = 0
+    out = _hip_pass(m, bt, output_hidden_states=True)
+    S = out.logits.shape[1]
+    hip = {"loss": float(out.loss.detach()), "hidden": out.hidden_states[-1].float().cpu(), "S": S,
+           "logits_slice": out.logits.float().cpu()[:, ::7, ::251].clone(),
+           "comps": {k: float(v) for k, v in out.loss_components.items()}}
+    out.loss.backward()
+    torch.cuda.synchronize()
+    hip.update(_hip_grads(m, cfg, bt))
+    st["hip"] = hip
+    return hip
+
+
+def test_a_7b_full_depth_forward_backward_vs_oracle(seven_b):
+    st = seven_b
+    m, cfg, bt = st["m"], st["cfg"], st["bt"]
+    hip = _default_pass(st)
+    assert hip["S"] == 512 + 355
+    ref = _oracle_pass(m, cfg, st["clip_np"], bt, torch.float32, torch.float32)
+    env = _oracle_pass(m, cfg, st["clip_np"], bt, BF, torch.float16)          # the reference's dtype path, op by op
+    st["ref_hidden"] = ref["hidden"]
+    S = hip["S"]
+    valid = torch.ones(1, S, dtype=torch.bool); valid[0, S - 5:] = False      # pad rows hold whatever the padding produced
+    vs = valid[:, ::7]
+    r = {"loss_hip": hip["loss"], "loss_oracle_fp32": ref["loss"], "loss_oracle_bf16_eager": env["loss"],
+         "loss_text": [hip["comps"]["text loss"], ref["loss_text"], env["loss_text"]],
+         "traj_loss": [hip["comps"]["traj_loss"], ref["traj_loss"], env["traj_loss"]],
+         "kl_loss": [hip["comps"]["traj_kl_loss"], ref["kl_loss"], env["kl_loss"]],
+         "oracle_wall_s": {"fp32": ref["wall_s"], "bf16_eager": env["wall_s"], "clip_fp32": ref["clip_s"], "clip_fp16": env["clip_s"]}}
+    hipq = {"hidden": rel(hip["hidden"][valid], ref["hidden"][valid]), "logits": rel(hip["logits_slice"][vs], ref["logits_slice"][vs])}
+    envq = {"hidden": rel(env["hidden"][valid], ref["hidden"][valid]), "logits": rel(env["logits_slice"][vs], ref["logits_slice"][vs])}
+    for k in GRAD_KEYS:
+        hipq[k], envq[k] = rel(hip[k], ref[k]), rel(env[k], ref[k])
+    r["hip_vs_fp32_oracle"], r["bf16_eager_oracle_vs_fp32_oracle"] = hipq, envq
+    st["hip_vs_oracle"] = hipq
+    r["loss_rel"] = abs(hip["loss"] - ref["loss"]) / abs(ref["loss"])
+    r["loss_rel_bf16_eager"] = abs(env["loss"] - ref["loss"]) / abs(ref["loss"])
+    # the outlier channels are really there (the point of the "trained-like" weights)
+    hx = ref["hidden"][0, : S - 5]
+    r["outlier_ratio_final_hidden"] = float(hx[:, list(OUTLIER_CH)].abs().mean() / hx.abs().mean())
+    REPORT["a_7b_L32_S867"] = r
+    print(json.dumps(r, indent=1))
+    assert np.isfinite(hip["loss"]) and r["loss_rel"] <= max(1.25 * r["loss_rel_bf16_eager"], 2e-3), r
+    for k, e in envq.items():
+        assert hipq[k] <= 1.25 * e + 1e-3, (k, hipq[k], e)
+    assert hipq["hidden"] < 3e-2 and hipq["logits"] < 3e-2
+    for k in GRAD_KEYS:
+        assert hipq[k] < 6e-2, (k, hipq[k])
+
+
+def test_b_7b_labelled_rows_packed_recompute_equal_default(seven_b):
+    st = seven_b
+    m, cfg, bt = st["m"], st["cfg"], st["bt"]
+    base = _default_pass(st)
+    rep = {}
+    variants = {"labelled_rows": dict(lbl=True, pack=False, rc=0), "packed": dict(lbl=False, pack=True, rc=0),
+                "recompute": dict(lbl=False, pack=False, rc=cfg.num_hidden_layers),
+                "labelled_rows+packed+recompute": dict(lbl=True, pack=True, rc=cfg.num_hidden_layers)}
+    try:
+        for name, v in variants.items():
+            cfg.lm_head_labelled_rows, cfg.pack_sequences = v["lbl"], v["pack"]
+            m.stack.recompute = v["rc"]
+            out = _hip_pass(m, bt)
+            loss = float(out.loss.detach())
+            out.loss.backward()
+            torch.cuda.synchronize()
+            g = _hip_grads(m, cfg, bt)
+            rep[name] = {"loss": loss, "loss_rel_vs_default": abs(loss - base["loss"]) / abs(base["loss"]),
+                         **{k: rel(g[k], base[k]) for k in GRAD_KEYS}}
+    finally:
+        cfg.lm_head_labelled_rows, cfg.pack_sequences = False, False
+        m.stack.recompute = 0
+    REPORT["b_7b_variants_vs_default"] = rep
+    print(json.dumps(rep, indent=1))
+    # Labelled rows: the last layer's GEMMs and lm_head sum over n_v instead of M rows, so a handful of bf16 roundings flip there
+    # (g_down_last: 3e-4) and every earlier layer's backward re-rounds the perturbed values — two bf16 runs of the SAME function
+    # decorrelate towards the bf16 noise floor of that tensor, which (a) measured as the HIP-vs-fp32-oracle distance.  Bound: 0.6x
+    # that distance (measured 0.31-0.37x at L = 3 and L = 32); without (a)'s numbers a flat 3e-2.
+    floor = st.get("hip_vs_oracle")
+    for name, rr in rep.items():
+        assert rr["loss_rel_vs_default"] <= 1e-6, (name, rr)
+        for k in GRAD_KEYS:
+            assert rr[k] <= (max(2e-3, 0.6 * floor[k]) if floor else 3e-2), (name, k, rr[k], floor and floor[k])
+    for k in GRAD_KEYS:                                                       # packed rows at B = 1 only drop the 5 pad rows
+        assert rep["packed"][k] <= 1e-3, k
+    assert rep["recompute"]["loss_rel_vs_default"] == 0.0                     # the recomputed forward is bit-identical
+    for k in GRAD_KEYS:
+        assert rep["recompute"][k] == 0.0, k
+
+
+def test_c_7b_fp8_at_depth_on_outlier_channel_weights(seven_b):
+    """BASELINE config 5 at the depth and on the activation statistics it would meet: 32 layers, outlier channels x40."""
+    st = seven_b
+    m, cfg, bt = st["m"], st["cfg"], st["bt"]
+    from hvlm import ops
+    from hvlm.traj_eval import evaluate_traj_stochastic
+    rep = {}
+    with torch.no_grad():
+        vis = m.visual_tokens(bt["images"].cuda())
+        plan = m.build_splice_plan(bt["ids"], None, vis.shape[1], 0, True, False)
+        x = ops.embed_splice_fwd(m.embed, vis, plan.src, None, None, None, 1, plan.S, m.token_dim, vis.shape[1], 1)
+        h16 = m.stack.forward(x, 1, plan.S, save=False).float().cpu()
+        h8 = m.stack.forward(x, 1, plan.S, save=False, fp8=True).float().cpu()
+    n = plan.S - 5
+    rep["final_hidden_rel_l2_fp8_vs_bf16"] = rel(h8[:n], h16[:n])
+    # control: the same network WITHOUT the outlier channels (the two down_proj row blocks back at their initial scale) — what the
+    # massive activations cost the per-token e4m3 scaling on top of e4m3's own 3-bit mantissa
+    ch_t = torch.tensor(OUTLIER_CH, device="cuda")
+    keep_rows = {li: m.stack.layers[li].w["down"][ch_t].clone() for li in (1, 2)}
+    try:
+        with torch.no_grad():
+            for li in (1, 2):
+                m.stack.layers[li].w["down"][ch_t] /= OUTLIER_GAIN
+            m.stack.invalidate_fp8()
+            c16 = m.stack.forward(x, 1, plan.S, save=False).float().cpu()
+            c8 = m.stack.forward(x, 1, plan.S, save=False, fp8=True).float().cpu()
+        rep["control_without_outliers"] = {"final_hidden_rel_l2_fp8_vs_bf16": rel(c8[:n], c16[:n]),
+                                           "outlier_ratio_final_hidden_bf16": float(c16[:n][:, list(OUTLIER_CH)].abs().mean() / c16[:n].abs().mean())}
+    finally:
+        with torch.no_grad():
+            for li in (1, 2):
+                m.stack.layers[li].w["down"][ch_t] = keep_rows[li]      # bit-exact restore
+                m.stack.layers[li].refresh_transposes()
+            m.stack.invalidate_fp8()
+    ch = list(OUTLIER_CH)
+    rep["outlier_ratio_final_hidden_bf16"] = float(h16[:n][:, ch].abs().mean() / h16[:n].abs().mean())
+    if "ref_hidden" in st:               # (a) ran: both against the fp32 oracle — training-pass splice differs only on the 4 hand rows
+        keep = torch.ones(n, dtype=torch.bool)
+        hand = (bt["ids"][0] == 32100).nonzero().flatten() + 355
+        keep[int(hand.min()):] = False   # rows from the first <hand_traj> on saw the GT-hand encoding in the training pass
+        want = st["ref_hidden"][0, :n][keep]
+        rep["final_hidden_rel_l2_vs_fp32_oracle"] = {"bf16": rel(h16[:n][keep], want), "fp8_prefill": rel(h8[:n][keep], want)}
+    # generation: 8 samples in lock step, forced tokens, pinned CVAE noise — the shift of the trajectory metrics
+    B, T = 8, 512
+    ids, _, mask = synth.make_text_batch(B, T, seed=61, n_hand=(0,), pad_tail=(0, 3, 9, 1))
+    r = np.random.RandomState(62)
+    base = torch.from_numpy(r.standard_normal((B, 8, 3, 224, 224)).astype(np.float32)).to(BF)
+    images = base[:, torch.arange(100) % 8].contiguous()
+    forced = [11, 12, 32100, 13, 32100, 14, 32100, 15, 32100, 16, 17, 2]
+    g = torch.Generator().manual_seed(63)
+    noise = [[2.0 * torch.randn(2, 256, generator=g) for _ in range(4)] for _ in range(B)]
+
+    def force(cur, scores):
+        s = torch.full_like(scores, -1e9)
+        s[:, forced[min(cur.shape[1] - T, len(forced) - 1)]] = 0.0
+        return s
+
+    kw = dict(logits_processor=[force], max_length=T + len(forced), eos_token_id=2, attention_mask=mask, image=images, hand_noise=noise)
+    runs = {"bf16": {}, "fp8_prefill": dict(fp8=True), "fp8_prefill_decode": dict(fp8=True, fp8_decode=True),
+            "all_fp8": dict(fp8=True, fp8_decode=True, fp8_clip=True)}
+    preds = {}
+    for name, sw in runs.items():
+        so = m.sample_batch(ids, **sw, **kw)
+        assert so.num_hands == [4] * B, name
+        preds[name] = so.pred_hands.float().cpu().numpy()
+    m.stack.invalidate_fp8()
+    m.stack._kv_cache_b = None
+    b16 = preds["bf16"]
+    gts = np.clip(b16 + np.random.RandomState(64).normal(0.0, 0.08, b16.shape), 0.01, 0.99).astype(np.float32)
+    valids = np.ones((B, 2), np.float32)
+    spread = np.linalg.norm(b16 - b16.mean((0, 2), keepdims=True), axis=-1).mean()
+    mb = np.array(evaluate_traj_stochastic(b16[:, None], gts, valids, reference_labels=False), dtype=np.float64)
+    rep["gen"] = {"bf16_ade_fde_wde": mb.tolist(), "pred_spread": float(spread)}
+    for name in ("fp8_prefill", "fp8_prefill_decode", "all_fp8"):
+        mt = np.array(evaluate_traj_stochastic(preds[name][:, None], gts, valids, reference_labels=False), dtype=np.float64)
+        dev = np.linalg.norm(preds[name] - b16, axis=-1)
+        rep["gen"][name] = {"ade_fde_wde": mt.tolist(), "metric_rel_shift": (np.abs(mt - mb) / mb).tolist(),
+                            "pred_hands_rel_l2_vs_bf16": rel(preds[name], b16), "mean_point_deviation": float(dev.mean()),
+                            "deviation_over_spread": float(dev.mean() / max(spread, 1e-12))}
+    REPORT["c_7b_fp8_L32_outliers"] = rep
+    print(json.dumps(rep, indent=1))
+    assert torch.isfinite(h8).all()
+    # e4m3 keeps 3 mantissa bits: a W8A8 GEMM output carries ~5 % relative error whatever K is (independent per-term errors of
+    # ~3.6 % x sqrt(2) do not average out relative to a random-sign sum), and the outlier channels — written by two down_proj GEMMs
+    # whose input went through two more — carry ~12-15 % of their own magnitude and dominate the L2 norm of the hidden state.
+    # What the evaluation consumes is the CVAE head's trajectory: its metrics move by <= 1 %.
+    # On a RANDOM-INIT network every layer's update is as large as the stream and depends on all of it, so per-GEMM errors compound
+    # with depth — for bf16 too: measured 0.146 (L = 3) and 0.288 (L = 32) for e4m3 against bf16's own 0.0116 / 0.0271 vs the fp32
+    # oracle, i.e. e4m3 sits 10.6-12.5x above bf16 at EVERY depth (3 mantissa bits against 8), with and without outlier channels
+    # (the control): nothing depth- or outlier-specific breaks.  What the evaluation consumes is the CVAE head's trajectory: its
+    # metrics move by <= 1 % (3 % asserted), decoded points by 1.6 % of the image (all-fp8).
+    assert rep["final_hidden_rel_l2_fp8_vs_bf16"] <= 0.40, rep
+    assert rep["final_hidden_rel_l2_fp8_vs_bf16"] <= 1.5 * rep["control_without_outliers"]["final_hidden_rel_l2_fp8_vs_bf16"] + 0.02, rep
+    if "final_hidden_rel_l2_vs_fp32_oracle" in rep:
+        e = rep["final_hidden_rel_l2_vs_fp32_oracle"]
+        rep["fp8_over_bf16_error_ratio"] = e["fp8_prefill"] / e["bf16"]
+        assert rep["fp8_over_bf16_error_ratio"] <= 16.0, rep
+    for name in ("fp8_prefill", "fp8_prefill_decode", "all_fp8"):
+        assert max(rep["gen"][name]["metric_rel_shift"]) <= 0.03, (name, rep["gen"][name])
+        assert rep["gen"][name]["mean_point_deviation"] <= 0.03, (name, rep["gen"][name])
+
+
+def test_d_13b_L40_S2048_forward_vs_oracle():
+    """BASELINE config 4's shape: Vicuna-13B width and depth, S = 2048 (T = 1693), B = 1, forward with labels (loss, final hidden,
+    logits slice) against the fp32 oracle, the bf16-eager oracle as the envelope."""
+    gc.collect()
+    torch.cuda.empty_cache()
+    m, cfg, clip_np = _build("13b", training=False)
+    bt = _batch(1, 1693, seed=50, pad_tail=(0,))
+    with torch.no_grad():
+        out = _hip_pass(m, bt, output_hidden_states=True)
+    S = out.logits.shape[1]
+    assert S == 2048
+    hip = {"loss": float(out.loss), "hidden": out.hidden_states[-1].float().cpu(), "logits_slice": out.logits.float().cpu()[:, ::7, ::251].clone()}
+    del out
+    ref = _oracle_pass(m, cfg, clip_np, bt, torch.float32, torch.float32, backward=False)
+    env = _oracle_pass(m, cfg, clip_np, bt, BF, torch.float16, backward=False)
+    r = {"loss_hip": hip["loss"], "loss_oracle_fp32": ref["loss"], "loss_oracle_bf16_eager": env["loss"],
+         "loss_rel": abs(hip["loss"] - ref["loss"]) / abs(ref["loss"]), "loss_rel_bf16_eager": abs(env["loss"] - ref["loss"]) / abs(ref["loss"]),
+         "hip_vs_fp32_oracle": {"hidden": rel(hip["hidden"], ref["hidden"]), "logits": rel(hip["logits_slice"], ref["logits_slice"])},
+         "bf16_eager_oracle_vs_fp32_oracle": {"hidden": rel(env["hidden"], ref["hidden"]), "logits": rel(env["logits_slice"], ref["logits_slice"])},
+         "oracle_wall_s": {"fp32": ref["wall_s"], "bf16_eager": env["wall_s"]}}
+    REPORT["d_13b_L40_S2048"] = r
+    print(json.dumps(r, indent=1))
+    del m
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert r["loss_rel"] <= max(1.25 * r["loss_rel_bf16_eager"], 2e-3), r
+    for k in ("hidden", "logits"):
+        assert r["hip_vs_fp32_oracle"][k] <= 1.25 * r["bf16_eager_oracle_vs_fp32_oracle"][k] + 1e-3, (k, r)
+        assert r["hip_vs_fp32_oracle"][k] < 8e-2          # (L = 40, S = 2048: measured 4.6e-2 against the bf16-eager oracle's 5.8e-2)
+
+
+def test_zz_write_report():
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/fulldepth_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1)

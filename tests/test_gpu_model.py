@@ -119,7 +119,12 @@ def test_lm_head_labelled_rows_equals_full_logits_and_reference_gradients(golden
         out = m(input_ids=ids, attention_mask=mask, labels=labels, image=images.to(torch.bfloat16), future_hands=fh.clone(),
                 contact_point=torch.zeros(2, 2), future_valid=fv.clone(), gt_label_valid=torch.ones(2),
                 cvae_eps=T(g3["eps_noise"]).cuda())
-        assert (out.logits is None) == flag
+        if flag:
+            with pytest.raises(RuntimeError, match="lm_head_labelled_rows"):
+                out.logits
+            assert out.logits_rows.shape[0] == out.rows.numel()
+        else:
+            assert out.logits is not None
         loss = float(out.loss)
         out.loss.backward()
         g = {n: gr.float().clone() for n, _, gr, _ in m.trainable_tensors()}

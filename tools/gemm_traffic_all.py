@@ -10,7 +10,14 @@ ONE process walks all shapes (3 calls of ops.gemm_nt each, operands = views of t
 profiler start-ups instead of two per shape (tools/gemm_traffic.py, round 2: ~12 GPU-minutes for 21 shapes).  The `run` side
 writes the number of GEMM-kernel launches each call made (a tail-split call is two) to <shapes>.launches.json; `drive` walks
 the counter CSV in dispatch order and hands consecutive gemm_pp dispatches to the shapes accordingly.
-Per shape it reports bytes per CALL (all launches of a call summed) and the launches per call, like the round-2 table."""
+Per shape it reports bytes per CALL (all launches of a call summed) and the launches per call, like the round-2 table.
+
+    python3 tools/gemm_traffic_all.py drive-fp8 [out.json]
+
+is the same for the e4m3 GEMMs of BASELINE config 5 (bench.py `eval.batched_fp8`): the four decoder-prefill shapes at
+M = 32 x 867 rows (q|k|v, o_proj, gate|up, down_proj; per-token x per-channel scales applied in the epilogue) through
+ops.gemm_fp8_nt_scaled -> gemm_pp4_fp8_kernel; algorithmic bytes = 1 B per operand element + 2 B per output element + the scales.
+The table is committed as profiles/r*_gemm_traffic_fp8.json and read by bench.py for `eval.batched_fp8.roofline.traffic`."""
 import csv
 import glob
 import json
@@ -22,11 +29,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CALLS = 3
 
 
-def run(shapes_path):
+FP8_SHAPES = [dict(M=32 * 867, N=12288, K=4096, launches=32), dict(M=32 * 867, N=4096, K=4096, launches=32),
+              dict(M=32 * 867, N=22016, K=4096, launches=32), dict(M=32 * 867, N=4096, K=11008, launches=32)]
+
+
+def run(shapes_path, fp8=False):
     sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
     import torch
     from hvlm import ops
     shapes = [r for r in json.load(open(shapes_path)) if r["K"] % 64 == 0]
+    if fp8:
+        return run_fp8(shapes, shapes_path, torch, ops)
     BF = torch.bfloat16
     na = max(r["M"] * r["K"] for r in shapes)
     nb = max(r["N"] * r["K"] for r in shapes)
@@ -52,18 +65,42 @@ def run(shapes_path):
     json.dump(launches, open(shapes_path + ".launches.json", "w"))
 
 
-def drive(shapes_path, out_path):
+def run_fp8(shapes, shapes_path, torch, ops):
+    BF = torch.bfloat16
+    launches = []
+    cur = [0]
+
+    def hook(M, N, K, begin, n_kernels=1):
+        if not begin:
+            cur[0] += n_kernels
+    ops.set_gemm_hook(hook)
+    for r in shapes:
+        M, N, K = r["M"], r["N"], r["K"]
+        a8, ia = ops.quantize_fp8_rowwise(torch.rand(M, K, device="cuda").sub_(0.5).to(BF))
+        b8, ib = ops.quantize_fp8_rowwise(torch.rand(N, K, device="cuda").sub_(0.5).to(BF))
+        out = torch.empty(M, N, dtype=BF, device="cuda")
+        cur[0] = 0
+        for _ in range(CALLS):
+            ops.gemm_fp8_nt_scaled(a8, b8, ia, ib, out=out)
+        torch.cuda.synchronize()
+        launches.append(dict(M=M, N=N, K=K, kernels=cur[0]))
+        del a8, b8, out
+    json.dump(launches, open(shapes_path + ".launches.json", "w"))
+
+
+def drive(shapes_path, out_path, fp8=False):
     by_ctr = {}
+    kname = "gemm_pp4_fp8" if fp8 else "gemm_pp"
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(ROOT, "gpurun_out", f"pmc_all_{ctr}")
         subprocess.run(["rm", "-rf", d])
         subprocess.run(["timeout", "900", "rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--",
-                        "python3", os.path.abspath(__file__), "run", os.path.abspath(shapes_path)],
+                        "python3", os.path.abspath(__file__), "run-fp8" if fp8 else "run", os.path.abspath(shapes_path)],
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         rows = []
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f)):
-                if "gemm_pp" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                if kname in row["Kernel_Name"] and row["Counter_Name"] == ctr:
                     rows.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
         rows.sort()
         by_ctr[ctr] = [v for _, v in rows]
@@ -82,7 +119,8 @@ def drive(shapes_path, out_path):
         pos += n
         M, N, K = r["M"], r["N"], r["K"]
         out.append(dict(M=M, N=N, K=K, launches=table[(M, N, K)], kernels_per_call=n / CALLS, fetch_bytes=f * 1024 * 2,
-                        write_bytes=w * 1024, algorithmic_bytes=2.0 * (M * K + N * K + M * N)))
+                        write_bytes=w * 1024,
+                        algorithmic_bytes=(1.0 * (M * K + N * K) + 2.0 * M * N + 4.0 * (M + N)) if fp8 else 2.0 * (M * K + N * K + M * N)))
         print(out[-1], flush=True)
     n = sum(o["launches"] for o in out)
     res = dict(per_shape=out,
@@ -101,5 +139,12 @@ if __name__ == "__main__":
     shapes = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "gemm_by_shape.json")
     if mode == "run":
         run(shapes)
+    elif mode == "run-fp8":
+        run(shapes, fp8=True)
+    elif mode == "drive-fp8":
+        sp = os.path.join(ROOT, "gpurun_out", "gemm_fp8_shapes.json")
+        os.makedirs(os.path.dirname(sp), exist_ok=True)
+        json.dump(FP8_SHAPES, open(sp, "w"))
+        drive(sp, sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "gemm_traffic_fp8.json"), fp8=True)
     else:
         drive(shapes, sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "gemm_traffic.json"))
