@@ -927,21 +927,6 @@ def main():
         default_run = (world == 1 and args.model == "7b" and args.image_size == 224 and not args.varlen and not args.dedup
                        and not args.recompute and args.layers is None and B == 16 and not cfg.lm_head_labelled_rows)
         want_cpu = world == 1 and not args.no_cpu_baseline
-        cpu_thread = None
-
-        def cpu_leg():
-            try:
-                res["cpu_baseline"] = cpu_baseline(cfg, T)
-            except Exception as ex:  # noqa
-                res["cpu_baseline"] = {"error": str(ex)[:200]}
-        if want_cpu and default_run and not args.no_other_configs:
-            # the CPU baseline (32 host threads of this box's 128+ cores, no GPU work) runs in a thread WHILE the child runs below
-            # keep the GPU busy: the children need one host core each, and the default run stays inside its wall-time budget
-            import threading
-            cpu_thread = threading.Thread(target=cpu_leg)
-            cpu_thread.start()
-        elif want_cpu:
-            cpu_leg()
         if default_run and not args.no_other_configs:
             # release this process's device memory (172 GiB of weights / optimizer state / activations), then run the other
             # BASELINE configurations as fresh child processes
@@ -956,10 +941,13 @@ def main():
             torch.cuda.empty_cache()
             left = torch.cuda.memory_allocated(device) / 2 ** 30
             res["other_configs"] = other_configs(args) if left < 8.0 else {"error": f"{left:.1f} GiB still allocated by the headline run"}
-        if cpu_thread is not None:
-            cpu_thread.join()
-            if isinstance(res.get("cpu_baseline"), dict) and "sample" in res["cpu_baseline"]:
-                res["cpu_baseline"]["sample"] += "; timed while this run's GPU child processes (other_configs) were running"
+        if want_cpu:
+            # AFTER the child runs, never beside them: 32 busy host threads slowed the launch-bound children by 5-30 % when this ran
+            # concurrently (profiles/r04a_bench7b_default.json: config 2 at 7.2 instead of 10.4 samples/s)
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, T)
+            except Exception as ex:  # noqa
+                res["cpu_baseline"] = {"error": str(ex)[:200]}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if torch.distributed.is_initialized():

@@ -1180,14 +1180,7 @@ int launch_pp(const GemmArgs& p, int grid, hipStream_t stream) {
 
 }  // namespace
 
-// Caller-owned scheduler state, per device (hvlm_gemm_set_sched_ws): the library's own `__device__` block above is only the
-// default, so that a host which wants every byte the kernels touch to be its own allocation can have that.
-static void* g_sched_ws[64] = {nullptr};
-void* pp_sched_ws() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  return g_sched_ws[dev];
-}
+// (the scheduler-state block of the current device's handle — hvlm_create — is looked up in runtime.hip: pp_sched_ws())
 
 int pp_sched_slot(hipStream_t stream) {
   static hipStream_t known[PP_NSCHED];
@@ -1240,18 +1233,3 @@ int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
 }  // namespace hvlm
 
 extern "C" size_t hvlm_gemm_sched_ws_bytes(void) { return sizeof(hvlm::PPSched) * hvlm::PP_NSCHED; }
-
-extern "C" int hvlm_gemm_set_sched_ws(void* ws, size_t bytes, void* stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { hvlm::set_error("gemm_set_sched_ws: no current device"); return HVLM_ERR_LAUNCH; }
-  if (ws == nullptr) { hvlm::g_sched_ws[dev] = nullptr; return HVLM_OK; }
-  HVLM_REQUIRE(bytes >= hvlm_gemm_sched_ws_bytes() && ((uintptr_t)ws & 255) == 0,
-               "gemm_set_sched_ws: need %zu bytes, 256-byte aligned", hvlm_gemm_sched_ws_bytes());
-  if (hipMemsetAsync(ws, 0, hvlm_gemm_sched_ws_bytes(), hvlm::as_stream(stream)) != hipSuccess) {
-    hvlm::set_error("gemm_set_sched_ws: hipMemsetAsync failed");
-    return HVLM_ERR_LAUNCH;
-  }
-  hvlm::g_sched_ws[dev] = ws;
-  return HVLM_OK;
-}
-

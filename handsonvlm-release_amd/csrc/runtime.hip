@@ -1,5 +1,7 @@
 // Error plumbing and device queries of libhvlm_hip.so.
 #include "common.h"
+#include "gemm_args.h"
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -96,6 +98,61 @@ extern "C" int hvlm_config_get(const char* key, int* value) {
 
 extern "C" int hvlm_is_dev_build(void) { return hvlm::kDevBuild ? 1 : 0; }
 
+// ---- per-device handle (include/hvlm.h: hvlm_create / hvlm_destroy) ------------------------------------------------------
+struct hvlm_handle {
+  int device;
+  void* sched_ws;       // caller-owned scheduler-state block of the persistent GEMM, or nullptr (the library's built-in block)
+};
+namespace hvlm {
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<hvlm_handle*> g_handles[kMaxDevices];      // the one table of mutable library state: device -> its handle
+}  // namespace
+void* pp_sched_ws() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  hvlm_handle* h = g_handles[dev].load(std::memory_order_acquire);
+  return h ? h->sched_ws : nullptr;
+}
+}  // namespace hvlm
+
+extern "C" int hvlm_create(int device, void* sched_ws, size_t sched_ws_bytes, void* stream, hvlm_handle** out) {
+  HVLM_REQUIRE(out != nullptr, "create: out is NULL");
+  *out = nullptr;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) { hvlm::set_error("create: no current device"); return HVLM_ERR_LAUNCH; }
+  HVLM_REQUIRE(device >= 0 && device < hvlm::kMaxDevices && device == cur,
+               "create: device %d is not the calling thread's current device (%d)", device, cur);
+  if (sched_ws != nullptr) {
+    HVLM_REQUIRE(sched_ws_bytes >= hvlm_gemm_sched_ws_bytes() && ((uintptr_t)sched_ws & 255) == 0,
+                 "create: sched_ws needs %zu bytes, 256-byte aligned", hvlm_gemm_sched_ws_bytes());
+    if (hipMemsetAsync(sched_ws, 0, hvlm_gemm_sched_ws_bytes(), hvlm::as_stream(stream)) != hipSuccess) {
+      hvlm::set_error("create: hipMemsetAsync failed");
+      return HVLM_ERR_LAUNCH;
+    }
+  }
+  hvlm_handle* h = new hvlm_handle{device, sched_ws};
+  hvlm_handle* expected = nullptr;
+  if (!hvlm::g_handles[device].compare_exchange_strong(expected, h, std::memory_order_acq_rel)) {
+    delete h;
+    hvlm::set_error("create: device %d already has a handle (hvlm_destroy it first)", device);
+    return HVLM_ERR_INVALID;
+  }
+  *out = h;
+  return HVLM_OK;
+}
+
+extern "C" int hvlm_destroy(hvlm_handle* handle) {
+  HVLM_REQUIRE(handle != nullptr && handle->device >= 0 && handle->device < hvlm::kMaxDevices, "destroy: bad handle");
+  hvlm_handle* expected = handle;
+  HVLM_REQUIRE(hvlm::g_handles[handle->device].compare_exchange_strong(expected, nullptr, std::memory_order_acq_rel),
+               "destroy: this handle is not the one registered for device %d", handle->device);
+  delete handle;
+  return HVLM_OK;
+}
+
+extern "C" int hvlm_handle_device(const hvlm_handle* handle) { return handle ? handle->device : HVLM_ERR_INVALID; }
+
 extern "C" int hvlm_abi_version(void) { return HVLM_ABI_VERSION; }
 
 extern "C" const char* hvlm_last_error(void) { return hvlm::g_err; }
@@ -116,6 +173,7 @@ extern "C" int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char*
   return HVLM_OK;
 }
 
+#ifdef HVLM_DEV
 // ---- diagnostic: occupy `workgroups` CUs for ~`cycles` clock cycles (64 KiB of LDS each, so that a workgroup
 // of the persistent GEMM cannot share the CU).  Stands in for an RCCL collective running beside the compute stream when
 // measuring how the GEMM behaves with fewer CUs than it was launched for (tools/contention_bench.py).
@@ -141,3 +199,4 @@ extern "C" int hvlm_debug_occupy(int workgroups, long cycles, void* stream) {
   hipLaunchKernelGGL(hvlm::occupy_kernel, dim3(workgroups), dim3(256), 0, hvlm::as_stream(stream), cycles, (unsigned*)nullptr);
   return hvlm::check_launch("debug_occupy");
 }
+#endif  // HVLM_DEV

@@ -36,11 +36,14 @@ def _ctype_of(decl: str):
     return _CTYPES[base]
 
 
-def parse_header(path: Path = HEADER_PATH):
-    """Returns {name: (restype, [argtypes])} for every `hvlm_*` prototype in the header."""
+def parse_header(path: Path = HEADER_PATH, dev: bool = False):
+    """Returns {name: (restype, [argtypes])} for every `hvlm_*` prototype in the header; the `#ifdef HVLM_DEV` blocks
+    (entry points that exist in `make DEV=1` builds only) are included with dev=True."""
     text = path.read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
+    if not dev:
+        text = re.sub(r"^\s*#ifdef HVLM_DEV\b.*?^\s*#endif[^\n]*$", "", text, flags=re.S | re.M)
     text = re.sub(r"^\s*#[^\n]*$", "", text, flags=re.M)          # preprocessor lines
     text = text.replace('extern "C" {', "")
     protos = {}
@@ -90,7 +93,8 @@ def load(path: os.PathLike | None = None) -> ctypes.CDLL:
     except ImportError:
         pass
     lib = ctypes.CDLL(str(p))
-    protos = parse_header()
+    lib.hvlm_is_dev_build.restype = ctypes.c_int
+    protos = parse_header(dev=bool(lib.hvlm_is_dev_build()))
     for name, (restype, argtypes) in protos.items():
         try:
             fn = getattr(lib, name)

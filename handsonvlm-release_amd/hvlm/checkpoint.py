@@ -117,23 +117,47 @@ def infer_vision_config(sd: Dict[str, torch.Tensor], prefix: str = "model.vision
                             image_size=int(round((npos - 1) ** 0.5)) * patch)
 
 
-def from_pretrained(path: str, device="cuda:0", training: bool = False, mm_projector_bin: Optional[str] = None, **cfg_overrides):
-    """load_pretrained_model (handsonvlm/model/builder.py:18) for the HIP model."""
+def from_pretrained(path: str, device="cuda:0", training: bool = False, mm_projector_bin: Optional[str] = None,
+                    vision_tower_path: Optional[str] = None, **cfg_overrides):
+    """load_pretrained_model (handsonvlm/model/builder.py:18) for the HIP model — and the training entry's
+    `from_pretrained(model_name_or_path)` + `initialize_vision_modules` + `initialize_constants`
+    (handsonvlm/train/train.py:235-240, llava/model/llava_arch.py:41-69, handsonvlm/model/handsonvlm_arch.py:17-45):
+      path               a HandsOnVLM checkpoint, or a base LLM (Vicuna: 32000-row embeddings, no projector / tower / head
+                         tensors) — the vocabulary is then extended to 32101 rows (100 time tokens + <hand_traj>)
+      mm_projector_bin   the LLaVA adapter file (`--pretrain_mm_mlp_adapter`), overrides / provides the projector
+      vision_tower_path  a local CLIPVisionModel checkpoint directory (`--vision_tower`; the reference names a hub model,
+                         there is no network here) for checkpoints that do not carry the tower's tensors"""
+    from .config import HAND_TOKEN_ID
     from .model import HandsOnVLMForCausalLM
     cfg = config_from_json(path)
     for k, v in cfg_overrides.items():
         setattr(cfg, k, v)
+    cfg.vocab_size = max(cfg.vocab_size, HAND_TOKEN_ID + 1)
     sd = load_state(path)
+    vt = "model.vision_tower.vision_tower."
+    if vision_tower_path is not None and not any(k.startswith(vt) for k in sd):
+        if not os.path.isdir(vision_tower_path):
+            raise FileNotFoundError(f"--vision_tower {vision_tower_path!r} is not a local directory (hub names cannot be fetched here): "
+                                    "point it at a CLIPVisionModel checkpoint directory")
+        tower_sd = load_state(vision_tower_path)
+        sd.update({vt + k: v for k, v in tower_sd.items() if "vision_model" in k or k.startswith(("embeddings.", "encoder.", "pre_layrnorm", "post_layernorm"))})
     if "vision" not in cfg_overrides and "vision_config" not in json.load(open(os.path.join(path, "config.json"))):
         vis = infer_vision_config(sd)
         if vis is not None:
             cfg.vision = vis
+            cfg.mm_hidden_size = vis.hidden_size
     model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
     if mm_projector_bin is not None:                           # initialize_vision_modules(pretrain_mm_mlp_adapter=...)
         adapter = torch.load(mm_projector_bin, map_location="cpu", weights_only=True)
         for k, v in adapter.items():
             if "mm_projector" in k:
                 sd["model.mm_projector." + k.split("mm_projector.")[1]] = v
+    if "model.mm_projector.weight" not in sd:
+        raise FileNotFoundError(f"{path} holds no mm_projector tensors: pass the LLaVA adapter file (mm_projector_bin / "
+                                "--pretrain_mm_mlp_adapter, scripts/finetune.sh:12)")
+    if not any(k.startswith(vt) for k in sd):
+        raise FileNotFoundError(f"{path} holds no CLIP tower tensors: pass a local CLIPVisionModel directory (vision_tower_path / "
+                                "--vision_tower, scripts/finetune.sh:11)")
     model.load_state_dict(sd)
     model._extra_state = {k: v for k, v in sd.items() if k not in model.state_dict()
                           and not k.startswith("model.vision_tower.")}
@@ -144,6 +168,10 @@ def save_pretrained(model, path: str, max_shard_bytes: int = 10 * 2 ** 30):
     os.makedirs(path, exist_ok=True)
     sd = dict(model.state_dict())
     sd.update(getattr(model, "_extra_state", {}))
+    if model.tower.is_loaded:
+        # the reference saves the full model state dict, frozen tower included (handsonvlm/train/train.py:101-136): a checkpoint
+        # written here is as self-contained as one of its own
+        sd.update({"model.vision_tower.vision_tower." + k: v for k, v in model.tower.export_state_dict().items()})
     config_to_json(model.config, path)
     save_state(sd, path, max_shard_bytes)
 

@@ -92,7 +92,36 @@ class CLIPVisionTower:
         self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
         self._pf = None                      # LayerNorm-folded copies (_fold_prepare) too
         self.is_loaded = True
+        # tensors of the checkpoint the hot path never reads (the last encoder layer, post_layernorm, position_ids buffers): carried
+        # on the host so that export_state_dict() writes the tower back complete, like the reference's full-model state dict
+        used = ("embeddings.class_embedding", "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight",
+                "pre_layrnorm.weight", "pre_layrnorm.bias") + tuple(f"encoder.layers.{i}." for i in range(self.n_run))
+        self._carried = {k[len(prefix):]: v.detach().to("cpu").clone() for k, v in sd.items()
+                         if k.startswith(prefix) and not k[len(prefix):].startswith(used)}
+        self._key_prefix = prefix
         return self
+
+    def export_state_dict(self, prefix: Optional[str] = None) -> Dict[str, torch.Tensor]:
+        """CLIPVisionModel-named tensors of the loaded tower (in its dtype) + whatever load_state_dict carried through."""
+        assert self.is_loaded
+        prefix = getattr(self, "_key_prefix", "vision_model.") if prefix is None else prefix
+        cfg, p, d = self.cfg, self.p, self.cfg.hidden_size
+        P = cfg.patch_size
+        out = {"embeddings.class_embedding": p["cls"], "embeddings.position_embedding.weight": p["pos"],
+               "embeddings.patch_embedding.weight": p["patch_w"][:, : 3 * P * P].reshape(d, 3, P, P),
+               "pre_layrnorm.weight": p["pre_ln_w"], "pre_layrnorm.bias": p["pre_ln_b"]}
+        for i in range(self.n_run):
+            lp = f"encoder.layers.{i}."
+            for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[lp + f"self_attn.{n}.weight"] = p[f"{i}.qkv_w"][j * d:(j + 1) * d]
+                out[lp + f"self_attn.{n}.bias"] = p[f"{i}.qkv_b"][j * d:(j + 1) * d]
+            out[lp + "self_attn.out_proj.weight"], out[lp + "self_attn.out_proj.bias"] = p[f"{i}.o_w"], p[f"{i}.o_b"]
+            out[lp + "layer_norm1.weight"], out[lp + "layer_norm1.bias"] = p[f"{i}.ln1_w"], p[f"{i}.ln1_b"]
+            out[lp + "layer_norm2.weight"], out[lp + "layer_norm2.bias"] = p[f"{i}.ln2_w"], p[f"{i}.ln2_b"]
+            out[lp + "mlp.fc1.weight"], out[lp + "mlp.fc1.bias"] = p[f"{i}.fc1_w"], p[f"{i}.fc1_b"]
+            out[lp + "mlp.fc2.weight"], out[lp + "mlp.fc2.bias"] = p[f"{i}.fc2_w"], p[f"{i}.fc2_b"]
+        out.update(getattr(self, "_carried", {}))
+        return {prefix + k: v for k, v in out.items()}
 
     def init_random(self, seed: int = 0, std: float = 0.02):
         """Random-init weights of the right shapes directly on the device (benchmarks)."""
@@ -115,6 +144,7 @@ class CLIPVisionTower:
         self.p = p
         self._p8 = None                      # e4m3 copies (fp8_prepare) follow the weights
         self._pf = None
+        self._carried, self._key_prefix = {}, "vision_model."
         self.is_loaded = True
         return self
 

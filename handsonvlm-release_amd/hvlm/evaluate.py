@@ -88,3 +88,62 @@ def evaluate_traj(model, samples: Iterable[Dict], reference_labels: bool = True,
         return dict(ade=float("nan"), fde=float("nan"), wde=float("nan"), n=int(len(gts)))
     a, f, w = evaluate_traj_stochastic(preds, gts, valids, reference_labels=reference_labels)
     return dict(ade=float(a), fde=float(f), wde=float(w), n=int(len(gts)))
+
+
+def main(argv=None, samples=None):
+    """`python -m hvlm.evaluate --model-path <ckpt> [--batch-size N]` — the entry point of handsonvlm/evaluation/evaluate.py:18-26
+    (`--model-path`, `--conv-mode`, `--load-8bit/4bit`, `--use_reason`, `--mode` accepted).  Loads the checkpoint through
+    hvlm.checkpoint.from_pretrained (handsonvlm/model/builder.py:18) and prints the metric dict the reference's
+    evaluate_epic_kitchen_traj reports.  Dataset readers are out of scope: the evaluation samples come from
+    `--samples-pt` (a torch-saved list of dicts with input_ids [1,T], image [1,100,3,H,W], future_hands [1,2,5,2],
+    future_valid [1,2] — what the reference's EpicConversationDataset + collator hand to `inference()`), from `samples`, or
+    are synthetic (`--synthetic N`)."""
+    import argparse
+    import json
+    from . import checkpoint, dp
+    ap = argparse.ArgumentParser(description="HandsOnVLM trajectory evaluation on MI355X", allow_abbrev=False)
+    ap.add_argument("--model-path", required=True)
+    ap.add_argument("--conv-mode", default=None)
+    ap.add_argument("--load-8bit", action="store_true")
+    ap.add_argument("--load-4bit", action="store_true")
+    ap.add_argument("--use_reason", action="store_true")
+    ap.add_argument("--mode", default="general")
+    ap.add_argument("--batch-size", type=int, default=1, help="1 = the reference's recipe; > 1 generates that many samples in lock step")
+    ap.add_argument("--samples-pt", default=None)
+    ap.add_argument("--synthetic", type=int, default=None, metavar="N")
+    ap.add_argument("--temperature", type=float, default=0.5)
+    ap.add_argument("--top-p", type=float, default=0.9)
+    ap.add_argument("--max-new-tokens", type=int, default=100)
+    ap.add_argument("--fp8", action="store_true", help="e4m3 prefill + decode + CLIP GEMMs (BASELINE config 5; needs --batch-size > 1)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device", default="cuda")
+    a = ap.parse_args(argv)
+    assert not (a.load_8bit or a.load_4bit), "bitsandbytes quantised loading is not part of the hot path"
+    rank, local, world = dp.init_from_env()
+    device = torch.device("cuda", local) if a.device == "cuda" else torch.device(a.device)
+    model = checkpoint.from_pretrained(a.model_path, device=device, training=False)
+    model.eval()
+    if samples is None and a.samples_pt:
+        samples = torch.load(a.samples_pt, map_location="cpu", weights_only=False)
+    if samples is None:
+        from .data import SyntheticEpicDataset
+        ds = SyntheticEpicDataset(a.synthetic or 8, seed=a.seed, image_size=model.config.vision.image_size)
+        samples = []
+        for i in range(len(ds)):
+            s = ds[i]
+            n_prompt = int((s["labels"] == -100).sum())               # the prompt = the masked prefix of the conversation
+            samples.append(dict(input_ids=s["input_ids"][None, :max(n_prompt, 2)], image=s["image"][None],
+                                future_hands=s["future_hands"][None], future_valid=s["future_valid"][None]))
+    torch.manual_seed(a.seed + rank)
+    kw = dict(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.max_new_tokens)
+    if a.fp8:
+        assert a.batch_size > 1, "--fp8 runs through the batched generation path"
+        kw.update(fp8=True, fp8_decode=True, fp8_clip=True)
+    res = evaluate_traj(model, samples, batch_size=a.batch_size, **kw)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    main()

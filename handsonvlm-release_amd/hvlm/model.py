@@ -183,10 +183,20 @@ class HandsOnVLMForCausalLM:
         hand_traj_decoder.*.  Unused reference tensors (time_embedding, bbox_to_feature ...) are ignored."""
         dev = self.device
         V = self.config.vocab_size
-        self.embed.copy_(sd["model.embed_tokens.weight"].to(dev, BF16))
-        self.lm_head[:V].copy_(sd["lm_head.weight"].to(dev, BF16))
-        self.proj_w.copy_(sd["model.mm_projector.weight"].to(dev, BF16))
-        self.proj_b.copy_(sd["model.mm_projector.bias"].to(dev, BF16))
+        for name, dst in (("model.embed_tokens.weight", self.embed), ("lm_head.weight", self.lm_head)):
+            src = sd[name]
+            n = src.shape[0]
+            assert n <= V, f"{name}: {n} rows, config.vocab_size is {V}"
+            dst[:n].copy_(src.to(dev, BF16))
+            if n < V:
+                # a base LLM (Vicuna: 32000 rows) before the reference's initialize_constants added the 100 time tokens and
+                # <hand_traj> (handsonvlm/model/handsonvlm_arch.py:17-31: tokenizer.add_tokens + resize_token_embeddings): the new
+                # rows get HF's initializer, N(0, initializer_range = 0.02), here from a fixed seed
+                g = torch.Generator().manual_seed(32100 + (0 if dst is self.embed else 1))
+                dst[n:V].copy_((torch.randn(V - n, dst.shape[1], generator=g) * 0.02).to(dev, BF16))
+        if "model.mm_projector.weight" in sd:                # (absent in a base LLM: the projector comes from the LLaVA adapter file)
+            self.proj_w.copy_(sd["model.mm_projector.weight"].to(dev, BF16))
+            self.proj_b.copy_(sd["model.mm_projector.bias"].to(dev, BF16))
         self.stack.load_hf(sd, "model.")
         head = {k[len("hand_traj_decoder."):]: v for k, v in sd.items() if k.startswith("hand_traj_decoder.")}
         if head:

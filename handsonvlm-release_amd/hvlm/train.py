@@ -5,6 +5,10 @@ on one process per GPU with RCCL gradient all-reduce (hvlm.dp), no
 DeepSpeed / ZeRO / HF Trainer.
 
     python -m torch.distributed.run --nproc-per-node 8 -m hvlm.train --model 7b --output_dir ckpt --steps 100
+    python -m torch.distributed.run --nproc-per-node 8 -m hvlm.train --model_name_or_path ./checkpoints/vicuna-v1-3-7b \
+        --pretrain_mm_mlp_adapter ./checkpoints/llava-vicuna-v1-3-7b-pretrain/mm_projector.bin --vision_tower ./checkpoints/clip-vit-large-patch14 \
+        --bf16 True --output_dir ./checkpoints/HandsOnVLM-CVAE-7B --num_train_epochs 40 --per_device_train_batch_size 16 --learning_rate 2e-5 \
+        --weight_decay 0. --warmup_ratio 0.03 --lr_scheduler_type cosine --model_max_length 2048 ...      (scripts/finetune.sh:6-60)
 """
 from __future__ import annotations
 
@@ -122,28 +126,93 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
     return log
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+# scripts/finetune.sh flags that steer subsystems outside the hot path (DeepSpeed, the HF Trainer's logging / eval plumbing, the
+# multi-task dataset mixer): accepted so that the script's command line runs unchanged, listed once, otherwise ignored
+_IGNORED_NOTE = "accepted for command-line compatibility with scripts/finetune.sh and ignored (outside the hot path)"
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description="HandsOnVLM SFT on MI355X (the hot path of scripts/finetune.sh)", allow_abbrev=False)
+    b = lambda v: str(v).lower() in ("1", "true", "yes")  # noqa: E731   (HfArgumentParser-style booleans: `--bf16 True`)
+    ap.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"], help="random-init geometry when no --model_name_or_path is given")
+    ap.add_argument("--model_name_or_path", default=None, help="HandsOnVLM checkpoint or base Vicuna directory (scripts/finetune.sh:8)")
+    ap.add_argument("--pretrain_mm_mlp_adapter", default=None, help="LLaVA mm_projector.bin (scripts/finetune.sh:12)")
+    ap.add_argument("--vision_tower", default=None, help="LOCAL CLIPVisionModel directory (the reference passes a hub name, :11)")
     ap.add_argument("--output_dir", default=None)
     ap.add_argument("--per_device_train_batch_size", type=int, default=16)
     ap.add_argument("--num_train_epochs", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--steps", "--max_steps", dest="steps", type=int, default=None)
     ap.add_argument("--learning_rate", type=float, default=2e-5)
-    ap.add_argument("--samples", type=int, default=48296, help="samples per epoch (scripts/finetune.sh:19)")
-    a = ap.parse_args()
-    rank, local, world = dp.init_from_env()
+    ap.add_argument("--weight_decay", type=float, default=0.0)
+    ap.add_argument("--warmup_ratio", type=float, default=0.03)
+    ap.add_argument("--lr_scheduler_type", default="cosine")
+    ap.add_argument("--bf16", type=b, default=True)
+    ap.add_argument("--model_max_length", type=int, default=2048)
+    ap.add_argument("--gradient_checkpointing", type=b, default=False,
+                    help="activation recompute (config.activation_recompute).  The reference needs it on 80-GB parts (:36); 288 GB do "
+                         "not at 7B / per-device 16, so the default here is off — pass True to mirror the script")
+    ap.add_argument("--lambda_traj", type=float, default=None)
+    ap.add_argument("--lambda_traj_kl", type=float, default=None)
+    ap.add_argument("--hoi_lambda", type=float, default=None)
+    ap.add_argument("--traj_decoder", default="CVAE")
+    ap.add_argument("--fuse_input_mode", default="origin")
+    ap.add_argument("--video_arch", default="temporal_spatial_pool")
+    ap.add_argument("--mm_vision_select_layer", type=int, default=-2)
+    ap.add_argument("--samples_per_epoch", "--samples", dest="samples", type=int, default=48296, help="scripts/finetune.sh:56")
+    ap.add_argument("--save_strategy", default="epoch", help='"epoch" (scripts/finetune.sh:27) | "steps" (then --save_steps applies, as in HF)')
+    ap.add_argument("--save_steps", type=int, default=None)
+    ap.add_argument("--dataloader_num_workers", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--labelled_rows", type=b, default=False,
+                    help="lm_head / CE / the last layer's MLP on labelled rows only (exact; `out.logits` is then unavailable)")
+    ap.add_argument("--dedup_frames", type=b, default=True, help="CLIP once per distinct frame (EK100 tiles 10 frames x10; exact)")
+    ap.add_argument("--device", default="cuda", help="cuda (default) | cpu (host-logic tests with the ops stand-in)")
+    ap.add_argument("--stop_after", type=int, default=None, help=argparse.SUPPRESS)
+    return ap
+
+
+def build_model(a, device):
     from .model import HandsOnVLMForCausalLM
+    over = {}
+    for k in ("lambda_traj", "lambda_traj_kl", "hoi_lambda"):
+        if getattr(a, k) is not None:
+            over[k] = getattr(a, k)
+    over.update(traj_decoder_name=a.traj_decoder, fuse_input_mode=a.fuse_input_mode, video_compress_mode=a.video_arch,
+                mm_vision_select_layer=a.mm_vision_select_layer, max_position_embeddings=a.model_max_length,
+                dedup_frames=a.dedup_frames, lm_head_labelled_rows=a.labelled_rows, activation_recompute=a.gradient_checkpointing)
+    if a.model_name_or_path:
+        return checkpoint.from_pretrained(a.model_name_or_path, device=device, training=True, mm_projector_bin=a.pretrain_mm_mlp_adapter,
+                                          vision_tower_path=a.vision_tower, **over)
     if a.model == "tiny":
         cfg = HandsOnVLMConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, mm_hidden_size=64,
                                vision=CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=1))
     else:
         cfg = HandsOnVLMConfig.vicuna_7b() if a.model == "7b" else HandsOnVLMConfig.vicuna_13b()
-    cfg.dedup_frames = True
-    cfg.lm_head_labelled_rows = True      # the trainer reads the loss only: lm_head and the last layer's MLP on labelled rows (exact)
-    model = HandsOnVLMForCausalLM(cfg, device=torch.device("cuda", local), training=True).init_random(0)
-    train(model, SyntheticEpicDataset(a.samples), a.output_dir, a.per_device_train_batch_size, a.num_train_epochs, a.steps,
-          a.learning_rate)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return HandsOnVLMForCausalLM(cfg, device=device, training=True).init_random(0)
+
+
+def main(argv=None, dataset=None):
+    """`python -m hvlm.train <the flags of scripts/finetune.sh>`: loads `--model_name_or_path` (+ `--pretrain_mm_mlp_adapter`,
+    `--vision_tower`) through hvlm.checkpoint like handsonvlm/train/train.py:235-240, or a random-init model of `--model`
+    geometry when no path is given, and runs the DP loop above.  Dataset readers are out of scope: `dataset`
+    (any torch Dataset yielding the collator's per-sample dicts, handsonvlm/dataset/hybrid_dataset.py:108-169) is passed by the
+    caller; the command line alone trains on SyntheticEpicDataset."""
+    a, unknown = build_parser().parse_known_args(argv)
+    rank, local, world = dp.init_from_env()
+    if rank == 0 and unknown:
+        names = sorted({u for u in unknown if u.startswith("--")})
+        print(f"hvlm.train: {len(names)} flags {_IGNORED_NOTE}: {' '.join(names)}", flush=True)
+    assert a.bf16, "the hot path computes in bf16 (scripts/finetune.sh:15); fp32 / fp16 training is not built"
+    assert a.lr_scheduler_type == "cosine", "only the cosine schedule of scripts/finetune.sh:33 is built"
+    device = torch.device("cuda", local) if a.device == "cuda" else torch.device(a.device)
+    model = build_model(a, device)
+    ds = dataset if dataset is not None else SyntheticEpicDataset(a.samples, seed=a.seed, image_size=model.config.vision.image_size)
+    return train(model, ds, a.output_dir, a.per_device_train_batch_size, a.num_train_epochs, a.steps, a.learning_rate,
+                 warmup_ratio=a.warmup_ratio, weight_decay=a.weight_decay, save_steps=a.save_steps if a.save_strategy == "steps" else None,
+                 save_every_epoch=a.save_strategy != "no", seed=a.seed,
+                 num_workers=a.dataloader_num_workers, stop_after=a.stop_after, log_every=1 if (a.steps or 0) and a.steps <= 10 else 10)
 
 
 if __name__ == "__main__":

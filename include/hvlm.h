@@ -42,9 +42,28 @@ int hvlm_abi_version(void);
 const char* hvlm_last_error(void);
 /* Fills CU count, LDS bytes per workgroup and the gcnArchName of `device`. */
 int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int arch_len);
-/* Diagnostic: keeps `workgroups` CUs busy (64 KiB LDS each) for about `cycles` shader clocks on `stream` — a stand-in
- * for a collective running beside the compute stream (tools/contention_bench.py). */
+#ifdef HVLM_DEV
+/* Development builds only (`make DEV=1`): keeps `workgroups` CUs busy (64 KiB LDS each) for about `cycles` shader clocks on
+ * `stream` — a stand-in for a collective running beside the compute stream (tools/contention_bench.py). */
 int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
+#endif
+
+/* Per-device handle — the ONLY mutable state the library keeps between calls: which block of device memory
+ * holds the scheduler state of the persistent GEMM kernels (per-XCD tile counters + per-workgroup hand-over slots of the
+ * dynamic tile scheduling, one slot per launching stream; hvlm_gemm_sched_ws_bytes() = 75 KiB).
+ *   hvlm_create(device, sched_ws, bytes, stream, &h)  `device` must be the calling thread's current HIP device.  sched_ws: a
+ *       caller-owned block of >= hvlm_gemm_sched_ws_bytes() bytes, 256-byte aligned, zero-filled by this call on `stream` and
+ *       kept alive by the caller until hvlm_destroy; or NULL (bytes 0) for the library's built-in block (a HIP module global,
+ *       one copy per device).  One handle per device: a second hvlm_create for a device that has one fails (HVLM_ERR_INVALID).
+ *   hvlm_destroy(h)   the device goes back to the built-in block; the caller's block is no longer touched by later launches.
+ * Every entry point that launches the persistent GEMM (hvlm_gemm_*_nt*, the lock-step decode GEMMs excepted) reads the handle
+ * of the CURRENT device at launch; without a handle it uses the built-in block.  Kernels of different streams use different
+ * slots of the block, so launches may overlap across streams.  Not thread-safe against launches in flight on that device. */
+typedef struct hvlm_handle hvlm_handle;
+int hvlm_create(int device, void* sched_ws, size_t sched_ws_bytes, void* stream, hvlm_handle** out);
+int hvlm_destroy(hvlm_handle* handle);
+int hvlm_handle_device(const hvlm_handle* handle);
+size_t hvlm_gemm_sched_ws_bytes(void);
 
 /* Library switches.  Every A/B switch of the library is one named integer: initialised ONCE, at the library's first use, from
  * the environment variable HVLM_<KEY IN CAPITALS>, changed at run time through hvlm_configure; no entry point reads the
@@ -73,15 +92,6 @@ int hvlm_is_dev_build(void);
 int hvlm_gemm_bf16_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda,
                       int ldb, int ldc, const void* bias, const void* residual, int ldr, int act,
                       int out_f32, void* stream);
-
-/* Scheduler state of the persistent GEMM kernels (per-XCD tile counters + per-workgroup hand-over slots of the dynamic tile
- * scheduling, one block per launching stream; 75 KiB).  By default it lives in the library's own device-side storage (one
- * copy per device, as HIP module globals are).  A host that wants every byte the kernels write to be its own allocation
- * installs a block for the CURRENT device: `ws` of hvlm_gemm_sched_ws_bytes() bytes, 256-byte aligned, zero-filled by the
- * call on `stream` and owned by the caller for as long as GEMMs are launched on that device (NULL restores the default).
- * Kernels of different streams use different slots of the block, so launches may overlap across streams as before. */
-size_t hvlm_gemm_sched_ws_bytes(void);
-int hvlm_gemm_set_sched_ws(void* ws, size_t bytes, void* stream);
 
 /* Split-K variant for skinny problems (few 256x256 output tiles, e.g. the batch-1 prefill, M = 867): `splits` K-slices
  * are computed by separate workgroups into fp32 slabs of `ws` (hvlm_gemm_splitk_ws_bytes) and summed, deterministically,

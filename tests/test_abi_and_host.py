@@ -241,7 +241,19 @@ def test_configure_switches_without_a_device(lib):
             lib.configure(key, lib.config_get(key))                               # the default value is always accepted
         syms = subprocess.run(["nm", str(lib.LIB_PATH)], capture_output=True, text=True).stdout
         assert "dbg" not in syms and "gemm_pp_kernel" not in syms and "attn_bwd_dkv_kernel" not in syms
-    assert l.hvlm_gemm_sched_ws_bytes() % 256 == 0 and l.hvlm_gemm_sched_ws_bytes() > 0      # (the setter itself needs a device)
+        assert "debug" not in syms and "occupy" not in syms                       # no diagnostic entry point in the production ABI
+        assert "hvlm_debug_occupy" not in lib.parse_header() and "hvlm_debug_occupy" in lib.parse_header(dev=True)
+    assert l.hvlm_gemm_sched_ws_bytes() % 256 == 0 and l.hvlm_gemm_sched_ws_bytes() > 0
+    # the per-device handle: declared, exported; without a device hvlm_create fails cleanly, never crashes
+    import ctypes
+    assert {"hvlm_create", "hvlm_destroy", "hvlm_handle_device"} <= set(lib.parse_header())
+    assert "hvlm_gemm_set_sched_ws" not in lib.parse_header()                       # superseded by the handle
+    h = ctypes.c_void_p()
+    assert l.hvlm_create(0, None, 0, None, None) == -1 and b"out is NULL" in l.hvlm_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        assert l.hvlm_create(0, None, 0, None, ctypes.byref(h)) < 0 and not h.value
+    assert l.hvlm_destroy(None) == -1 and l.hvlm_handle_device(None) == -1
     # no entry point reads the environment: the only getenv of the library is the one-time initialisation in runtime.hip
     import glob
     import os

@@ -81,11 +81,11 @@ def test_reference_checkpoint_ingestion(tmp_path, monkeypatch):
     checkpoint.save_pretrained(m, str(tmp_path / "resaved"))
     back = checkpoint.load_state(str(tmp_path / "resaved"))
     orig = checkpoint.load_state(d)
-    for k in names:
-        if k.startswith("model.vision_tower."):
-            continue                                      # the frozen tower is not re-saved (loaded from its own checkpoint)
+    for k in names:                                       # (the frozen tower is re-saved too, complete, in its fp16 dtype)
         assert k in back, k
         assert torch.equal(back[k].float(), orig[k].to(back[k].dtype).float()), k
+    m2 = checkpoint.from_pretrained(str(tmp_path / "resaved"), device="cpu", training=False)     # self-contained: loads and reproduces
+    check_loaded_model(m2, exp, "cpu")
 
 
 def test_safetensors_variant_and_adapter_override(tmp_path, monkeypatch):

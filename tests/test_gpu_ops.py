@@ -490,9 +490,16 @@ def test_gemm_dynamic_scheduling_under_contention(ops):
     quiet = ops.gemm_nt(a, b, bias=bias)
     side = torch.cuda.Stream()
     lib = _lib.load()
+    dev_build = bool(lib.hvlm_is_dev_build())
+    hog = torch.zeros(64 << 20, device="cuda")
     for occ in (8, 40, 120):
         torch.cuda.synchronize()
-        _lib.check(lib.hvlm_debug_occupy(occ, 4_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
+        if dev_build:                           # the diagnostic occupier exists in development builds only
+            _lib.check(lib.hvlm_debug_occupy(occ, 4_000_000, ctypes.c_void_p(side.cuda_stream)), "occupy")
+        else:                                   # production build: a contender made of plain elementwise kernels on the side stream
+            with torch.cuda.stream(side):
+                for _ in range(occ // 4):
+                    hog.mul_(1.0001).add_(1e-3)
         torch.cuda._sleep(100_000)
         busy = ops.gemm_nt(a, b, bias=bias)
         torch.cuda.synchronize()
@@ -573,10 +580,11 @@ def test_gemm_half_tile_tail_units_bit_identical(ops, M, N, K, dt, epi):
         assert rel(halves, ref.to(tdt)) <= 1.5e-3
 
 
-def test_gemm_scheduler_state_in_caller_memory(ops):
-    """hvlm_gemm_set_sched_ws: the dynamic tile scheduler's counters / hand-over slots live in a caller-provided block instead
-    of the library's own device storage — same tiles, same arithmetic: the result is bit-identical, on two streams at once, and
-    the block is left at rest (all counters zero) after every launch."""
+def test_handle_puts_gemm_scheduler_state_in_caller_memory(ops):
+    """hvlm_create(device, sched_ws, ...): the per-device handle (the library's only mutable state) moves the
+    dynamic tile scheduler's counters / hand-over slots into a caller-provided block instead of the library's own device
+    storage — same tiles, same arithmetic: the result is bit-identical, on two streams at once, and the block is left at rest
+    (all counters zero) after every launch.  One handle per device; hvlm_destroy restores the built-in block."""
     import ctypes
     from hvlm import _lib
     lib = _lib.load()
@@ -588,10 +596,17 @@ def test_gemm_scheduler_state_in_caller_memory(ops):
     ws = torch.full((nbytes + 256,), 0xAB, dtype=torch.uint8, device="cuda")
     off = (-ws.data_ptr()) % 256
     blk = ws[off:off + nbytes]
-    rc = lib.hvlm_gemm_set_sched_ws(ctypes.c_void_p(blk.data_ptr() + 8), nbytes, ops._stream())
-    assert rc == -1 and b"256-byte aligned" in lib.hvlm_last_error()
-    _lib.check(lib.hvlm_gemm_set_sched_ws(ctypes.c_void_p(blk.data_ptr()), nbytes, ops._stream()), "set_sched_ws")
+    dev = torch.cuda.current_device()
+    h = ctypes.c_void_p()
+    rc = lib.hvlm_create(dev, ctypes.c_void_p(blk.data_ptr() + 8), nbytes, ops._stream(), ctypes.byref(h))
+    assert rc == -1 and b"256-byte aligned" in lib.hvlm_last_error() and not h.value
+    rc = lib.hvlm_create(dev + 7, ctypes.c_void_p(blk.data_ptr()), nbytes, ops._stream(), ctypes.byref(h))
+    assert rc == -1 and b"current device" in lib.hvlm_last_error()
+    _lib.check(lib.hvlm_create(dev, ctypes.c_void_p(blk.data_ptr()), nbytes, ops._stream(), ctypes.byref(h)), "create")
+    assert h.value and lib.hvlm_handle_device(h) == dev
     try:
+        h2 = ctypes.c_void_p()
+        assert lib.hvlm_create(dev, None, 0, ops._stream(), ctypes.byref(h2)) == -1 and b"already has a handle" in lib.hvlm_last_error()
         mine = ops.gemm_nt(a, b)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -605,5 +620,13 @@ def test_gemm_scheduler_state_in_caller_memory(ops):
         for s in range(8):                                      # every stream slot: tile counters and completion count at rest
             assert int(words[s * per: s * per + 8 * 32 + 32].abs().sum()) == 0
     finally:
-        _lib.check(lib.hvlm_gemm_set_sched_ws(None, 0, ops._stream()), "reset sched_ws")
+        torch.cuda.synchronize()
+        _lib.check(lib.hvlm_destroy(h), "destroy")
+    blk.fill_(0xAB)                                             # the block is the caller's again: later launches do not touch it
     assert torch.equal(ops.gemm_nt(a, b), base)
+    torch.cuda.synchronize()
+    assert int((blk != 0xAB).sum()) == 0
+    # a handle WITHOUT a block (the built-in state), then destroyed: create/destroy cycle is clean
+    _lib.check(lib.hvlm_create(dev, None, 0, ops._stream(), ctypes.byref(h)), "create (built-in block)")
+    assert torch.equal(ops.gemm_nt(a, b), base)
+    _lib.check(lib.hvlm_destroy(h), "destroy")

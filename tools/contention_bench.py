@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How the persistent GEMM behaves when a few CUs are taken by another stream (an RCCL all-reduce in data-parallel
-training): time of one GEMM alone vs beside `hvlm_debug_occupy` holding N CUs for the whole duration (GPU box)."""
+training): time of one GEMM alone vs beside `hvlm_debug_occupy` holding N CUs for the whole duration (GPU box; the occupier
+exists in development builds only: run with HVLM_LIB=handsonvlm-release_amd/lib/libhvlm_hip_dev.so)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "handsonvlm-release_amd"))
