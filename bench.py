@@ -786,10 +786,19 @@ def main():
     dt = time.perf_counter() - t0
     ev.enabled = False
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    rank_skew = None
     if torch.distributed.is_initialized():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+        # straggler skew: every rank's mean / min / max GPU time per step (its own compute stream), gathered on all ranks
+        mine = torch.tensor([float(np.mean(step_ms)), float(np.min(step_ms)), float(np.max(step_ms))], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [[round(float(v), 2) for v in t.tolist()] for t in allr]
+        means = [p[0] for p in per_rank]
+        rank_skew = {"per_rank_step_ms_mean_min_max": per_rank, "slowest_rank": int(np.argmax(means)), "fastest_rank": int(np.argmin(means)),
+                     "mean_step_ms_spread": round(max(means) - min(means), 2)}
     loss = float(out.loss.detach())
     gs = ev.summary()
     # north_star's "HBM GB/s against peak": the HBM-bound kernels of the step, event-timed in situ during one more (untimed) step
@@ -902,7 +911,12 @@ def main():
                            "exposed_ms_definition": "HIP-event time on the compute stream from the last backward kernel (tail hook) to the end of "
                                                     "the step (last all-reduce complete + last AdamW update joined); `step_tail_ms` of the N = 1 "
                                                     "line is the same interval without communication",
-                           "ring_bytes_per_gpu": 2.0 * (buckets.world - 1) / max(1, buckets.world) * buckets.bytes}
+                           "ring_bytes_per_gpu": 2.0 * (buckets.world - 1) / max(1, buckets.world) * buckets.bytes,
+                           "rank_skew": rank_skew,
+                           "library": {"nccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None),
+                                       "hip": getattr(torch.version, "hip", None),
+                                       "env": {k: v for k, v in sorted(os.environ.items())
+                                               if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HVLM_DP", "HVLM_DIST", "HVLM_FORCE_DIST", "HVLM_SHARE"))}}}
         if args.layers is not None:
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)
