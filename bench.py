@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--image-size", type=int, default=224,
                     help="frame size: 224 = the only geometry the reference accepts (default); 336 = the build's generalisation "
                          "(24x24 patches, 676 visual tokens, S = T + 675)")
+    ap.add_argument("--no-pool-fc2", action="store_true",
+                    help="the last CLIP layer's fc2 + residual on every token like the reference (default: on the pooled rows — "
+                         "config.pool_before_last_fc2, exact up to the rounding order, tagged `_poolfc2`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-events", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="also write gpurun_out/gemm_by_shape.json (rank 0)")
@@ -97,6 +100,7 @@ def make_config(args):
     if args.clip_chunk:
         cfg.clip_chunk_frames = args.clip_chunk
     cfg.vision_dtype = args.clip_dtype
+    cfg.pool_before_last_fc2 = not args.no_pool_fc2
     cfg.activation_recompute = True if args.recompute < 0 else args.recompute
     cfg.pack_sequences = args.pack
     cfg.vision.image_size = args.image_size
@@ -840,6 +844,10 @@ def main():
         else:       # algorithmic work = the real tokens of every sample (padding rows are not work)
             flops_llm = 3.0 * sum(model.stack.flops_forward(1, int(n) + nv1, cfg.vocab_size) for n in lens)
         flops_clip = n_frames * model.tower.flops_per_frame()
+        # the last tower layer's fc2 on the pooled rows only (config.pool_before_last_fc2): the rows it skips are NOT counted as work
+        pool_fc2 = (cfg.pool_before_last_fc2 and cfg.project_after_pool and not args.dedup and args.clip_dtype == "fp16")
+        if pool_fc2:
+            flops_clip -= B * (cfg.num_frames * (nv1 + 2 - cfg.num_frames) - (nv1 + 1)) * 2.0 * cfg.vision.hidden_size * cfg.vision.intermediate_size
         # lm_head on labelled rows only: the rows it does not run on are NOT counted as work (forward + dX + dW = 3 x 2 D V per row)
         rows_all = B * S if lens is None else int(sum(int(n) + nv1 for n in lens))
         lab = batch["labels"]
@@ -863,6 +871,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"sft_step_{args.model}_b{B}_T{T if lens is None else 'U' + args.varlen.replace(':', '-')}_S{S}_{cfg.num_frames}x{cfg.vision.image_size}px"
                                    + ("_dedupclip" if args.dedup else "_refequiv") + ("_poolproj" if cfg.project_after_pool else "")
+                                   + ("_poolfc2" if pool_fc2 else "")
                                    + ("_lblrows" if cfg.lm_head_labelled_rows else "")
                                    + ("_packed" if args.pack else "")
                                    + ("_recompute" if args.recompute else ""),
@@ -872,6 +881,10 @@ def main():
                        "projector_note": ("mm_projector applied AFTER the temporal/spatial pooling (Linear commutes with the means: 356 rows per "
                                           "sample instead of the reference's 25 600; its skipped FLOPs are not counted as work)"
                                           if cfg.project_after_pool else "mm_projector on all patch tokens, as the reference"),
+                       "clip_last_fc2_rows_per_sample": (nv1 + 1) if pool_fc2 else cfg.num_frames * (nv1 + 2 - cfg.num_frames),
+                       "clip_last_fc2_note": ("the LAST CLIP layer's fc2 + residual run AFTER the temporal/spatial pooling (affine per-token maps "
+                                              "commute with the means): 356 rows per sample instead of 25 700, 1/23 of the tower's fc2 work; its "
+                                              "skipped FLOPs are not counted as work" if pool_fc2 else "every CLIP layer on every token, as the reference"),
                        "lm_head_rows_per_step": rows_lbl, "rows_per_step": rows_all,
                        "lm_head_note": ("lm_head, the cross-entropy, the LAST decoder layer's o_proj + MLP and their backward run on the rows "
                                         "that carry a target (the synthetic batch masks the first 40 % of the text like a prompt; visual-token "

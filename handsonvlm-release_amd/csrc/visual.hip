@@ -64,9 +64,13 @@ __device__ __forceinline__ int sel_frame(int k, int T) {
 // 24 at 336 px), G2 = G*G, H = G/2, P2 = H*H pooled cells per selected frame.
 //   out row r < T     : mean over the G2 patches of frame r
 //   out row r >= T    : j = r-T; frame sel(j/P2); (oy,ox) = ((j%P2)/H, j%H); mean of the 2x2 patches
+// F16: the tokens / the output are IEEE half (the CLIP tower's own dtype: pooling INSIDE the tower's last layer, see
+// hvlm/clip.py::_last_layer_pooled) instead of bfloat16; accumulation is fp32 either way.
+template <bool F16>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ tok,
                                                        bf16_t* __restrict__ out, int B, int T, int D, int G,
                                                        int skip /*1 if cls is dropped*/) {
+  using EL = E16<F16>;
   const int dv = D / 8;
   const int G2 = G * G, H = G / 2, P2 = H * H;
   const int tpf = G2 + skip;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
       for (int p = 0; p < G2; ++p) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += EL::lo(v[e]); acc[2 * e + 1] += EL::hi(v[e]); }
       }
       scale = 1.f / (float)G2;
     } else {
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
           const int p = (2 * oy + dy) * G + 2 * ox + dx;
           const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+          for (int e = 0; e < 4; ++e) { acc[2 * e] += EL::lo(v[e]); acc[2 * e + 1] += EL::hi(v[e]); }
         }
       scale = 0.25f;
     }
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
+    for (int e = 0; e < 4; ++e) o[e] = EL::pack2(acc[2 * e] * scale, acc[2 * e + 1] * scale);
     *reinterpret_cast<u32x4*>(out + rr * (long)D + c) = o;
   }
 }
@@ -299,9 +303,19 @@ extern "C" int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int
   HVLM_REQUIRE(tokens && out && B > 0 && T >= 1 && D % 8 == 0, "pool_fwd: bad args");
   HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_fwd: grid=%d must be even (16 = reference geometry)", grid);
   const long total = (long)B * (T + grid * grid) * (D / 8);
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(pool_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                      (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0);
   return check_launch("temporal_spatial_pool_fwd");
+}
+
+extern "C" int hvlm_temporal_spatial_pool_fwd_f16(const void* tokens, void* out, int B, int T, int D,
+                                                  int drop_cls, int grid, void* stream) {
+  HVLM_REQUIRE(tokens && out && B > 0 && T >= 1 && D % 8 == 0, "pool_fwd_f16: bad args");
+  HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_fwd_f16: grid=%d must be even (16 = reference geometry)", grid);
+  const long total = (long)B * (T + grid * grid) * (D / 8);
+  hipLaunchKernelGGL(pool_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0);
+  return check_launch("temporal_spatial_pool_fwd_f16");
 }
 
 extern "C" int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D,

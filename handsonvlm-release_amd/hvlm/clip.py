@@ -211,13 +211,18 @@ class CLIPVisionTower:
 
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, fp8: bool = False) -> torch.Tensor:
+    def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, fp8: bool = False,
+                       pool: Optional[tuple] = None) -> torch.Tensor:
         """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d] (bf16).  `out`: an
         optional [N, NP+1, d] bf16 destination (a slice of the caller's buffer: no concatenation of chunks afterwards).
+        `pool` = (B, T): the N = B*T frames are B whole samples and the caller only wants the temporal/spatial POOLING of the
+        patch tokens (VisualToTokenHelper.compress_tokens, CLS dropped): returns [B, T + G*G, d] bf16 instead, with the last
+        layer's fc2 + residual applied AFTER the pooling (fp16 tower only; see _last_layer_pooled).
         `fp8`: the q|k|v / out_proj / fc1 / fc2 GEMMs of every layer on e4m3 operands (CDNA4 scaled MFMA, fp32 accumulation,
         per-token activation and per-channel weight scales); LayerNorm, attention, the residual stream, biases and QuickGELU
         stay bf16, the patch embedding stays a bf16 GEMM (K = 588)."""
         if fp8:
+            assert pool is None
             return self._forward_tokens_fp8(images, out)
         cfg, p = self.cfg, self.p
         assert self.is_loaded
@@ -241,8 +246,9 @@ class CLIPVisionTower:
         del pe
         x = ln(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
         scale = dh ** -0.5
+        assert pool is None or (f16 and pool[0] * pool[1] == N and self.n_run >= 1), "pool=(B, T): fp16 tower, whole samples"
         if f16 and _FOLD_LN and d % 256 == 0 and cfg.intermediate_size % 256 == 0:
-            return self._forward_layers_folded(x, N, T, out)
+            return self._forward_layers_folded(x, N, T, out, pool)
         for i in range(self.n_run):
             y = ln(x, p[f"{i}.ln1_w"], p[f"{i}.ln1_b"], cfg.layer_norm_eps)
             qkv = mm(y, p[f"{i}.qkv_w"], bias=p[f"{i}.qkv_b"])
@@ -254,6 +260,8 @@ class CLIPVisionTower:
             x = mm(a, p[f"{i}.o_w"], bias=p[f"{i}.o_b"], residual=x)
             y = ln(x, p[f"{i}.ln2_w"], p[f"{i}.ln2_b"], cfg.layer_norm_eps, out=y)
             hmid = mm(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
+            if pool is not None and i == self.n_run - 1:
+                return self._last_layer_pooled(i, x, hmid, N, T, pool)
             x = mm(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x)
             del hmid
         if f16:
@@ -263,7 +271,35 @@ class CLIPVisionTower:
             x = out
         return x.view(N, T, d)
 
-    def _forward_layers_folded(self, x: torch.Tensor, N: int, T: int, out: Optional[torch.Tensor]) -> torch.Tensor:
+    def _last_layer_pooled(self, i: int, x: torch.Tensor, hmid: torch.Tensor, N: int, T: int, pool: tuple) -> torch.Tensor:
+        """The tail of the LAST layer that is run, for a caller that only pools its output (config.pool_before_last_fc2):
+            pool(x + fc2(h) + b) = pool(x) + fc2(pool(h)) + b
+        — the temporal means over a frame's patches and the 2x2 spatial means are linear, fc2 and the residual add are affine and
+        act per token — so the residual stream x [N*T, d] and the QuickGELU output h [N*T, 4d] are pooled first (fp32 sums of the
+        fp16 values, ONE rounding to fp16) and fc2 runs on B * (frames + G*G) rows instead of N * T.  x = the stream after the
+        attention block (the o_proj GEMM's output), hmid = QuickGELU(fc1(LN2(x)))."""
+        p, cfg = self.p, self.cfg
+        B, F = pool
+        G = cfg.image_size // cfg.patch_size
+        d = cfg.hidden_size
+        NV = F + G * G
+        # Persistent small buffers (83 MB at 16 samples): allocated from the caching allocator while the multi-GB x / hmid blocks are
+        # alive, fresh tensors of these sizes were carved out of a big free block every step — one more hipMalloc (30-90 ms) in the
+        # first timed step of a default bench run until the allocator settled.
+        key = (B, NV, str(x.device))
+        bufs = getattr(self, "_pool_bufs", None)
+        if bufs is None or bufs[0] != key:
+            m = hmid.shape[1]
+            bufs = (key, torch.empty((B, NV, m), dtype=torch.float16, device=x.device), torch.empty((B, NV, d), dtype=torch.float16, device=x.device),
+                    torch.empty((B * NV, d), dtype=torch.float16, device=x.device))
+            self._pool_bufs = bufs
+        _, ph, px, y = bufs
+        ops.temporal_spatial_pool_fwd(hmid.view(N, T, -1), B, F, drop_cls=True, grid=G, out=ph)    # [B, F + G*G, 4d] fp16
+        ops.temporal_spatial_pool_fwd(x.view(N, T, d), B, F, drop_cls=True, grid=G, out=px)        # [B, F + G*G, d]
+        ops.gemm_f16_nt(ph.view(B * NV, -1), p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=px.view(B * NV, d), out=y)
+        return ops.cast16(y, BF16).view(B, NV, d)      # image_features.to(images.dtype), clip_encoder.py:48
+
+    def _forward_layers_folded(self, x: torch.Tensor, N: int, T: int, out: Optional[torch.Tensor], pool: Optional[tuple] = None) -> torch.Tensor:
         """The encoder layers with layer_norm1 / layer_norm2 folded into q|k|v / fc1 (see _fold_prepare): per layer
         q|k|v GEMM (LN fold) -> attention -> out_proj GEMM (+residual, row statistics) -> fc1 GEMM (LN fold, QuickGELU) ->
         fc2 GEMM (+residual, row statistics).  Layer 0's layer_norm1 is the one explicit pass left (its input comes from
@@ -298,6 +334,8 @@ class CLIPVisionTower:
                 hmid = ops.gemm_f16_nt(y, p[f"{i}.fc1_w"], bias=p[f"{i}.fc1_b"], act=ops.ACT_QUICK_GELU)
                 del y
             last = i == self.n_run - 1
+            if last and pool is not None:
+                return self._last_layer_pooled(i, x, hmid, N, T, pool)
             x = ops.gemm_f16_nt_ln(hmid, p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=x, stats_out=None if last else part)
             del hmid
             if not last:

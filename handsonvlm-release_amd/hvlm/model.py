@@ -255,14 +255,28 @@ class HandsOnVLMForCausalLM:
                 frames = frames[first]
         n = frames.shape[0]
         NT = cfg.vision.num_patches + 1
+        G = cfg.vision.image_size // cfg.vision.patch_size       # patches per side: 16 at the reference's 224 px
+        NV = T + G * G
+        # the last tower layer's fc2 + residual AFTER the pooling (config.pool_before_last_fc2): the tower hands back the pooled
+        # [B, NV, d] features directly, chunked by whole samples
+        if (cfg.pool_before_last_fc2 and cfg.project_after_pool and inv is None and not fp8 and self.tower.wdtype == torch.float16
+                and self.tower.n_run >= 1 and cfg.mm_vision_select_feature == "patch"):
+            per = max(1, cfg.clip_chunk_frames // T)                 # samples per tower pass
+            pooled = torch.empty((B, NV, d), dtype=BF16, device=self.device)
+            for b0 in range(0, B, per):
+                b1 = min(B, b0 + per)
+                pooled[b0:b1] = self.tower.forward_tokens(frames[b0 * T:b1 * T], pool=(b1 - b0, T))
+            pooled = pooled.view(B * NV, d)
+            vis = ops.gemm_nt(pooled, self.proj_w, bias=self.proj_b)
+            if keep_for_backward:
+                self._vis_saved = dict(pooled=pooled)
+            return vis.view(B, NV, self.token_dim)
         tok = torch.empty((n, NT, d), dtype=BF16, device=self.device)          # [n, 257, d]: every chunk writes its slice
         for s in range(0, n, cfg.clip_chunk_frames):
             self.tower.forward_tokens(frames[s:s + cfg.clip_chunk_frames], out=tok[s:s + cfg.clip_chunk_frames], fp8=fp8)
         if inv is not None:
             tok = tok[inv]
         tok = tok.contiguous()
-        G = cfg.vision.image_size // cfg.vision.patch_size       # patches per side: 16 at the reference's 224 px
-        NV = T + G * G
         if cfg.project_after_pool:
             pooled = ops.temporal_spatial_pool_fwd(tok, B, T, drop_cls=True, grid=G).view(B * NV, d)
             vis = ops.gemm_nt(pooled, self.proj_w, bias=self.proj_b)

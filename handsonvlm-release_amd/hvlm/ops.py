@@ -628,14 +628,17 @@ def clip_embed(patch_out, cls, pos, N: int, NP: int, D: int) -> torch.Tensor:
     return tokens
 
 
-def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool, grid: int = 16) -> torch.Tensor:
-    """grid = patches per side (16: the reference's 224-px geometry; 24: 336 px)."""
-    _chk(tokens, BF16, "pool.tokens")
-    assert tokens.is_contiguous()
+def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool, grid: int = 16, out=None) -> torch.Tensor:
+    """grid = patches per side (16: the reference's 224-px geometry; 24: 336 px).  bf16 or fp16 tokens (output in the same dtype)."""
+    if tokens.dtype != torch.float16:
+        _chk(tokens, BF16, "pool.tokens")
+    assert tokens.is_cuda and tokens.is_contiguous()
     D = tokens.shape[-1]
-    out = torch.empty((B, T + grid * grid, D), dtype=BF16, device=tokens.device)
-    check(_lib.load().hvlm_temporal_spatial_pool_fwd(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _stream()),
-          "pool_fwd")
+    if out is None:
+        out = torch.empty((B, T + grid * grid, D), dtype=tokens.dtype, device=tokens.device)
+    assert out.shape == (B, T + grid * grid, D) and out.dtype == tokens.dtype and out.is_contiguous()
+    fn = _lib.load().hvlm_temporal_spatial_pool_fwd_f16 if tokens.dtype == torch.float16 else _lib.load().hvlm_temporal_spatial_pool_fwd
+    check(fn(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _stream()), "pool_fwd")
     return out
 
 

@@ -336,6 +336,11 @@ int hvlm_clip_embed(const void* patch_out, const void* cls, const void* pos, voi
  * (feature_select 'patch', clip_encoder.py:29-37). */
 int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, int D,
                                    int drop_cls, int grid, void* stream);
+/* The same on IEEE-half tokens / output (fp32 accumulation): the pooling applied INSIDE the last layer of the fp16 CLIP tower
+ * (config.pool_before_last_fc2: the means commute with CLIPMLP.fc2 and the residual add, transformers modeling_clip through
+ * clip_encoder.py:39-51, so fc2 runs on T + G*G pooled rows per sample instead of T*(G*G+1)). */
+int hvlm_temporal_spatial_pool_fwd_f16(const void* tokens, void* out, int B, int T, int D,
+                                       int drop_cls, int grid, void* stream);
 /* backward of the above: dtokens [B,T,G*G,D] (fully written) from dout [B,T+G*G,D]. */
 int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D, int grid, void* stream);
 

@@ -250,7 +250,7 @@ def clip_embed(patch_out, cls, pos, N, NP, D):
     return tok.to(BF16)
 
 
-def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16):
+def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16, out=None):
     D = tokens.shape[-1]
     G = grid
     t = tokens.float().reshape(B, T, -1, D)
@@ -259,7 +259,11 @@ def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16):
     sel = np.round(np.linspace(0, T - 1, 4)).astype(int)
     s = t[:, sel].reshape(B * 4, G, G, D).permute(0, 3, 1, 2)
     s = F.avg_pool2d(s, 2).permute(0, 2, 3, 1).reshape(B, G * G, D)
-    return torch.cat([t.mean(2), s], 1).to(BF16)
+    res = torch.cat([t.mean(2), s], 1).to(tokens.dtype if tokens.dtype == torch.float16 else BF16)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def temporal_spatial_pool_bwd(dout, B, T, grid=16):

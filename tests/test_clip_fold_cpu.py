@@ -101,3 +101,45 @@ def test_fold_refuses_columns_that_sink_into_fp16_subnormals_and_falls_back(monk
         print(f"ln_w spread from {lo}: folded (+ fallbacks) vs oracle {e_fold:.2e}, explicit vs oracle {e_expl:.2e}")
         assert torch.isfinite(outs[True]).all()
         assert e_fold <= 1.5 * e_expl + 5e-4 and e_fold <= 2e-2
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_last_layer_fc2_after_pooling_equals_pooling_the_full_output(monkeypatch, fold):
+    """config.pool_before_last_fc2 (hvlm/clip.py::_last_layer_pooled): pool(x + fc2(h) + b) = pool(x) + fc2(pool(h)) + b — the
+    tower called with pool=(B, T) must return what VisualToTokenHelper.compress_tokens (hoi_forecast/model/visual_to_tokens.py:
+    252-272; CLS dropped, clip_encoder.py:29-37) makes of its full output, up to the rounding order, and match the fp32 oracle as
+    well as the unpooled path does.  Folded and explicit-LayerNorm towers."""
+    import cpu_ops
+    cpu_ops.install(monkeypatch)
+    from hvlm import clip as clip_mod
+    from hvlm import ops
+    from hvlm.config import CLIPVisionConfig
+    c = dict(clip_d=256, clip_mlp=512, clip_layers=4, clip_heads=4, patch=14, image=56)      # 4 x 4 patches + CLS
+    cfg = CLIPVisionConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4, image_size=56, patch_size=14)
+    p = synth.to_torch(synth.clip_params(c, seed=8))
+    B, T = 2, 6
+    img = synth.make_images(B, T, 3, 56, seed=21)                            # [B, T, 3, 56, 56], duplicate frames inside a sample
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    with torch.no_grad():
+        feats = R.clip_features(img.flatten(0, 1), p, 4, 4)                  # [B*T, 16, 256] fp32, CLS dropped
+        want = R.temporal_spatial_pool(feats.view(B, T, 16, 256))            # [B, T + 16, 256]
+    monkeypatch.setattr(clip_mod, "_FOLD_LN", fold)
+    tower = clip_mod.CLIPVisionTower(cfg, "cpu", dtype=torch.float16)
+    tower.load_state_dict(p)
+    frames = img.flatten(0, 1).to(torch.bfloat16)
+    full = tower.forward_tokens(frames)                                       # [B*T, 17, 256] bf16
+    ref_path = ops.temporal_spatial_pool_fwd(full.contiguous(), B, T, drop_cls=True, grid=4).float()
+    calls = []
+    g0 = ops.gemm_f16_nt
+    monkeypatch.setattr(ops, "gemm_f16_nt", lambda a, b, **k: (calls.append((a.shape[0], b.shape[0], a.shape[1])), g0(a, b, **k))[1])
+    got = tower.forward_tokens(frames, pool=(B, T)).float()
+    monkeypatch.setattr(ops, "gemm_f16_nt", g0)
+    assert got.shape == (B, T + 16, 256)
+    assert (B * (T + 16), 256, 512) in calls                                  # fc2 of the last layer ran on the pooled rows ...
+    if not fold:                                                              # ... and on every token only in the layers before it
+        assert calls.count((B * T * 17, 256, 512)) == tower.n_run - 1         # (the folded tower's other fc2s go through gemm_f16_nt_ln)
+    else:
+        assert (B * T * 17, 256, 512) not in calls
+    e_new, e_old, e_ab = rel(got, want), rel(ref_path, want), rel(got, ref_path)
+    print(f"fold={fold}: pooled-fc2 vs oracle {e_new:.2e}, pool of the full output vs oracle {e_old:.2e}, the two paths {e_ab:.2e}")
+    assert e_new <= 1.25 * e_old + 2e-4 and e_ab <= 6e-3
