@@ -58,8 +58,13 @@ __device__ __forceinline__ float quick_gelu_pp(float x) {
 // 16-byte global store the compiler's wait-count tracking does not see (gfx9 reads store data at issue, so the
 // registers are free immediately).  With tracked stores pending at the top of the K loop the compiler guards every
 // first ds_read of a K-tile with its own `s_waitcnt vmcnt(0)` (it cannot order them against the LDS-DMA in flight).
+// The trailing s_nop is the ISA's "VMEM store of more than 64 bits of data -> write of those data VGPRs" hazard: the hardware keeps
+// reading the upper data dwords for a cycle or two after issue, and the compiler — which inserts the wait state itself behind a
+// store it can see — does not look inside inline asm.  Without it the first dword of a row's 16 bytes was clobbered whenever the
+// register allocator happened to reuse v[data] for the next address computation right behind the store (round 4: seen the moment the
+// epilogue loop was specialised and rescheduled; before that the instruction order hid it).
 __device__ __forceinline__ void store16_untracked(void* ptr, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ void store8_untracked(void* ptr, u32x2 v) {
@@ -648,8 +653,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             }
         }
       }
-      u32x4 o_prev[2];
+      // The loop below exists in a few SPECIALISATIONS of (bias, QuickGELU, LayerNorm fold): with the three as run-time flags the
+      // compiler emitted a scalar branch around every 4-element group, four v_cndmask per group for the fold select, and ran the
+      // exp -> add -> rcp chain of one element at a time behind s_nop hazards.  (1 / 0 = known at compile time, -1 = run time.)
       const int f_lo = 2 * i_lo, f_hi = 2 * i_hi;       // fragments of this unit (a half-tile unit: 4 of the 8)
+      auto run_nores = [&](auto hb_t, auto act_t, auto lnf_t) {
+      constexpr int HBc = decltype(hb_t)::value, ACc = decltype(act_t)::value, LNc = decltype(lnf_t)::value;
+      const bool hb = HBc >= 0 ? (HBc == 1) : (p.bias != nullptr);
+      const bool gelu = ACc >= 0 ? (ACc == 1) : (p.act == HVLM_ACT_QUICK_GELU);
+      const bool lnf_on = LNc >= 0 ? (LNc == 1) : lnf;
+      u32x4 o_prev[2];
 #pragma unroll
       for (int f = 0; f <= 8; ++f) {
         const int i = f >> 1, j = f & 1;
@@ -661,19 +674,24 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[j][i][4 * g + e];
             if constexpr (LNF) {
-              if (lnf) {
+              if (lnf_on) {
                 const float nmu = -lmu[i][g & 1], rs = lrs[i][g & 1];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(nmu, c1f[j][g >> 1][e], v[e]) * rs;
               }
             }
-            if (p.bias) {
+            if (hb) {
               const u32x2 bb = bias_q[j][g];
               v[0] += EL::lo(bb[0]); v[1] += EL::hi(bb[0]); v[2] += EL::lo(bb[1]); v[3] += EL::hi(bb[1]);
             }
-            if (p.act == HVLM_ACT_QUICK_GELU) {
+            if (gelu) {                      // x * sigmoid(1.702 x), the four elements' chains interleaved stage by stage
+              float z[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = quick_gelu_pp(v[e]);
+              for (int e = 0; e < 4; ++e) z[e] = __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[e]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) z[e] = __builtin_amdgcn_rcpf(1.f + z[e]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= z[e];
             }
             const u32x2 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3])};
             const int qr = qrow(g), qc = qcol(g);   // row qr, bf16 columns qc..qc+3 of the 32x32 fragment (64-B rows)
@@ -706,6 +724,21 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           }
         }
       }
+      };   // run_nores
+      using TM = std::integral_constant<int, -1>;
+      const bool hb_r = p.bias != nullptr, gelu_r = p.act == HVLM_ACT_QUICK_GELU, plain_r = p.act == HVLM_ACT_NONE;
+      if constexpr (LNF) {                   // the CLIP tower's fp16 kernel: q|k|v, fc1 (folded and explicit-LayerNorm towers)
+        if (hb_r && lnf && gelu_r) run_nores(T1{}, T1{}, T1{});
+        else if (hb_r && lnf && plain_r) run_nores(T1{}, T0{}, T1{});
+        else run_nores(TM{}, TM{}, TM{});
+      } else if constexpr (FP8) {            // e4m3: the decoder prefill (no bias) and the e4m3 CLIP tower (bias, bias + QuickGELU)
+        if (!hb_r && plain_r) run_nores(T0{}, T0{}, T0{});
+        else if (hb_r && gelu_r) run_nores(T1{}, T1{}, T0{});
+        else run_nores(TM{}, TM{}, T0{});
+      } else {                               // bf16: the decoder's GEMMs carry neither
+        if (!hb_r && plain_r) run_nores(T0{}, T0{}, T0{});
+        else run_nores(TM{}, TM{}, T0{});
+      }
       return;
     }
     float bias_f[2][8];
@@ -730,6 +763,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           dst[j][q] = *reinterpret_cast<const u32x4*>(p.res + (size_t)mc * p.ldr + ncol0 + j * 32);
         }
     };
+    // (specialised like the no-residual loop above: bias / activation / statistics known at compile time, or all at run time)
+    auto run_res = [&](auto hb_t, auto st_t) {
+    constexpr int HBc = decltype(hb_t)::value, STc = decltype(st_t)::value;
+    const bool hb = HBc >= 0 ? (HBc == 1) : (p.bias != nullptr);
+    const bool gelu = HBc >= 0 ? false : (p.act == HVLM_ACT_QUICK_GELU);      // the specialised forms are dispatched for act == NONE only
     load_res(i_lo, res_n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -757,11 +795,11 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(epi + r * 128 + (((2 * t_c) ^ (r & 7)) << 4));
           const f32x4 hi4 = *reinterpret_cast<const f32x4*>(epi + r * 128 + (((2 * t_c + 1) ^ (r & 7)) << 4));
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-          if (p.bias) {
+          if (hb) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bias_f[j][e];
           }
-          if (p.act == HVLM_ACT_QUICK_GELU) {
+          if (gelu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = quick_gelu_pp(v[e]);
           }
@@ -775,7 +813,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           const u32x4 o = {EL::pack2(v[0], v[1]), EL::pack2(v[2], v[3]), EL::pack2(v[4], v[5]), EL::pack2(v[6], v[7])};
           if (m < p.M) store16_untracked(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ncol0 + j * 32, o);
           if constexpr (LNF) {
-            if (p.stats_out) {                 // statistics of the values AS STORED (rounded to 16 bits): what the consumer reads
+            if (STc >= 0 ? (STc == 1) : (p.stats_out != nullptr)) {                 // statistics of the values AS STORED (rounded to 16 bits): what the consumer reads
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float a = EL::lo(o[e]), b = EL::hi(o[e]);
@@ -788,7 +826,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         }
       }
       if constexpr (LNF) {
-        if (p.stats_out) {
+        if (STc >= 0 ? (STc == 1) : (p.stats_out != nullptr)) {
           // the four lanes t_c = 0..3 of a row hold its 4 x 8 columns per j: quad reduction, lane 0 of the quad writes the wave's
           // partial for (row, tile column, wave column block) — one writer per entry, fixed order: deterministic
 #pragma unroll
@@ -808,6 +846,12 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         }
       }
     }
+    };   // run_res
+    // (ONE instantiation, everything tested at run time: a second, specialised copy of this loop — bias + statistics known at compile
+    // time — pushed the fp16 kernel to 108 bytes of scratch with reloads all over the epilogue, each behind a vmcnt wait that also
+    // drains the next tile's LDS-DMA prefetch; measured on the no-residual loop the specialisation is worth 2-3 %, here it is not
+    // worth the spills)
+    run_res(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
     }   // !EPI_SWAP
   };
 
