@@ -444,6 +444,214 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   attn_fwd_body<DH, CAUSAL, NW, F16>(qkv, vt, out, lse, S_max, H, ld, S_pad, scale_log2, cu_seqlens);
 }
 
+#ifdef HVLM_DEV
+// =================================================================================================
+// forward, software-pipelined inside each wave (round 4 EXPERIMENT, development builds only; bf16, the decoder's dh = 128 path):
+//   iteration t:   S(t+1) = K(t+1) Q^T  (16 MFMAs)  ||  exp / row sum of S(t)  (VALU)   ->   O += V(t)^T P(t)
+// The streaming kernel above runs QK^T, the softmax VALU and PV of one tile one after the other and relies on the second wave
+// of the SIMD to fill the gaps — but the VALU stream of one wave and the MFMA stream of another serialise on the SIMD's issue
+// port (tools/valu_mfma_probe.hip: 1213 cycles for two role-split waves against 881 for one wave carrying both streams).  Here the
+// score MFMAs of the NEXT key tile sit in the same basic block as the exponentials of the current one (a second score set, 32
+// registers), so one wave interleaves them.  LDS: K and V rings of two tiles each with K running one tile ahead of V (K(t+1) and
+// V(t) in use, K(t+2) and V(t+1) in flight) — the same 64 KiB, still two workgroups per CU, one barrier per tile.
+// Same arithmetic, same order per element as attn_fwd_body: bit-identical results (checked on the GPU).
+// MEASURED AND NOT ADOPTED (profiles/r04g_attn_fwd_pipelined.txt): at two waves per SIMD (256 VGPRs) the second score set does not
+// fit — O 64 + Q 32 + S 32 + S' 32 + K fragments 32 + V fragments 16-32 + addresses: 332-408 bytes of scratch with reloads through
+// the whole loop; at one workgroup per CU (launch bounds (256, 1)) the compiler takes 356 registers, parks half of them in
+// AccVGPRs (~200 v_accvgpr_read/write per tile) and still clusters the MFMAs ahead of the exponentials (sched_group_barrier
+// requests are not honoured across the LDS-read waits): 343.6 us against 230.6 us for the shipped kernel at B = 16, S = 867, H = 32
+// (451 vs 252 at S = 2048, H = 40).  The probe's 881-cycle arrangement needs a hand-allocated register file (assembly), not this.
+template <int DH, bool CAUSAL, int NW>
+__device__ __forceinline__ void attn_fwd_pipe_body(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                   int S_max, int H, int ld, float scale_log2, const int32_t* __restrict__ cu_seqlens) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr unsigned KT = 64 * DH * 2;   // one 64-key tile of K or V
+  const int tid = threadIdx.x, l = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = l & 31, hi = l >> 5;
+  constexpr int QB = NW * 32;
+  int bx, h, b;
+  xcd_block(bx, h, b);
+  const long tok0 = cu_seqlens ? (long)cu_seqlens[b] : (long)b * S_max;
+  const int S = cu_seqlens ? (cu_seqlens[b + 1] - cu_seqlens[b]) : S_max;
+  const int nqt = (S + QB - 1) / QB;
+  if (bx >= nqt) return;
+  const int qt = CAUSAL ? (nqt - 1 - bx) : bx;  // heavy tiles first
+  const int q0 = qt * QB;
+  const int qi = q0 + w * 32 + l31;
+  const int qmax_w = q0 + w * 32 + 31;           // last query row of this wave
+
+  bf16x8 qf[DH / 16];
+  {
+    const bf16_t* qp = qkv + (tok0 + min(qi, S - 1)) * ld + h * DH + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+  }
+  f32x16 o[DH / 32];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+
+  const int nkt_all = (S + 63) / 64;
+  const int nkt = CAUSAL ? min(nkt_all, min(q0 + QB - 1, S - 1) / 64 + 1) : nkt_all;
+
+  TileDma<DH, NW> dma;
+  dma.init(ld, w, l);
+  const __amdgpu_buffer_rsrc_t rs_kv = sample_rsrc(qkv + tok0 * ld, S, ld);
+  const unsigned k_col = (unsigned)(((long)H * DH + h * DH) * 2), v_col = k_col + (unsigned)((long)H * DH * 2);
+  auto stage_k = [&](int kt) { dma.issue(rs_kv, (unsigned)((long)kt * 64 * ld * 2) + k_col, (unsigned)(kt & 1) * KT, smem); };
+  auto stage_v = [&](int kt) { dma.issue(rs_kv, (unsigned)((long)kt * 64 * ld * 2) + v_col, 2 * KT + (unsigned)(kt & 1) * KT, smem); };
+  const int p16 = l & 15, g16 = l31 >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long)(lds_ptr_t)smem;
+  unsigned v_off[DH / 32][2];
+#pragma unroll
+  for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      v_off[db][hf] = lds0 + tile_addr<DH>(4 * hi + (p16 >> 2) + 8 * hf, db * 4 + g16 * 2 + ((p16 & 3) >> 1)) + (unsigned)((p16 & 1) * 8);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // does this wave touch tile kt at all / its second 32-key block (wave-uniform)
+  auto active = [&](int kt) { return kt < nkt && !(CAUSAL && kt * 64 > qmax_w); };
+  auto has_kb1 = [&](int kt) { return (kt * 64 + 32 < S) && !(CAUSAL && kt * 64 + 32 > qmax_w); };
+  // raw scores of tile kt from the K ring slot kt & 1, BOTH 32-key blocks, no branches (it has to sit in one basic block with the
+  // exponentials it is interleaved with): a block past the sequence end / above the diagonal is computed on whatever the slot
+  // holds and masked to -inf by the boundary code of its own iteration; two half-sweeps over the head dim, 32 fragment registers each
+  auto qk_tile = [&](int kt, f32x16 (&sc)[2]) {
+    const unsigned sK = (unsigned)(kt & 1) * KT;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      bf16x8 kfr[DH / 32][2];
+#pragma unroll
+      for (int k2 = 0; k2 < DH / 32; ++k2)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) kfr[k2][kb] = lds_frag128(smem, sK + tile_addr<DH>(kb * 32 + l31, (hh * (DH / 32) + k2) * 2 + hi));
+#pragma unroll
+      for (int k2 = 0; k2 < DH / 32; ++k2)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int ks = hh * (DH / 32) + k2;
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[k2][kb], qf[ks], ks == 0 ? zero16 : sc[kb], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) in flight; S(0) computed before the loop ----
+  stage_k(0);
+  stage_v(0);
+  if (nkt > 1) stage_k(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x16 sn[2];                            // scores of the NEXT tile (set by the previous iteration)
+  qk_tile(0, sn);                          // (tile 0 is active for every wave)
+  (void)has_kb1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // K(kt+1), V(kt) landed for everyone; everyone is past its reads of K(kt) and V(kt-1)
+    if (kt + 2 < nkt) stage_k(kt + 2);     // -> the slot of K(kt)
+    if (kt + 1 < nkt) stage_v(kt + 1);     // -> the slot of V(kt-1)
+    if (!active(kt)) continue;             // (tiles ascend: once inactive, always inactive; the loop goes on for the barriers / DMA)
+    const int kv0 = kt * 64;
+    const unsigned sV = 2 * KT + (unsigned)(kt & 1) * KT;
+    const bool kb1 = has_kb1(kt);
+    f32x16 s[2];
+    s[0] = sn[0]; s[1] = sn[1];
+    if ((kv0 + 64 > S) || (CAUSAL && kv0 + 63 > q0 + w * 32)) {       // boundary tile: sequence tail / causal diagonal
+      int lim = S - 1 - kv0 - 4 * hi;
+      if (CAUSAL) lim = min(lim, qi - kv0 - 4 * hi);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb * 32 + (r & 3) + 8 * (r >> 2) > lim) s[kb][r] = -INFINITY;
+    }
+    s16x4_t vlo[2][DH / 32], vhi[2][DH / 32];
+#define HVLM_FWD_VREADS(SET, KB, SP)                                                                                   \
+    do {                                                                                                                \
+      const unsigned kbytes_ = sV + (unsigned)((KB) * 32 + 16 * (SP)) * (DH * 2);                                      \
+      _Pragma("unroll") for (int db = 0; db < DH / 32; ++db)                                                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3"                                         \
+                     : "=&v"(vlo[SET][db]), "=&v"(vhi[SET][db]) : "v"(v_off[db][0] + kbytes_), "v"(v_off[db][1] + kbytes_) : "memory"); \
+    } while (0)
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, xlane32(mx));
+    const float mnew = fmaxf(m, mx * scale_log2);
+    if (__builtin_amdgcn_ballot_w64(mnew > m)) {
+      const float alpha = fast_exp2(m - mnew);
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      m = mnew;
+    }
+    // ---- the pipelined block: score MFMAs of tile kt+1 beside the exponentials of tile kt (ONE basic block; the last
+    // iteration's extra tile reads a stale slot and is never used) ----
+    __builtin_amdgcn_sched_barrier(0);
+    qk_tile(kt + 1, sn);
+    float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = fast_exp2(__builtin_fmaf(s[kb][r], scale_log2, -m));
+        const float p1 = fast_exp2(__builtin_fmaf(s[kb][r + 1], scale_log2, -m));
+        s[kb][r] = p0; s[kb][r + 1] = p1;
+        psum0 += p0; psum1 += p1;
+      }
+    lsum += psum0 + psum1;
+    __builtin_amdgcn_sched_barrier(0);
+    HVLM_FWD_VREADS(0, 0, 0);
+    const int ngrp = kb1 ? 4 : 2;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      if (gi >= ngrp) break;
+      const int kb = gi >> 1, sp = gi & 1, cur = gi & 1;
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[kb][8 * sp + j];
+      const bf16x8 pf = pack8<false>(pv);
+      if (gi + 1 < ngrp) {
+        if (cur == 0) HVLM_FWD_VREADS(1, (gi + 1) >> 1, (gi + 1) & 1);
+        else HVLM_FWD_VREADS(0, (gi + 1) >> 1, (gi + 1) & 1);
+        if constexpr (DH == 128) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int db = 0; db < DH / 32; ++db) {
+        s16x8_t vv = {vlo[cur][db][0], vlo[cur][db][1], vlo[cur][db][2], vlo[cur][db][3], vhi[cur][db][0], vhi[cur][db][1], vhi[cur][db][2], vhi[cur][db][3]};
+        asm volatile("" : "+v"(vv));
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[db], 0, 0, 0);
+      }
+    }
+#undef HVLM_FWD_VREADS
+  }
+  const float ltot = lsum + xlane32(lsum);
+  __syncthreads();
+  {
+    const int qw0 = q0 + w * 32;
+    store_block_rows<DH, false>(smem + w * (32 * DH * 2), o, 1.f / ltot, out + (tok0 + qw0) * (long)(H * DH) + h * DH, (long)H * DH,
+                                S - qw0, l);
+    if (qi < S && lse && hi == 0) lse[((long)b * H + h) * S_max + qi] = m * LN2 + logf(ltot);
+  }
+}
+template <int DH, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_fwd_pipe_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int S_max, int H, int ld, float scale_log2,
+                                                            const int32_t* __restrict__ cu_seqlens) {
+  attn_fwd_pipe_body<DH, CAUSAL, NW>(qkv, out, lse, S_max, H, ld, scale_log2, cu_seqlens);
+}
+
+#endif  // HVLM_DEV (attn_fwd_pipe)
+
 // =================================================================================================
 // forward, short non-causal sequences (CLIP: S = 257, dh = 64): K and V of one (batch, head) stay RESIDENT in LDS.
 //   One workgroup = one (batch, head), one wave per 32 queries (S = 257 -> 9 waves), K and V ([32*NKB rows][DH], row
@@ -1581,6 +1789,17 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us
   // per CLIP layer, and were removed)
+#ifdef HVLM_DEV
+  if constexpr (DH == 128 && !F16) {
+    if (config().attn_fwd_pipe) {            // the intra-wave software pipeline (attn_fwd_pipe_body), development builds
+      rc = set_lds(attn_fwd_pipe_kernel<DH, CAUSAL, 4>, LDS, "attn_fwd_pipe");
+      if (rc) return rc;
+      dim3 grid((S + 127) / 128, H, B);
+      hipLaunchKernelGGL((attn_fwd_pipe_kernel<DH, CAUSAL, 4>), grid, dim3(256), LDS, st, qkv, out, lse, S, H, ld, scale * LOG2E, cu);
+      return check_launch("attn_fwd_pipe");
+    }
+  }
+#endif
   {
     rc = set_lds(attn_fwd_kernel<DH, CAUSAL, 4, F16>, LDS, "attn_fwd");
     if (rc) return rc;

@@ -150,6 +150,7 @@ struct Config {
   int gemm_tn_seg4 = 1;       // 0: 8-phase schedule for the K-strided (TN) kernel
   int gemm_fp8_m16 = 0;       // 1: 16x16x128 form of the e4m3 kernel
   int attn_dkv_fused = 1;     // 0: dV and dK in two passes
+  int attn_fwd_pipe = 0;      // 1: dh = 128 bf16 forward on the intra-wave software-pipelined kernel (round-4 experiment, slower)
 };
 Config& config();
 

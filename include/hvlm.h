@@ -71,7 +71,7 @@ size_t hvlm_gemm_sched_ws_bytes(void);
  * "gemm_static" (1: static tile assignment), "attn_no_resident" (1: CLIP attention on the streaming kernel),
  * "decode_unfused" (1: RoPE / split combine of the native decode step as separate launches), "skinny_per" (forced K-slice of
  * the weight-streaming GEMM).  Switches that select a superseded kernel variant or the K-loop ablation kernel ("gemm_dbg",
- * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "gemm_epi_swap", "gemm_tail_half", "attn_dkv_fused") exist in development builds only
+ * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "gemm_epi_swap", "gemm_tail_half", "attn_dkv_fused", "attn_fwd_pipe") exist in development builds only
  * (`make DEV=1`; hvlm_is_dev_build() == 1): a production build returns HVLM_ERR_UNSUPPORTED for any non-default value, and
  * does not contain those kernels.  Not thread-safe against concurrent launches (set switches before issuing work). */
 int hvlm_configure(const char* key, int value);
