@@ -845,9 +845,9 @@ def main():
             flops_llm = 3.0 * sum(model.stack.flops_forward(1, int(n) + nv1, cfg.vocab_size) for n in lens)
         flops_clip = n_frames * model.tower.flops_per_frame()
         # the last tower layer's fc2 on the pooled rows only (config.pool_before_last_fc2): the rows it skips are NOT counted as work
-        pool_fc2 = (cfg.pool_before_last_fc2 and cfg.project_after_pool and not args.dedup and args.clip_dtype == "fp16")
-        if pool_fc2:
-            flops_clip -= B * (cfg.num_frames * (nv1 + 2 - cfg.num_frames) - (nv1 + 1)) * 2.0 * cfg.vision.hidden_size * cfg.vision.intermediate_size
+        pool_fc2 = (cfg.pool_before_last_fc2 and cfg.project_after_pool and args.clip_dtype == "fp16")
+        if pool_fc2:                   # (tokens per frame = nv1 + 2 - frames; pooled rows per sample = nv1 + 1)
+            flops_clip -= (n_frames * (nv1 + 2 - cfg.num_frames) - B * (nv1 + 1)) * 2.0 * cfg.vision.hidden_size * cfg.vision.intermediate_size
         # lm_head on labelled rows only: the rows it does not run on are NOT counted as work (forward + dX + dW = 3 x 2 D V per row)
         rows_all = B * S if lens is None else int(sum(int(n) + nv1 for n in lens))
         lab = batch["labels"]
@@ -881,7 +881,7 @@ def main():
                        "projector_note": ("mm_projector applied AFTER the temporal/spatial pooling (Linear commutes with the means: 356 rows per "
                                           "sample instead of the reference's 25 600; its skipped FLOPs are not counted as work)"
                                           if cfg.project_after_pool else "mm_projector on all patch tokens, as the reference"),
-                       "clip_last_fc2_rows_per_sample": (nv1 + 1) if pool_fc2 else cfg.num_frames * (nv1 + 2 - cfg.num_frames),
+                       "clip_last_fc2_rows_per_sample": (nv1 + 1) if pool_fc2 else (n_frames // B) * (nv1 + 2 - cfg.num_frames),
                        "clip_last_fc2_note": ("the LAST CLIP layer's fc2 + residual run AFTER the temporal/spatial pooling (affine per-token maps "
                                               "commute with the means): 356 rows per sample instead of 25 700, 1/23 of the tower's fc2 work; its "
                                               "skipped FLOPs are not counted as work" if pool_fc2 else "every CLIP layer on every token, as the reference"),

@@ -66,10 +66,12 @@ __device__ __forceinline__ int sel_frame(int k, int T) {
 //   out row r >= T    : j = r-T; frame sel(j/P2); (oy,ox) = ((j%P2)/H, j%H); mean of the 2x2 patches
 // F16: the tokens / the output are IEEE half (the CLIP tower's own dtype: pooling INSIDE the tower's last layer, see
 // hvlm/clip.py::_last_layer_pooled) instead of bfloat16; accumulation is fp32 either way.
+// fidx (optional, int32 [B*T]): frame (b, t) of the pooled layout is token block fidx[b*T + t] of `tok` — the tower ran on the
+// DISTINCT frames only (config.dedup_frames) and the pooling gathers them back.
 template <bool F16>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict__ tok,
                                                        bf16_t* __restrict__ out, int B, int T, int D, int G,
-                                                       int skip /*1 if cls is dropped*/) {
+                                                       int skip /*1 if cls is dropped*/, const int32_t* __restrict__ fidx) {
   using EL = E16<F16>;
   const int dv = D / 8;
   const int G2 = G * G, H = G / 2, P2 = H * H;
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     float scale;
     if (r < T) {
-      const bf16_t* base = tok + ((b * T + r) * (long)tpf + skip) * D + c;
+      const long fr = fidx ? (long)fidx[b * T + r] : b * T + r;
+      const bf16_t* base = tok + (fr * (long)tpf + skip) * D + c;
       for (int p = 0; p < G2; ++p) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long)p * D);
 #pragma unroll
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const bf16_t* __restrict_
       const int f = sel_frame(j / P2, T);
       const int jj = j % P2;
       const int oy = jj / H, ox = jj % H;
-      const bf16_t* base = tok + ((b * T + f) * (long)tpf + skip) * D + c;
+      const long fr = fidx ? (long)fidx[b * T + f] : b * T + f;
+      const bf16_t* base = tok + (fr * (long)tpf + skip) * D + c;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -304,17 +308,17 @@ extern "C" int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int
   HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_fwd: grid=%d must be even (16 = reference geometry)", grid);
   const long total = (long)B * (T + grid * grid) * (D / 8);
   hipLaunchKernelGGL(pool_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0);
+                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0, (const int32_t*)nullptr);
   return check_launch("temporal_spatial_pool_fwd");
 }
 
 extern "C" int hvlm_temporal_spatial_pool_fwd_f16(const void* tokens, void* out, int B, int T, int D,
-                                                  int drop_cls, int grid, void* stream) {
+                                                  int drop_cls, int grid, const int32_t* frame_index, void* stream) {
   HVLM_REQUIRE(tokens && out && B > 0 && T >= 1 && D % 8 == 0, "pool_fwd_f16: bad args");
   HVLM_REQUIRE(grid >= 2 && grid % 2 == 0, "pool_fwd_f16: grid=%d must be even (16 = reference geometry)", grid);
   const long total = (long)B * (T + grid * grid) * (D / 8);
   hipLaunchKernelGGL(pool_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0);
+                     (const bf16_t*)tokens, (bf16_t*)out, B, T, D, grid, drop_cls ? 1 : 0, frame_index);
   return check_launch("temporal_spatial_pool_fwd_f16");
 }
 

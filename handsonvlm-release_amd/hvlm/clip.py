@@ -212,12 +212,13 @@ class CLIPVisionTower:
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_tokens(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, fp8: bool = False,
-                       pool: Optional[tuple] = None) -> torch.Tensor:
+                       pool: Optional[tuple] = None, frame_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """images [N,3,H,W] (any float dtype; cast to bf16) -> hidden_states[select_layer] [N, NP+1, d] (bf16).  `out`: an
         optional [N, NP+1, d] bf16 destination (a slice of the caller's buffer: no concatenation of chunks afterwards).
         `pool` = (B, T): the N = B*T frames are B whole samples and the caller only wants the temporal/spatial POOLING of the
         patch tokens (VisualToTokenHelper.compress_tokens, CLS dropped): returns [B, T + G*G, d] bf16 instead, with the last
-        layer's fc2 + residual applied AFTER the pooling (fp16 tower only; see _last_layer_pooled).
+        layer's fc2 + residual applied AFTER the pooling (fp16 tower only; see _last_layer_pooled).  With `frame_index`
+        (int32 [B*T]) the N images are the DISTINCT frames and frame (b, t) is image frame_index[b*T + t] (config.dedup_frames).
         `fp8`: the q|k|v / out_proj / fc1 / fc2 GEMMs of every layer on e4m3 operands (CDNA4 scaled MFMA, fp32 accumulation,
         per-token activation and per-channel weight scales); LayerNorm, attention, the residual stream, biases and QuickGELU
         stay bf16, the patch embedding stays a bf16 GEMM (K = 588)."""
@@ -246,7 +247,10 @@ class CLIPVisionTower:
         del pe
         x = ln(x, p["pre_ln_w"], p["pre_ln_b"], cfg.layer_norm_eps)
         scale = dh ** -0.5
-        assert pool is None or (f16 and pool[0] * pool[1] == N and self.n_run >= 1), "pool=(B, T): fp16 tower, whole samples"
+        assert pool is None or (f16 and self.n_run >= 1 and (pool[0] * pool[1] == N if frame_index is None else frame_index.numel() == pool[0] * pool[1])), \
+            "pool=(B, T): fp16 tower, whole samples"
+        if pool is not None:
+            pool = (pool[0], pool[1], frame_index)
         if f16 and _FOLD_LN and d % 256 == 0 and cfg.intermediate_size % 256 == 0:
             return self._forward_layers_folded(x, N, T, out, pool)
         for i in range(self.n_run):
@@ -279,7 +283,7 @@ class CLIPVisionTower:
         fp16 values, ONE rounding to fp16) and fc2 runs on B * (frames + G*G) rows instead of N * T.  x = the stream after the
         attention block (the o_proj GEMM's output), hmid = QuickGELU(fc1(LN2(x)))."""
         p, cfg = self.p, self.cfg
-        B, F = pool
+        B, F, fidx = pool
         G = cfg.image_size // cfg.patch_size
         d = cfg.hidden_size
         NV = F + G * G
@@ -294,8 +298,8 @@ class CLIPVisionTower:
                     torch.empty((B * NV, d), dtype=torch.float16, device=x.device))
             self._pool_bufs = bufs
         _, ph, px, y = bufs
-        ops.temporal_spatial_pool_fwd(hmid.view(N, T, -1), B, F, drop_cls=True, grid=G, out=ph)    # [B, F + G*G, 4d] fp16
-        ops.temporal_spatial_pool_fwd(x.view(N, T, d), B, F, drop_cls=True, grid=G, out=px)        # [B, F + G*G, d]
+        ops.temporal_spatial_pool_fwd(hmid.view(N, T, -1), B, F, drop_cls=True, grid=G, out=ph, frame_index=fidx)    # [B, F + G*G, 4d] fp16
+        ops.temporal_spatial_pool_fwd(x.view(N, T, d), B, F, drop_cls=True, grid=G, out=px, frame_index=fidx)        # [B, F + G*G, d]
         ops.gemm_f16_nt(ph.view(B * NV, -1), p[f"{i}.fc2_w"], bias=p[f"{i}.fc2_b"], residual=px.view(B * NV, d), out=y)
         return ops.cast16(y, BF16).view(B, NV, d)      # image_features.to(images.dtype), clip_encoder.py:48
 

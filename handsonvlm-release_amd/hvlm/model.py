@@ -259,13 +259,18 @@ class HandsOnVLMForCausalLM:
         NV = T + G * G
         # the last tower layer's fc2 + residual AFTER the pooling (config.pool_before_last_fc2): the tower hands back the pooled
         # [B, NV, d] features directly, chunked by whole samples
-        if (cfg.pool_before_last_fc2 and cfg.project_after_pool and inv is None and not fp8 and self.tower.wdtype == torch.float16
-                and self.tower.n_run >= 1 and cfg.mm_vision_select_feature == "patch"):
-            per = max(1, cfg.clip_chunk_frames // T)                 # samples per tower pass
+        if (cfg.pool_before_last_fc2 and cfg.project_after_pool and not fp8 and self.tower.wdtype == torch.float16
+                and self.tower.n_run >= 1 and cfg.mm_vision_select_feature == "patch" and (inv is None or n <= cfg.clip_chunk_frames)):
             pooled = torch.empty((B, NV, d), dtype=BF16, device=self.device)
-            for b0 in range(0, B, per):
-                b1 = min(B, b0 + per)
-                pooled[b0:b1] = self.tower.forward_tokens(frames[b0 * T:b1 * T], pool=(b1 - b0, T))
+            if inv is not None:
+                # de-duplicated frames: ONE tower pass over the distinct frames; the pooling gathers frame (b, t) = distinct frame
+                # inv[b*T + t] — the same sums over the same values as the pass over all B*T frames: identical visual tokens
+                pooled.copy_(self.tower.forward_tokens(frames, pool=(B, T), frame_index=inv.to(torch.int32).contiguous()))
+            else:
+                per = max(1, cfg.clip_chunk_frames // T)                 # samples per tower pass
+                for b0 in range(0, B, per):
+                    b1 = min(B, b0 + per)
+                    pooled[b0:b1] = self.tower.forward_tokens(frames[b0 * T:b1 * T], pool=(b1 - b0, T))
             pooled = pooled.view(B * NV, d)
             vis = ops.gemm_nt(pooled, self.proj_w, bias=self.proj_b)
             if keep_for_backward:

@@ -628,8 +628,9 @@ def clip_embed(patch_out, cls, pos, N: int, NP: int, D: int) -> torch.Tensor:
     return tokens
 
 
-def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool, grid: int = 16, out=None) -> torch.Tensor:
-    """grid = patches per side (16: the reference's 224-px geometry; 24: 336 px).  bf16 or fp16 tokens (output in the same dtype)."""
+def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bool, grid: int = 16, out=None, frame_index=None) -> torch.Tensor:
+    """grid = patches per side (16: the reference's 224-px geometry; 24: 336 px).  bf16 or fp16 tokens (output in the same dtype).
+    frame_index (int32 [B*T], fp16 tokens only): frame (b, t) = token block frame_index[b*T + t] (frame de-duplication)."""
     if tokens.dtype != torch.float16:
         _chk(tokens, BF16, "pool.tokens")
     assert tokens.is_cuda and tokens.is_contiguous()
@@ -637,8 +638,14 @@ def temporal_spatial_pool_fwd(tokens: torch.Tensor, B: int, T: int, drop_cls: bo
     if out is None:
         out = torch.empty((B, T + grid * grid, D), dtype=tokens.dtype, device=tokens.device)
     assert out.shape == (B, T + grid * grid, D) and out.dtype == tokens.dtype and out.is_contiguous()
-    fn = _lib.load().hvlm_temporal_spatial_pool_fwd_f16 if tokens.dtype == torch.float16 else _lib.load().hvlm_temporal_spatial_pool_fwd
-    check(fn(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _stream()), "pool_fwd")
+    if tokens.dtype == torch.float16:
+        if frame_index is not None:
+            _chk(frame_index, torch.int32, "pool.frame_index")
+            assert frame_index.numel() == B * T
+        check(_lib.load().hvlm_temporal_spatial_pool_fwd_f16(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _p(frame_index), _stream()), "pool_fwd_f16")
+    else:
+        assert frame_index is None, "frame_index: fp16 tokens only"
+        check(_lib.load().hvlm_temporal_spatial_pool_fwd(_p(tokens), _p(out), B, T, D, 1 if drop_cls else 0, grid, _stream()), "pool_fwd")
     return out
 
 

@@ -338,9 +338,11 @@ int hvlm_temporal_spatial_pool_fwd(const void* tokens, void* out, int B, int T, 
                                    int drop_cls, int grid, void* stream);
 /* The same on IEEE-half tokens / output (fp32 accumulation): the pooling applied INSIDE the last layer of the fp16 CLIP tower
  * (config.pool_before_last_fc2: the means commute with CLIPMLP.fc2 and the residual add, transformers modeling_clip through
- * clip_encoder.py:39-51, so fc2 runs on T + G*G pooled rows per sample instead of T*(G*G+1)). */
+ * clip_encoder.py:39-51, so fc2 runs on T + G*G pooled rows per sample instead of T*(G*G+1)).
+ * frame_index (int32 [B*T], may be NULL): frame (b, t) is token block frame_index[b*T + t] of `tokens` — the tower ran on the
+ * DISTINCT frames only (config.dedup_frames: EK100 tiles 10 frames x10, epic_dataset.py:90-95) and the pooling gathers them. */
 int hvlm_temporal_spatial_pool_fwd_f16(const void* tokens, void* out, int B, int T, int D,
-                                       int drop_cls, int grid, void* stream);
+                                       int drop_cls, int grid, const int32_t* frame_index, void* stream);
 /* backward of the above: dtokens [B,T,G*G,D] (fully written) from dout [B,T+G*G,D]. */
 int hvlm_temporal_spatial_pool_bwd(const void* dout, void* dtokens, int B, int T, int D, int grid, void* stream);
 

@@ -250,9 +250,11 @@ def clip_embed(patch_out, cls, pos, N, NP, D):
     return tok.to(BF16)
 
 
-def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16, out=None):
+def temporal_spatial_pool_fwd(tokens, B, T, drop_cls, grid=16, out=None, frame_index=None):
     D = tokens.shape[-1]
     G = grid
+    if frame_index is not None:
+        tokens = tokens.reshape(-1, tokens.shape[-2], D)[frame_index.long()]
     t = tokens.float().reshape(B, T, -1, D)
     if drop_cls:
         t = t[:, :, 1:]
