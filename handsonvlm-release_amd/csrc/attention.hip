@@ -1109,8 +1109,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =================================================================================================
 template <int DH, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt_g /*K^T [B,H,DH,S_pad]*/,
-    const bf16_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out_g /*O [tokens, H*DH], or NULL: delta is read, not computed*/,
+    const bf16_t* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta,
     bf16_t* __restrict__ dqkv, int S_max, int H, int ld, int S_pad, float scale,
     const int32_t* __restrict__ cu_seqlens, const bf16_t* __restrict__ rope_cos, const bf16_t* __restrict__ rope_sin,
     const int32_t* __restrict__ rope_pos) {
@@ -1142,7 +1142,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(
     }
   }
   const float lse2 = lse[((long)b * H + h) * S_max + qc] * LOG2E;
-  const float dlt = delta[((long)b * H + h) * S_max + qc];
+  // delta[b, h, s] = sum_d O[s, d] dO[s, d]: this lane and its lane^32 partner hold the two halves of the row's dO already, so the
+  // separate pass over O and dO (attn_delta_kernel: 44 us per layer at the SFT shape) folds into 8 loads of O and 64 FMAs here;
+  // the row's value is written out for the dK/dV kernel, which is launched after this one.
+  float dlt;
+  if (out_g) {
+    const bf16_t* op = out_g + (tok0 + qc) * (long)(H * DH) + h * DH + hi * 8;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < DH / 16; ++ks) {
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(op + ks * 16);
+      const u32x4 gv = __builtin_bit_cast(u32x4, dof[ks]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part += bf_lo(ov[e]) * bf_lo(gv[e]) + bf_hi(ov[e]) * bf_hi(gv[e]);
+    }
+    dlt = part + xlane32(part);
+    if (qi < S && hi == 0) delta[((long)b * H + h) * S_max + qi] = dlt;
+  } else {
+    dlt = delta[((long)b * H + h) * S_max + qc];
+  }
 
   f32x16 dq[DH / 32];
 #pragma unroll
@@ -1819,19 +1837,21 @@ static int bwd_impl(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, co
   float* delta = reinterpret_cast<float*>(ws);
   const int fused = config().attn_dkv_fused;
   int rc;   // (no Q^T / K^T / dO^T pre-passes any more: the kernels gather those fragments with LDS transpose reads)
-  {
+  const bool delta_sep = config().attn_delta_separate != 0;     // 1: delta by its own pass (A/B); default: inside the dQ kernel
+  if (delta_sep) {
     const long tokens = cu ? total_tokens : (long)B * S;
     const long total = tokens * H * (DH / 8);
     hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out,
                        dout, delta, tokens, S, H, cu, B);
     if ((rc = check_launch("attn_delta"))) return rc;
   }
+  (void)kT;
   {
     constexpr int LDS = 2 * 2 * 64 * DH * 2;            // two stages of (K, V)
     if ((rc = set_lds(attn_bwd_dq_kernel<DH, CAUSAL>, LDS, "attn_bwd_dq"))) return rc;
     dim3 grid((S + 127) / 128, H, B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, (const bf16_t*)kT,
-                       dout, lse, (const float*)delta, dqkv, S, H, ld, spad(S), scale, cu,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH, CAUSAL>), grid, dim3(256), LDS, st, qkv, delta_sep ? (const bf16_t*)nullptr : out,
+                       dout, lse, delta, dqkv, S, H, ld, spad(S), scale, cu,
                        fused ? rope_cos : (const bf16_t*)nullptr, rope_sin, rope_pos);
     if ((rc = check_launch("attn_bwd_dq"))) return rc;
   }

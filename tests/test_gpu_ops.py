@@ -126,7 +126,9 @@ def test_attention_fwd_bwd_vs_oracle(ops, B, S, H, dh, causal):
     d = dqkv.float().cpu().view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
     assert not torch.isnan(dqkv).any()
     for got, want in zip(d, (q.grad, k.grad, v.grad)):
-        assert rel(got, want) <= 6e-3
+        # (a gradient that is exactly zero in exact arithmetic — S = 1: P = 1, dS = dP - delta = 0 — is compared absolutely: dP comes
+        # from an MFMA and delta from a plain fp32 sum, they agree to an ulp, not to the bit)
+        assert rel(got, want) <= 6e-3 or (float(want.abs().max()) < 1e-6 and float(got.abs().max()) < 1e-5)
 
 
 def test_attention_rescale_branch_is_exercised(ops):
