@@ -138,7 +138,8 @@ def main(argv=None, samples=None):
     kw = dict(temperature=a.temperature, top_p=a.top_p, max_new_tokens=a.max_new_tokens)
     if a.fp8:
         assert a.batch_size > 1, "--fp8 runs through the batched generation path"
-        kw.update(fp8=True, fp8_decode=True, fp8_clip=True)
+        v = model.config.vision                      # (the e4m3 GEMM needs K % 128 == 0: every tower GEMM of ViT-L/14 qualifies)
+        kw.update(fp8=True, fp8_decode=True, fp8_clip=(v.hidden_size % 128 == 0 and v.intermediate_size % 128 == 0))
     res = evaluate_traj(model, samples, batch_size=a.batch_size, **kw)
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -208,3 +208,32 @@ def test_reference_written_checkpoint_on_hip(tmp_path):
     valid = torch.ones(2, 379, dtype=torch.bool); valid[1, 374:] = False
     got = out.logits.float().cpu()[:, ::7, ::251][valid[:, ::7]]
     assert rel(got, exp["logits_slice_adapter"][valid[:, ::7].numpy()]) < 1.5e-2
+
+
+def test_entry_points_on_hip(tmp_path, capsys):
+    """SURVEY.md §8 f1 + f2 joined, on the real kernels: `python -m hvlm.train` with the command line of scripts/finetune.sh loads
+    tests/golden/ckpt_tiny through hvlm.checkpoint (handsonvlm/train/train.py:235-240), trains two steps, writes a self-contained
+    checkpoint (tower included, like the reference's full state dict), and `python -m hvlm.evaluate --model-path` loads it back
+    (handsonvlm/evaluation/evaluate.py:18-26).  The CPU twin with the ops stand-in is tests/test_entrypoints_cpu.py."""
+    import json
+    import os
+    from test_ckpt_reference_cpu import inflate
+    from test_entrypoints_cpu import FINETUNE_SH_FLAGS
+    from hvlm import checkpoint, evaluate, train
+    d = inflate(str(tmp_path / "ck"))
+    out = str(tmp_path / "out")
+    torch.manual_seed(0)
+    log = train.main(["--model_name_or_path", d, "--pretrain_mm_mlp_adapter", os.path.join(d, "mm_projector.bin"), "--output_dir", out,
+                      "--num_train_epochs", "1", "--per_device_train_batch_size", "2", "--samples_per_epoch", "4"] + FINETUNE_SH_FLAGS)
+    assert [r["step"] for r in log][-1] == 2 and all(np.isfinite(r["loss"]) for r in log)
+    ck = os.path.join(out, "checkpoint-2")
+    sd = checkpoint.load_state(ck)
+    assert any(k.startswith("model.vision_tower.vision_tower.") for k in sd)           # self-contained
+    assert sd["model.embed_tokens.weight"].shape[0] == 32101
+    capsys.readouterr()
+    res = evaluate.main(["--model-path", ck, "--synthetic", "3", "--batch-size", "3", "--max-new-tokens", "4"])
+    assert set(res) == {"ade", "fde", "wde", "n"} and res["n"] == 3
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["n"] == 3
+    # the same evaluation in e4m3 (BASELINE config 5's switches through the entry point)
+    res8 = evaluate.main(["--model-path", ck, "--synthetic", "3", "--batch-size", "3", "--max-new-tokens", "4", "--fp8"])
+    assert res8["n"] == 3
