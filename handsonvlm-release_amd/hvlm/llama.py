@@ -543,8 +543,7 @@ class LlamaStack:
         assert dhidden.shape == (n_want, self.D), \
             (f"backward: d(hidden) has {tuple(dhidden.shape)}, the forward returned [{n_want}, {self.D}]"
              + (" (last_rows: the stack's last layer ran on the labelled rows only)" if last_rows is not None else ""))
-        dx, dwn = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"])
-        self.norm_g.copy_(dwn)
+        dx, _ = ops.rmsnorm_bwd(dhidden, self.final["x"], self.norm_w, self.final["rstd"], dw_out=self.norm_g)
         for i in range(self.L - 1, -1, -1):
             lp, sv = self.layers[i], self.saved[i]
             if i < self.recompute:
@@ -565,8 +564,7 @@ class LlamaStack:
             dhn = ops.gemm_nt(dgu, lp.wt["gu"])                        # [M,D]
             self._dw(dgu, sv["hn"], lp.g["gu"], mpad, dyT=dguT)
             del dgu, dguT
-            dh, dw2 = ops.rmsnorm_bwd(dhn, sv["h"], lp.w["ln2"], sv["rstd2"], add=dx)
-            lp.g["ln2"].copy_(dw2)
+            dh, _ = ops.rmsnorm_bwd(dhn, sv["h"], lp.w["ln2"], sv["rstd2"], add=dx, dw_out=lp.g["ln2"])
             # ---- attention ----
             dao = ops.gemm_nt(dh, lp.wt["o"])
             self._dw(dh, sv["ao"] if rows is None else sv["ao_v"], lp.g["o"], mpad)
@@ -582,8 +580,7 @@ class LlamaStack:
             dxn = ops.gemm_nt(dqkv, lp.wt["qkv"])
             self._dw(dqkv, sv["xn"], lp.g["qkv"], mpad)
             del dqkv, dao
-            dx, dw1 = ops.rmsnorm_bwd(dxn, sv["x"], lp.w["ln1"], sv["rstd1"], add=dh)
-            lp.g["ln1"].copy_(dw1)
+            dx, _ = ops.rmsnorm_bwd(dxn, sv["x"], lp.w["ln1"], sv["rstd1"], add=dh, dw_out=lp.g["ln1"])
             self.saved[i] = None
             del sv
             self._join_side()

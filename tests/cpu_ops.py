@@ -65,7 +65,7 @@ def rmsnorm_fwd(x, w, eps, save_rstd=True, out=None):
     return y, (rstd.reshape(-1) if save_rstd else None)
 
 
-def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None):
+def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None, dw_out=None):
     D = x.shape[-1]
     xf, dyf = x.float().reshape(-1, D), dy.float().reshape(-1, D)
     xhat = xf * rstd[:, None]
@@ -78,6 +78,9 @@ def rmsnorm_bwd(dy, x, w, rstd, add=None, out=None):
     if out is not None:
         out.copy_(dx)
         dx = out
+    if dw_out is not None:
+        dw_out.copy_(dw)
+        dw = dw_out
     return dx, dw
 
 
