@@ -307,11 +307,12 @@ def cpu_baseline(cfg, T, budget_s=60.0):
             best = c
     torch.set_num_threads(best)
 
-    def timed(fn, share):
-        """3 warm-ups + median of 5.  Only a host so slow that this would blow the budget (one call > share / 8)
-        gets 1 warm-up + median of 3 — and the line says which was run (`warmups`, `reps`)."""
+    def timed(fn, share, want_full=True):
+        """3 warm-ups + median of 5 for the fp32 leg (the reported `value`).  The secondary bf16 leg, and a host so
+        slow that 3 + 5 would blow the budget (one call > share / 8), get 1 warm-up + median of 3 — the line says which was run
+        (`warmups`, `reps`)."""
         t0 = time.perf_counter(); fn(); first = time.perf_counter() - t0
-        full = first * 8 <= share
+        full = want_full and first * 8 <= share
         for _ in range(2 if full else 0):
             fn()
         ts = []
@@ -355,9 +356,10 @@ def cpu_baseline(cfg, T, budget_s=60.0):
             with torch.no_grad():
                 R.clip_layer(xc, cp, cpre, v.num_attention_heads)
         share = max(2.0, (budget_s - (time.perf_counter() - t_start)) * (0.62 if name == "fp32" else 1.0))
-        t_llama, w1, n1 = timed(llama_step, 0.65 * share)
-        t_head, w2, n2 = timed(head_step, 0.30 * share)
-        t_clip10, w3, n3 = timed(clip_step, 0.05 * share)
+        full = name == "fp32"
+        t_llama, w1, n1 = timed(llama_step, 0.65 * share, full)
+        t_head, w2, n2 = timed(head_step, 0.30 * share, full)
+        t_clip10, w3, n3 = timed(clip_step, 0.05 * share, full)
         per_sample = cfg.num_hidden_layers * t_llama + t_head + n_clip_layers * (cfg.num_frames / 10.0) * t_clip10
         out[name] = dict(samples_per_s=1.0 / per_sample, layer_fwd_bwd_s=t_llama, lm_head_fwd_bwd_s=t_head,
                          clip_layer_10_frames_s=t_clip10, warmups=min(w1, w2, w3), reps=min(n1, n2, n3))
