@@ -537,7 +537,7 @@ def other_configs(args):
     import subprocess
     runs = {
         "config2_7b_inference_336px_b1": ["--eval-only", "--image-size", "336"],
-        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "2", "--warmup", "2", "--no-eval",
+        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "3", "--warmup", "2", "--no-eval",
                                      "--no-cpu-baseline", "--no-gemm-events"],
         # the headline workload with EXACT frame de-duplication: the reference's EK100 dataset always hands the model 10 distinct
         # frames tiled to 100 (handsonvlm/dataset/epic_dataset.py:90-95: image.unsqueeze(0).repeat(10, ...).reshape(100, ...)) and
