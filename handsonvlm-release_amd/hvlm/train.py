@@ -72,6 +72,7 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
     step, t0, log = 0, time.perf_counter(), []
     if resume is not None:
         step = int(checkpoint.load_training_state(opt, resume, rank)["global_step"])
+    logged_at = step                       # (samples_per_s of a log record = the steps since the previous record)
     last_saved = step if resume is not None else -1
 
     def save():
@@ -111,8 +112,8 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
             step += 1
             if step % log_every == 0 or step == total:
                 rec = dict(step=step, loss=float(out.loss.detach()), **{k: float(v) for k, v in out.loss_components.items()},
-                           samples_per_s=world * per_device_batch * log_every / (time.perf_counter() - t0))
-                t0 = time.perf_counter()
+                           samples_per_s=world * per_device_batch * (step - logged_at) / (time.perf_counter() - t0))
+                t0, logged_at = time.perf_counter(), step
                 log.append(rec)
                 if rank == 0:
                     print(json.dumps(rec), flush=True)
