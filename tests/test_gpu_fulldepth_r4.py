@@ -17,6 +17,8 @@ and the whole backward — against the CPU oracle (oracle/ref_cpu.py, fp32) on t
       against bf16 and against the fp32 oracle, and the ADE / FDE / WDE shift of fp8-prefill / all-fp8 generation against bf16 with
       pinned CVAE noise.
   (d) 13B (L = 40, D = 5120, H = 40, F = 13824), S = 2048 (BASELINE config 4), forward-only loss and final hidden vs the oracle.
+  (e) the KV-cached decode path at full depth: prefill of 600 rows + 6 single-token steps on the 32-layer model, every step's hidden
+      state vs the oracle's row of that position.
 
 Numbers go to gpurun_out/fulldepth_report.json (committed as profiles/r04*_fulldepth_report.json) and DESIGN.md §4."""
 import gc
@@ -373,6 +375,50 @@ def test_c_7b_fp8_at_depth_on_outlier_channel_weights(seven_b):
     for name in ("fp8_prefill", "fp8_prefill_decode", "all_fp8"):
         assert max(rep["gen"][name]["metric_rel_shift"]) <= 0.03, (name, rep["gen"][name])
         assert rep["gen"][name]["mean_point_deviation"] <= 0.03, (name, rep["gen"][name])
+
+
+def test_e_7b_kv_cached_decode_at_full_depth_vs_oracle(seven_b, monkeypatch):
+    """The batch-1 KV-cached generation path (model.sample: prefill + hvlm_llama_decode_step per token — the build's replacement for
+    the reference's cache-less loop, handsonvlm.py:543-647) at FULL depth: 32 layers of 7B width, prefill of 600 spliced rows
+    (visual tokens + text), then 6 single-token steps, each step's final hidden state against the oracle's row of the same position
+    (a causal decoder's row t depends on rows <= t only, so R.llama_model over the whole 606-row sequence IS the reference's t-th
+    re-run at its last position).  Envelope: the oracle's bf16-eager run.  tests/test_gpu_decode_r3.py does this on 2 layers."""
+    st = seven_b
+    m, cfg, bt = st["m"], st["cfg"], st["bt"]
+    from hvlm import ops
+    monkeypatch.setenv("HVLM_DECODE_GRAPH", "0")
+    S0, n = 600, 6
+    with torch.no_grad():
+        vis = m.visual_tokens(bt["images"].cuda())
+        plan = m.build_splice_plan(bt["ids"], None, vis.shape[1], 0, True, False)
+        x = ops.embed_splice_fwd(m.embed, vis, plan.src, None, None, None, 1, plan.S, m.token_dim, vis.shape[1], 1)[: S0 + n].contiguous()
+        stk = m.stack
+        stk._kv_cache, stk._dec_tables = None, None
+        cache = stk.new_cache(S0 + n + 1)
+        for c in cache:
+            c.copy_(torch.full(c.shape, float("nan"), device="cuda", dtype=BF))      # a row read before it is written poisons the result
+        got = [stk.forward(x[:S0].contiguous(), 1, S0, save=False, cache=cache)[S0 - 1].clone()]
+        for t in range(n):
+            got.append(stk.decode_step(x[S0 + t:S0 + t + 1].contiguous(), S0 + t, cache).view(-1).clone())
+        torch.cuda.synchronize()
+        stk._kv_cache, stk._dec_tables = None, None
+    got = torch.stack(got).float().cpu()
+    rows = [S0 - 1] + [S0 + t for t in range(n)]
+    xs = x.float().cpu()[None]
+    res = {}
+    with _threads(), torch.no_grad():
+        for name, dt in (("fp32", torch.float32), ("bf16", BF)):
+            p = {k: v.detach().to("cpu", dt) for k, v in stk.export_hf("model.").items()}
+            res[name] = R.llama_model(xs.to(dt), p, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.rms_norm_eps)[0][rows].float()
+            del p
+            gc.collect()
+    rep = {"rows": rows, "hip_vs_fp32_oracle": [rel(got[i], res["fp32"][i]) for i in range(len(rows))],
+           "bf16_eager_oracle_vs_fp32_oracle": [rel(res["bf16"][i], res["fp32"][i]) for i in range(len(rows))]}
+    REPORT["e_7b_L32_kv_decode"] = rep
+    print(json.dumps(rep, indent=1))
+    assert torch.isfinite(got).all()
+    for h, e in zip(rep["hip_vs_fp32_oracle"], rep["bf16_eager_oracle_vs_fp32_oracle"]):
+        assert h <= 1.5 * e + 1e-3 and h < 6e-2, (h, e)
 
 
 def test_d_13b_L40_S2048_forward_vs_oracle():
