@@ -234,13 +234,17 @@ class CLIPVisionTower:
         T = NP + 1
         x_img = images.to(device=self.device, dtype=BF16).contiguous()
         f16 = self.wdtype == torch.float16
-        if f16:
-            x_img = ops.cast16(x_img, torch.float16)               # images.to(dtype=self.dtype), clip_encoder.py:48
         mm = ops.gemm_f16_nt if f16 else ops.gemm_nt
         ln = ops.layernorm_fwd_f16 if f16 else ops.layernorm_fwd
-        patches = ops.patch_im2col(x_img.view(BF16) if f16 else x_img, cfg.patch_size, self.kpad)    # 2-byte moves: dtype-agnostic
-        if f16:
-            patches = patches.view(torch.float16)
+        even = cfg.patch_size % 2 == 0 and cfg.image_size % 2 == 0 and 3 * cfg.patch_size * cfg.image_size * 2 <= 64 * 1024
+        if f16 and even:
+            # images.to(dtype=self.dtype) (clip_encoder.py:48) rides in the im2col gather: no separate cast pass over the frames
+            patches = ops.patch_im2col(x_img, cfg.patch_size, self.kpad, to_f16=True)
+        elif f16:
+            x_img = ops.cast16(x_img, torch.float16)
+            patches = ops.patch_im2col(x_img.view(BF16), cfg.patch_size, self.kpad).view(torch.float16)    # 2-byte moves: dtype-agnostic
+        else:
+            patches = ops.patch_im2col(x_img, cfg.patch_size, self.kpad)
         pe = mm(patches, p["patch_w"])
         del patches
         x = (ops.clip_embed_f16 if f16 else ops.clip_embed)(pe, p["cls"], p["pos"], N, NP, d).view(N * T, d)

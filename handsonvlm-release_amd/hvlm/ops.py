@@ -614,13 +614,16 @@ def swiglu_bwd(gu, dact, out=None):
 # ------------------------------------------------------------------------------------------------
 # visual pipeline
 # ------------------------------------------------------------------------------------------------
-def patch_im2col(images: torch.Tensor, P: int, kpad: int) -> torch.Tensor:
+def patch_im2col(images: torch.Tensor, P: int, kpad: int, to_f16: bool = False) -> torch.Tensor:
+    """bf16 frames [N, 3, HW, HW] -> patch rows [N * (HW/P)^2, kpad]: bf16, or (to_f16) IEEE half — the frames' cast to the
+    fp16 tower's dtype applied on the way through."""
     _chk(images, BF16, "im2col.images")
     assert images.is_contiguous() and images.dim() == 4 and images.shape[1] == 3
     N, _, HW, _ = images.shape
     G = HW // P
-    out = torch.empty((N * G * G, kpad), dtype=BF16, device=images.device)
-    check(_lib.load().hvlm_patch_im2col(_p(images), _p(out), N, HW, P, kpad, _stream()), "patch_im2col")
+    out = torch.empty((N * G * G, kpad), dtype=torch.float16 if to_f16 else BF16, device=images.device)
+    fn = _lib.load().hvlm_patch_im2col_f16 if to_f16 else _lib.load().hvlm_patch_im2col
+    check(fn(_p(images), _p(out), N, HW, P, kpad, _stream()), "patch_im2col")
     return out
 
 

@@ -323,6 +323,9 @@ int hvlm_swiglu_bwd_t(const void* gu, const void* dact, void* dgu, void* dguT, i
 /* im2col for the CLIP patch-embed conv (kernel = stride = P, no bias): images bf16
  * [N,3,HW,HW] -> patches bf16 [N*(HW/P)^2, Kpad] (K = 3*P*P, zero-padded to Kpad). */
 int hvlm_patch_im2col(const void* images, void* patches, int N, int HW, int P, int Kpad, void* stream);
+/* The same with bf16 frames in and IEEE-half patches out: images.to(dtype=self.dtype) of clip_encoder.py:48 applied on the way
+ * through (bit-identical to hvlm_cast_bf16_to_f16 followed by hvlm_patch_im2col).  P, HW, Kpad even. */
+int hvlm_patch_im2col_f16(const void* images, void* patches, int N, int HW, int P, int Kpad, void* stream);
 /* tokens[n, 0, :] = cls + pos[0];  tokens[n, 1+p, :] = patch_out[n*NP+p, :] + pos[1+p]
  * (transformers CLIPVisionEmbeddings). */
 int hvlm_clip_embed(const void* patch_out, const void* cls, const void* pos, void* tokens, int N,

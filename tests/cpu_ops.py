@@ -237,12 +237,12 @@ def swiglu_bwd_t(gu, dact, r_pad):
     return dgu, transpose(dgu, r_pad=r_pad)
 
 
-def patch_im2col(images, P, kpad):
+def patch_im2col(images, P, kpad, to_f16=False):
     N, _, HW, _ = images.shape
     G = HW // P
     x = images.reshape(N, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(N * G * G, 3 * P * P)
-    out = torch.zeros((N * G * G, kpad), dtype=BF16)
-    out[:, : 3 * P * P] = x
+    out = torch.zeros((N * G * G, kpad), dtype=torch.float16 if to_f16 else BF16)
+    out[:, : 3 * P * P] = x.to(out.dtype)
     return out
 
 

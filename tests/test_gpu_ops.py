@@ -265,11 +265,13 @@ def test_llama_layer_dh128_vs_reference_golden(ops, golden):
     orig = o.rmsnorm_bwd
     calls = {"n": 0}
 
-    def first_identity(dyy, xx, w, rstd, add=None, out=None):
+    def first_identity(dyy, xx, w, rstd, add=None, out=None, dw_out=None):
         calls["n"] += 1
         if calls["n"] == 1:
+            if dw_out is not None:
+                dw_out.zero_()
             return dyy, torch.zeros(256, dtype=BF, device="cuda")
-        return orig(dyy, xx, w, rstd, add=add, out=out)
+        return orig(dyy, xx, w, rstd, add=add, out=out, dw_out=dw_out)
 
     o.rmsnorm_bwd = first_identity
     try:

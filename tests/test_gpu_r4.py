@@ -98,3 +98,22 @@ def test_model_switch_changes_nothing_but_rounding(golden):
     for n in ("proj_w", "proj_b", "layers.0.qkv", "embed"):
         assert rel(g1_[n], g0_[n]) < 2e-2, (n, rel(g1_[n], g0_[n]))
     assert rel(g1_["proj_w"], g3["g_proj_w"]) < 3e-2 and rel(g1_["proj_b"], g3["g_proj_b"]) < 3e-2
+
+
+@pytest.mark.parametrize("N,HW,P", [(3, 224, 14), (2, 336, 14), (2, 28, 14), (2, 35, 7)])
+def test_im2col_strip_kernel_exact(N, HW, P):
+    """hvlm_patch_im2col (coalesced strip kernel for even P / HW, the element-wise kernel otherwise) and hvlm_patch_im2col_f16 (the
+    frames' cast to the tower's fp16 applied on the way through, clip_encoder.py:48): a pure gather — bit-exact against the unfold
+    of the frames, the fp16 form equal to casting the frames first; the K padding is zero."""
+    from hvlm import ops
+    g = torch.Generator(device="cuda").manual_seed(N * HW)
+    img = (torch.randn(N, 3, HW, HW, device="cuda", generator=g) * 2.0).to(BF)
+    G, K = HW // P, 3 * P * P
+    kpad = (K + 63) // 64 * 64
+    want = img.reshape(N, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(N * G * G, K)
+    got = ops.patch_im2col(img, P, kpad)
+    assert got.shape == (N * G * G, kpad) and torch.equal(got[:, :K], want) and float(got[:, K:].abs().max() if kpad > K else 0.0) == 0.0
+    if P % 2 == 0 and HW % 2 == 0:
+        got16 = ops.patch_im2col(img, P, kpad, to_f16=True)
+        assert got16.dtype == F16 and torch.equal(got16[:, :K], want.to(F16)) and float(got16[:, K:].abs().max() if kpad > K else 0.0) == 0.0
+        assert torch.equal(got16, ops.patch_im2col(ops.cast16(img, F16).view(BF), P, kpad).view(F16))
