@@ -99,6 +99,22 @@ __device__ PPSched g_pp_all[PP_NSCHED];
 
 #define HVLM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// -DHVLM_GEMM_PROF (tools/gemm_tile_timeline.sh; never in the shipped libraries): s_memtime stamps of the tile cycle — for the
+// workgroups on XCD 0's first 8 CUs, every wave, the first 32 tiles: [0] loop top, [1] K loop done, [2] epilogue entered, [3] epilogue
+// done, [4] next-unit bookkeeping done, [5] first K-tile done, [6..9] residual epilogue: row fragment i entered, [10] its loop left.  The stamp stores are untracked 8-byte stores by lane 0.
+#ifdef HVLM_GEMM_PROF
+__device__ unsigned long long g_pp_prof[8][8][32][12];
+#define HVLM_PP_STAMP(k)                                                                                              \
+  do {                                                                                                                \
+    if ((blockIdx.x & 7) == 0 && blockIdx.x < 64 && it < 32 && l == 0) {                                             \
+      const unsigned long long t_ = __builtin_readcyclecounter();                                                     \
+      asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(&g_pp_prof[blockIdx.x >> 3][w][it][k]), "v"(t_) : "memory"); \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define HVLM_PP_STAMP(k) do {} while (0)
+#endif
+
 // TN = both operands K-strided: A is [K, M] (element (m,k) at A[k*lda + m]), B is [K, N].  This is dW = dY^T X on the
 // activations exactly as the forward / backward passes left them (token-major): no transposed copies.  What changes:
 //   * a half-tile is 64 k-rows x 128 columns (256-B LDS rows), a DMA piece = 4 k-rows;
@@ -189,20 +205,35 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     const int t = cnt % wg_x;
     return (t > 0 && 2 * t <= wg_x) ? t : 0;
   };
-  auto fetch_unit = [&]() -> int {          // one lane
-    for (int a = 0; a < 8; ++a) {
-      const int x = (my_xcd + a) & 7;
-      const int cnt = ch_q + (x < ch_r ? 1 : 0);
-      const int tl = chunk_tail(cnt), full = cnt - tl;
-      const unsigned i = __hip_atomic_fetch_add(&g_pp.ctr[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int)i < full) return chunk_start(x) + (int)i;
-      if ((int)i < full + 2 * tl) {
-        const int v = (int)i - full;
-        return (chunk_start(x) + full + (v >> 1)) | ((1 + (v & 1)) << 28);
-      }
+  // A fetch is split in two so that its round trip (1300 - 3200 cycles measured per tile, tools/gemm_tile_timeline.py: wave 0 stalled
+  // in front of its epilogue and the other waves then waited for it at the next tile's first barrier) hides under the epilogue:
+  // fetch_issue() = the atomic on the workgroup's own XCD counter, fetch_resolve(i) = everything that needs its result (and, once
+  // that chunk is exhausted — the last tiles of a launch — the synchronous walk over the other XCDs' counters).
+  auto unit_of = [&](int x, unsigned i) -> int {      // the unit ticket i of XCD x's counter stands for, -1: chunk exhausted
+    const int cnt = ch_q + (x < ch_r ? 1 : 0);
+    const int tl = chunk_tail(cnt), full = cnt - tl;
+    if ((int)i < full) return chunk_start(x) + (int)i;
+    if ((int)i < full + 2 * tl) {
+      const int v = (int)i - full;
+      return (chunk_start(x) + full + (v >> 1)) | ((1 + (v & 1)) << 28);
     }
     return -1;
   };
+  // (atomic INC with a wrap bound of 2^32 - 1 = fetch-and-add 1: LLVM's atomic optimizer rewrites a one-lane atomic ADD into a wave
+  // reduction whose broadcast — s_waitcnt vmcnt(0) ; v_readfirstlane — sits right behind the instruction, i.e. the stall this split
+  // is meant to remove; it leaves INC alone, and the result is then waited for at its first use)
+  auto fetch_issue = [&]() -> unsigned {    // one lane
+    return __builtin_amdgcn_atomic_inc32(&g_pp.ctr[my_xcd][0], 0xffffffffu, __ATOMIC_RELAXED, "agent");
+  };
+  auto fetch_resolve = [&](unsigned i0) -> int {
+    int u = unit_of(my_xcd, i0);
+    for (int a = 1; a < 8 && u < 0; ++a) {
+      const int x = (my_xcd + a) & 7;
+      u = unit_of(x, __hip_atomic_fetch_add(&g_pp.ctr[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return u;
+  };
+  auto fetch_unit = [&]() -> int { return fetch_resolve(fetch_issue()); };
   int t_cur, t_nxt;                        // swizzled unit index of the tile being computed / the one after (-1: none)
   constexpr int BKE = BK * 2 / ES;          // K-tile in elements: 64 bf16 or 128 fp8 (128 bytes either way)
   const int nk = TN ? (p.K + BK - 1) / BK : (p.splits > 1 ? p.k_split : p.K) / BKE;
@@ -411,6 +442,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   using T2 = std::integral_constant<int, 2>; using T3 = std::integral_constant<int, 3>;
 
   f32x16 acc[2][4];                       // [column half j][row fragment i]
+  unsigned it = 0;                        // tiles done by this workgroup
 
   // ---- epilogues: register quad g (registers 4g..4g+3) of a 32x32 fragment = 4 consecutive columns of ONE row:
   //   32x32x16: row l31 of the fragment, columns 8g + 4hi ..;   16x16x32 (M16): quadrant g = 2*(column half) + (row half):
@@ -856,7 +888,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   };
 
   // ---- prologue: K-tile 0 (4 half-tiles) and A0,B0 of K-tile 1 in flight -------------------------
-  unsigned it = 0;                        // tiles done by this workgroup
   if (dyn) {
     // wave 0 draws the first three units; the first two are needed by everyone right away (through LDS, free now)
     int* lq = reinterpret_cast<int*>(smem);
@@ -954,10 +985,13 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   } while (0)
   // 16x16x32 form of the 16-MFMA segment: 4 (j, i) fragments x 4 quadrants x 2 k-halves = 32 MFMAs of 16 cycles.  A
   // quadrant t = 2*sb + sa of acc[j][i] (registers 4t..4t+3) += W-block sb (16 output columns, MFMA A) x X-block sa (16 rows, B).
+  constexpr bool PEEL = M16;               // first K-tile peeled, C = 0 by inline constant (see the tile loop)
   constexpr int NKH16 = FP8 ? 1 : 2;      // MFMA k-steps per K-tile in the 16x16 form (fp8: one 16x16x128; 16-bit: two 16x16x32)
-  auto mfma16 = [&](f32x16& c, int t, const frag_t& wf, const frag_t& xf) {
+  // `zero`: the first k-step of a tile takes C = 0 as the MFMA's inline constant instead of reading a zeroed accumulator (PEEL below)
+  auto mfma16 = [&](f32x16& c, int t, const frag_t& wf, const frag_t& xf, bool zero) {
     if constexpr (M16) {
       f32x4 q = {c[4 * t], c[4 * t + 1], c[4 * t + 2], c[4 * t + 3]};
+      if (zero) q = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (FP8) q = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf, xf, q, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       else if constexpr (F16) q = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), q, 0, 0, 0);
       else q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, q, 0, 0, 0);
@@ -967,15 +1001,15 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #define HVLM_MFMA_OCT16(I0, AF0, AF1)                                                                     \
   do {                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                    \
-    asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1]));      \
+    if constexpr (!FIRSTK) asm volatile("" : "+v"(acc[0][I0]), "+v"(acc[0][I0 + 1]), "+v"(acc[1][I0]), "+v"(acc[1][I0 + 1])); \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int ks2_ = 0; ks2_ < NKH16; ++ks2_) {                                          \
       _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
         const int sb_ = t_ >> 1, sa_ = t_ & 1;                                                            \
-        mfma16(acc[0][I0], t_, fb0[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_]);                         \
-        mfma16(acc[0][I0 + 1], t_, fb0[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_]);                     \
-        mfma16(acc[1][I0], t_, fb1[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_]);                         \
-        mfma16(acc[1][I0 + 1], t_, fb1[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_]);                     \
+        mfma16(acc[0][I0], t_, fb0[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_], FIRSTK && ks2_ == 0);     \
+        mfma16(acc[0][I0 + 1], t_, fb0[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_], FIRSTK && ks2_ == 0); \
+        mfma16(acc[1][I0], t_, fb1[sb_ * NKH16 + ks2_], AF0[sa_ * NKH16 + ks2_], FIRSTK && ks2_ == 0);     \
+        mfma16(acc[1][I0 + 1], t_, fb1[sb_ * NKH16 + ks2_], AF1[sa_ * NKH16 + ks2_], FIRSTK && ks2_ == 0); \
       }                                                                                                   \
     }                                                                                                     \
     __builtin_amdgcn_s_setprio(0);                                                                        \
@@ -990,19 +1024,26 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   } while (0)
 
   while (true) {
+    HVLM_PP_STAMP(0);
+    // PEEL (the 16x16 kernels): no zeroing pass over the 128 accumulator registers at the top of a tile (128 v_mov per wave, two waves
+    // per SIMD: ~1000 cycles before the first MFMA of the tile, tools/gemm_tile_timeline.py) — the first K-tile is a copy of the loop
+    // body whose first k-step passes C = 0 to the MFMA as an inline constant; same sums, bit for bit
+    if constexpr (!PEEL) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+          for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    }
     if (grp == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
     // hm = 0: the whole tile; 1 / 2: a half-tile unit — only MFMA segment A (rows 0-127) / B (rows 128-255) and its fragment
     // reads are issued, everything else (staging, barriers, cursors) is the same code.  Three copies of the loop, so that the
     // whole-tile loop is compiled exactly as before.
-    auto run_k = [&](auto hm_tag) {
+    auto ktile = [&](auto hm_tag, auto first_tag, const int kt) {
     constexpr int HM = decltype(hm_tag)::value;
-    for (int kt = 0; kt < nk; ++kt, ++g) {
+    constexpr bool FIRSTK = decltype(first_tag)::value != 0;
+    {
       const unsigned cb = g & 1u, ob = cb ^ 1u;
       const unsigned sb = cb * STAGE_BYTES;
       frag_t fb0[NKS], fb1[NKS], fa0[NKS], fa1[NKS];
@@ -1089,21 +1130,35 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
         advance(c2);
       }
       if (!(grp == 1 && kt + 1 == nk)) __builtin_amdgcn_s_barrier();   // group 1 re-aligns at the epilogue
+#ifdef HVLM_GEMM_PROF
+      if (kt == 0) HVLM_PP_STAMP(5);
+#endif
     }
-    };   // run_k
+    };   // ktile
+    auto run_k = [&](auto hm_tag) {
+      if constexpr (PEEL) {
+        ktile(hm_tag, T1{}, 0);
+        ++g;
+        for (int kt = 1; kt < nk; ++kt, ++g) ktile(hm_tag, T0{}, kt);
+      } else {
+        for (int kt = 0; kt < nk; ++kt, ++g) ktile(hm_tag, T0{}, kt);
+      }
+    };
     const int half = HALF_OK ? (t_cur >> 28) : 0;          // (wave-uniform: t_cur is)
     if constexpr (HALF_OK) {
       if (half == 0) run_k(T0{}); else if (half == 1) run_k(T1{}); else run_k(T2{});
     } else {
       run_k(T0{});
     }
+    HVLM_PP_STAMP(1);
     int m0, n0, ksl;
     tile_coords(t_cur, m0, n0, ksl);
     // dynamic mode: wave 0 draws the unit three tiles ahead and parks it in this workgroup's ring (an untracked store, see
     // store16_untracked); every wave picks up the unit two tiles ahead, parked one tile ago (L1-bypassing load)
-    int t_aft_v = -1, u_fetched = 0;
+    int t_aft_v = -1;
+    unsigned u_ticket = 0;
     if (dyn) {
-      if (w == 0 && l == 0) u_fetched = fetch_unit();          // result is only needed after the epilogue
+      if (w == 0 && l == 0) u_ticket = fetch_issue();          // its result is consumed after the epilogue (fetch_resolve)
       t_aft_v = __hip_atomic_load(&g_pp.slots[blockIdx.x][(it + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (FP8) {
@@ -1146,16 +1201,20 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             for (int e = 0; e < 4; ++e) acc[j][i][4 * g4 + e] *= rs * csv[j][g4][e];
           }
     }
+    HVLM_PP_STAMP(2);
     epilogue(m0, n0, (size_t)ksl * p.slab, half == 2 ? 2 : 0, half == 1 ? 2 : 4);
+    HVLM_PP_STAMP(3);
     int t_aft = -1;
     asm volatile("" : "+v"(t_aft_v));       // retire the slot load here: left pending, it puts a vmcnt(0) into the K loop
     if (dyn) {
       if (w == 0 && l == 0) {
+        const int u_fetched = fetch_resolve(u_ticket);
         int* sp = &g_pp.slots[blockIdx.x][(it + 3) & 3];
         asm volatile("global_store_dword %0, %1, off" ::"v"(sp), "v"(u_fetched) : "memory");
       }
       t_aft = __builtin_amdgcn_readfirstlane(t_aft_v);
     }
+    HVLM_PP_STAMP(4);
     ++it;
     if (dyn) {
       if (t_nxt < 0) break;
@@ -1276,4 +1335,14 @@ int launch_gemm_pp_fp8(const GemmArgs& p, int grid, hipStream_t stream) {
 
 }  // namespace hvlm
 
+#ifdef HVLM_GEMM_PROF
+extern "C" int hvlm_debug_gemm_prof(void* host_dst, int clear) {
+  if (clear) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(hvlm::g_pp_prof)) != hipSuccess) return 1;
+    return hipMemset(dptr, 0, sizeof(hvlm::g_pp_prof)) == hipSuccess ? 0 : 1;
+  }
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(hvlm::g_pp_prof), sizeof(hvlm::g_pp_prof)) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" size_t hvlm_gemm_sched_ws_bytes(void) { return sizeof(hvlm::PPSched) * hvlm::PP_NSCHED; }
