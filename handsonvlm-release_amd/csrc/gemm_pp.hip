@@ -1040,10 +1040,23 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     // hm = 0: the whole tile; 1 / 2: a half-tile unit — only MFMA segment A (rows 0-127) / B (rows 128-255) and its fragment
     // reads are issued, everything else (staging, barriers, cursors) is the same code.  Three copies of the loop, so that the
     // whole-tile loop is compiled exactly as before.
+    // Next-unit bookkeeping of the tile, issued at the top of its LAST K-tile and consumed right behind the K loop (a K-tile of latency
+    // for both round trips): wave 0's ticket for the unit three tiles ahead (fetch_issue) and everyone's load of the unit two tiles ahead
+    // from the workgroup's ring.  Round 4 (tools/gemm_tile_timeline.py): consumed behind the epilogue, their wait was a vmcnt(0) that
+    // also waited for the tile's 16 stores per wave to be acknowledged — ~800 cycles per tile on every wave.
+    int m0 = 0, n0 = 0, ksl = 0, t_aft_v = -1;
+    unsigned u_ticket = 0;
     auto ktile = [&](auto hm_tag, auto first_tag, const int kt) {
     constexpr int HM = decltype(hm_tag)::value;
     constexpr bool FIRSTK = decltype(first_tag)::value != 0;
     {
+      if (kt + 1 == nk) {
+        tile_coords(t_cur, m0, n0, ksl);
+        if (dyn) {
+          if (w == 0 && l == 0) u_ticket = fetch_issue();
+          t_aft_v = __hip_atomic_load(&g_pp.slots[blockIdx.x][(it + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       const unsigned cb = g & 1u, ob = cb ^ 1u;
       const unsigned sb = cb * STAGE_BYTES;
       frag_t fb0[NKS], fb1[NKS], fa0[NKS], fa1[NKS];
@@ -1151,15 +1164,16 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       run_k(T0{});
     }
     HVLM_PP_STAMP(1);
-    int m0, n0, ksl;
-    tile_coords(t_cur, m0, n0, ksl);
-    // dynamic mode: wave 0 draws the unit three tiles ahead and parks it in this workgroup's ring (an untracked store, see
-    // store16_untracked); every wave picks up the unit two tiles ahead, parked one tile ago (L1-bypassing load)
-    int t_aft_v = -1;
-    unsigned u_ticket = 0;
+    // dynamic mode: wave 0 parks the unit three tiles ahead in this workgroup's ring (an untracked store, see store16_untracked);
+    // every wave picked up the unit two tiles ahead, parked one tile ago (L1-bypassing load)
+    int t_aft = -1;
     if (dyn) {
-      if (w == 0 && l == 0) u_ticket = fetch_issue();          // its result is consumed after the epilogue (fetch_resolve)
-      t_aft_v = __hip_atomic_load(&g_pp.slots[blockIdx.x][(it + 2) & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == 0 && l == 0) {
+        const int u_fetched = fetch_resolve(u_ticket);
+        int* sp = &g_pp.slots[blockIdx.x][(it + 3) & 3];
+        asm volatile("global_store_dword %0, %1, off" ::"v"(sp), "v"(u_fetched) : "memory");
+      }
+      t_aft = __builtin_amdgcn_readfirstlane(t_aft_v);
     }
     if constexpr (FP8) {
       // de-quantisation: tensor scale (alpha) x per-token scale of the row x per-output-channel scale of the column
@@ -1204,16 +1218,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     HVLM_PP_STAMP(2);
     epilogue(m0, n0, (size_t)ksl * p.slab, half == 2 ? 2 : 0, half == 1 ? 2 : 4);
     HVLM_PP_STAMP(3);
-    int t_aft = -1;
-    asm volatile("" : "+v"(t_aft_v));       // retire the slot load here: left pending, it puts a vmcnt(0) into the K loop
-    if (dyn) {
-      if (w == 0 && l == 0) {
-        const int u_fetched = fetch_resolve(u_ticket);
-        int* sp = &g_pp.slots[blockIdx.x][(it + 3) & 3];
-        asm volatile("global_store_dword %0, %1, off" ::"v"(sp), "v"(u_fetched) : "memory");
-      }
-      t_aft = __builtin_amdgcn_readfirstlane(t_aft_v);
-    }
     HVLM_PP_STAMP(4);
     ++it;
     if (dyn) {

@@ -6,7 +6,7 @@ for r in 1 2; do
   echo "== new";  python3 tools/clip_epi_bench.py 2>&1 | grep -v amdgpu.ids
 done | tee gpurun_out/r04q_clip_epi_ab.txt
 HVLM_LIB=handsonvlm-release_amd/lib/libhvlm_hip_prof.so python3 tools/gemm_tile_timeline.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r04p_gemm_tile_timeline.txt
-grep -E "^==|first_ktile|tile period" gpurun_out/r04p_gemm_tile_timeline.txt | cut -c1-150
+grep -E "^==|first_ktile|tile period|pre_epi|post_epi|epilogue  " gpurun_out/r04p_gemm_tile_timeline.txt | cut -c1-150
 timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_parity_r2.py tests/test_gpu_r4.py -q -x -m gpu 2>&1 | tail -5
 B="python bench.py --no-cpu-baseline --no-eval --no-other-configs --steps 6 --warmup 2"
 for r in 1 2; do
