@@ -623,13 +623,19 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
       }
     }
   };
+  // PEEL (the 16x16 kernels, see the tile loop): every epilogue path holds ONE full vmcnt(0) before its first store — behind the loads
+  // it needs itself (bias, LayerNorm-fold vectors, first residual fragment), so that their latency and the landing of the pieces
+  // staged for the next tile's first K-tile (HVLM_PHASE_SYNC_K relies on it) are waited for together
+  auto staged_landed = [&]() { if constexpr (M16) __builtin_amdgcn_s_waitcnt(0x0F70); };
   auto epilogue = [&](int m0, int n0, size_t c_slab, int i_lo, int i_hi) {   // row fragments i_lo .. i_hi - 1 (a half-tile unit: 2 of 4)
     if (!fast_ok || n0 + BN > p.N) {
+      staged_landed();
       epilogue_generic(m0, n0, c_slab, i_lo, i_hi);
       __builtin_amdgcn_s_waitcnt(0x0F70);   // tracked stores must not be pending at the top of the K loop (see above)
       return;
     }
     if constexpr (EPI_SWAP) {
+      staged_landed();
       epilogue_swap(m0, n0, i_lo, i_hi);
       return;
     } else {
@@ -685,6 +691,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
             }
         }
       }
+      staged_landed();
       // The loop below exists in a few SPECIALISATIONS of (bias, QuickGELU, LayerNorm fold): with the three as run-time flags the
       // compiler emitted a scalar branch around every 4-element group, four v_cndmask per group for the fold select, and ran the
       // exp -> add -> rcp chain of one element at a time behind s_nop hazards.  (1 / 0 = known at compile time, -1 = run time.)
@@ -801,6 +808,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     const bool hb = HBc >= 0 ? (HBc == 1) : (p.bias != nullptr);
     const bool gelu = HBc >= 0 ? false : (p.act == HVLM_ACT_QUICK_GELU);      // the specialised forms are dispatched for act == NONE only
     load_res(i_lo, res_n);
+    staged_landed();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < i_lo || i >= i_hi) continue;
@@ -1174,7 +1182,6 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     } else {
       run_k(T0{});
     }
-    if constexpr (PEEL) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every staged piece has landed (HVLM_PHASE_SYNC_K), ticket and slot too
     HVLM_PP_STAMP(1);
     // dynamic mode: wave 0 parks the unit three tiles ahead in this workgroup's ring (an untracked store, see store16_untracked);
     // every wave picked up the unit two tiles ahead, parked one tile ago (L1-bypassing load)
