@@ -11,5 +11,5 @@ python - <<'PY'
 import json
 for r in (1,2,3):
   for f in ("base","new"):
-    d=json.load(open(f"gpurun_out/r04s_{f}{r}.json")); print(f, r, round(d["ms_per_step"],1), d["step_ms"], round(d["loss"],4), round(d["roofline"]["achieved"],1))
+    d=json.load(open(f"gpurun_out/r04s_{f}{r}.json")); print(f, r, round(d["ms_per_step"],1), d["step_ms"], round(d["loss"],4), round(d["roofline"]["achieved"],1), round(d["box_calibration"]["gemm_13872x12288x4096_bf16_tflops"],1))
 PY
