@@ -759,7 +759,7 @@ def main():
     barrier()
     # Box calibration (outside the timed region): the decoder's largest GEMM, isolated, on this GPU right now.  The boxes of one pool
     # differ by up to 7 % in the GEMM rate they sustain under the power cap; this one number lets two bench lines from different
-    # boxes be compared (the kernel is unchanged since round 2: 1383-1391 TFLOP/s on the boxes profiled then).
+    # boxes of ONE build be compared (the kernel changed in round 4: ~2.5 % faster on a given box than in rounds 2-3).
     calib = None
     if args.model in ("7b", "13b") and not args.no_gemm_events:
         try:
@@ -775,7 +775,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             calib = {"gemm_13872x12288x4096_bf16_tflops": 20 * 2.0 * 13872 * 12288 * 4096 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
-                     "note": "20 isolated launches of the decoder's QKV-shaped GEMM right before the timed steps: the speed of THIS box"}
+                     "note": "20 isolated launches of the decoder's QKV-shaped GEMM right before the timed steps: the speed of THIS box "
+                             "(production kernel: since the tile-boundary work of round 4 it is itself ~2.5 % faster on a given box — "
+                             "1400-1408 -> 1434-1444 TFLOP/s, profiles/r04s_step_ab_slow_box.txt — so compare only lines of the same build)"}
             del ca, cb, cc
         except Exception as ex:  # noqa
             calib = {"error": str(ex)[:200]}
