@@ -724,6 +724,9 @@ def main():
     model = HandsOnVLMForCausalLM(cfg, device=device, training=True).init_random(seed=0)
     opt = AdamW(model, lr=2e-5, weight_decay=0.0, overlap=not args.no_opt_overlap)
     buckets = hdp.attach(model, hdp.GradBuckets(), opt)
+    # N > 1: every rank on its own GPU, or no scaling number (rank 0 prints the device map to stderr; shared devices abort unless the
+    # run is the declared functional check HVLM_DIST_BACKEND=gloo)
+    topo = hdp.check_topology() if buckets.active else None
     lens = None
     if args.varlen:
         lo, hi = (int(v) for v in args.varlen.split(":"))
@@ -918,6 +921,8 @@ def main():
         res["device_allocs_in_timed_region"] = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - segs0)   # hipMalloc calls of the caching allocator
         if buckets.active:
             res["comm"] = {"backend": torch.distributed.get_backend(), "world": buckets.world,
+                           "distinct_devices": bool(topo and topo["distinct"]),
+                           "devices": [f"{h}/{i}" for h, i, _, _ in topo["devices"]] if topo else None,
                            "collectives_per_step": buckets.n_collectives, "bytes_allreduced_per_step": buckets.bytes,
                            "buckets": f"{cfg.num_hidden_layers} decoder layers (one flat bf16 bucket each, reduced from the layer's backward hook) + "
                                       "lm_head (before the decoder backward) + tail (final norm, embed_tokens, mm_projector, CVAE head)",

@@ -32,6 +32,9 @@
 #include <stdlib.h>
 
 namespace hvlm {
+// attention_asm.hip
+int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, int B, int S_max, int H, int ld, float scale_log2,
+                             const int32_t* cu, hipStream_t st);
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1803,6 +1806,10 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
                          S, H, ld, nkb, nitems, scale * LOG2E);
       return check_launch("attn_fwd_resident");
     }
+  }
+  if constexpr (DH == 128 && CAUSAL && !F16) {
+    // the decoder's forward: hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_fwd_d128.py, attention_asm.hip)
+    if (config().attn_fwd_asm) return attn_fwd_d128_causal_asm(qkv, out, lse, B, S, H, ld, scale * LOG2E, cu, st);
   }
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us

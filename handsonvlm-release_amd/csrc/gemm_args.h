@@ -14,7 +14,7 @@ struct GemmArgs {
   int splits, k_split;          // split-K: `splits` K-slices of k_split columns, slice s writes fp32 slab s of C
   size_t slab;                  // elements between fp32 slabs
   int dyn;                      // gemm_pp: 0 = static tile assignment, s+1 = dynamic scheduling on state slot s (pp_sched_slot)
-  void* sched = nullptr;        // gemm_pp: caller-provided scheduler state (hvlm_gemm_set_sched_ws), NULL = the library's built-in state
+  void* sched = nullptr;        // gemm_pp: caller-provided scheduler state (the sched_ws given to hvlm_create), NULL = the library's built-in state
   int dbg;                      // development ablations (HVLM_GEMM_DBG), 0 in production
   int epi_swap = 0;             // gemm_pp, development builds: 1 = register-exchange epilogue (v_permlane swaps)
   int tail_half = 0;            // gemm_pp, dynamic scheduling: 1 = an XCD chunk's last partial round of tiles runs as half-tile units
@@ -35,7 +35,7 @@ int launch_gemm_pp(const GemmArgs& p, int grid, hipStream_t stream);
 // Dynamic-scheduling state slot of `stream` (launches on one stream are serialised, so they can share a slot; kernels
 // on different streams may overlap and must not): the first 8 distinct streams get their own slot, -1 after that.
 int pp_sched_slot(hipStream_t stream);
-// The scheduler-state block the caller installed for the CURRENT device (hvlm_gemm_set_sched_ws), or NULL.
+// The scheduler-state block the caller installed for the CURRENT device (hvlm_create), or NULL.
 void* pp_sched_ws();
 // same kernel, both operands K-strided (A is [K, M], B is [K, N]; lda / ldb = row strides of those): dW = dY^T X
 int launch_gemm_pp_tn(const GemmArgs& p, int grid, hipStream_t stream);

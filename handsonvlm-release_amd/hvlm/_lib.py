@@ -102,7 +102,7 @@ def load(path: os.PathLike | None = None) -> ctypes.CDLL:
             raise HvlmError(f"{p} does not export {name} declared in {HEADER_PATH}") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.hvlm_abi_version() != 1:
+    if lib.hvlm_abi_version() != 2:
         raise HvlmError("ABI version mismatch between include/hvlm.h and libhvlm_hip.so")
     _lib, _protos = lib, protos
     return lib

@@ -146,18 +146,19 @@ def from_pretrained(path: str, device="cuda:0", training: bool = False, mm_proje
         if vis is not None:
             cfg.vision = vis
             cfg.mm_hidden_size = vis.hidden_size
-    model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
     if mm_projector_bin is not None:                           # initialize_vision_modules(pretrain_mm_mlp_adapter=...)
         adapter = torch.load(mm_projector_bin, map_location="cpu", weights_only=True)
         for k, v in adapter.items():
             if "mm_projector" in k:
                 sd["model.mm_projector." + k.split("mm_projector.")[1]] = v
+    # every missing-file error BEFORE the model (13 - 26 GB of device memory at 7B / 13B) is constructed
     if "model.mm_projector.weight" not in sd:
         raise FileNotFoundError(f"{path} holds no mm_projector tensors: pass the LLaVA adapter file (mm_projector_bin / "
                                 "--pretrain_mm_mlp_adapter, scripts/finetune.sh:12)")
     if not any(k.startswith(vt) for k in sd):
         raise FileNotFoundError(f"{path} holds no CLIP tower tensors: pass a local CLIPVisionModel directory (vision_tower_path / "
                                 "--vision_tower, scripts/finetune.sh:11)")
+    model = HandsOnVLMForCausalLM(cfg, device=device, training=training)
     model.load_state_dict(sd)
     model._extra_state = {k: v for k, v in sd.items() if k not in model.state_dict()
                           and not k.startswith("model.vision_tower.")}

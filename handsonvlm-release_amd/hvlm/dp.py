@@ -35,6 +35,44 @@ def init_from_env(backend: Optional[str] = None):
     return rank, local, world
 
 
+def check_topology(group=None, verbose: bool = True) -> dict:
+    """First-step readiness check of an N > 1 run: every rank must drive its OWN GPU.  Two ranks that landed
+    on one device (a launcher that does not set LOCAL_RANK, HIP_VISIBLE_DEVICES hiding all but one GPU, ...) still produce a
+    "working" run — RCCL refuses it, but a gloo fall-back or HVLM_DIST_BACKEND=gloo does not — whose samples/s says nothing
+    about xGMI scaling.  Gathers (host, PCI bus id, device name) from every rank, asserts the (host, bus id) pairs are distinct
+    and has rank 0 print ONE line with the world size, the backend, the RCCL version and the device map.  Shared-device runs are
+    legitimate only as functional checks and must say so: HVLM_DIST_BACKEND=gloo skips the assertion (the line still prints
+    "SHARED")."""
+    import socket
+    if not dist.is_initialized():
+        return {"world": 1, "distinct": True}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if torch.cuda.is_available():
+        dev = torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(dev)
+        bus = getattr(pr, "pci_bus_id", None)
+        ident = f"{getattr(pr, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(pr, 'pci_device_id', 0):02x}" if bus is not None else str(getattr(pr, "uuid", dev))
+        mine = (socket.gethostname(), ident, pr.name, dev)
+    else:
+        mine = (socket.gethostname(), f"cpu-rank{rank}", "cpu", -1)
+    allr = [None] * world
+    dist.all_gather_object(allr, mine, group=group)
+    distinct = len({(h, i) for h, i, _, _ in allr}) == world
+    backend = dist.get_backend(group)
+    shared_ok = os.environ.get("HVLM_DIST_BACKEND") == "gloo" or not torch.cuda.is_available()
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else "-"
+    except Exception:                                         # noqa: BLE001  (a build without the nccl bindings)
+        ver = "?"
+    if rank == 0 and verbose:
+        print(f"hvlm.dp: world {world} backend {backend} (RCCL {ver}) devices "
+              + " ".join(f"r{r}={h}/{i}[{d}]" for r, (h, i, _, d) in enumerate(allr))
+              + (" DISTINCT" if distinct else " SHARED"), flush=True)
+    assert distinct or shared_ok, \
+        f"data-parallel ranks share a GPU: {allr} — one process per GPU is the contract (set LOCAL_RANK / do not hide devices)"
+    return {"world": world, "distinct": distinct, "backend": backend, "devices": allr}
+
+
 class GradBuckets:
     """Flat gradient buckets + asynchronous all-reduce handles."""
 

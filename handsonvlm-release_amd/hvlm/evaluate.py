@@ -140,6 +140,8 @@ def main(argv=None, samples=None):
         assert a.batch_size > 1, "--fp8 runs through the batched generation path"
         v = model.config.vision                      # (the e4m3 GEMM needs K % 128 == 0: every tower GEMM of ViT-L/14 qualifies)
         kw.update(fp8=True, fp8_decode=True, fp8_clip=(v.hidden_size % 128 == 0 and v.intermediate_size % 128 == 0))
+    # under torchrun every rank scores samples[rank::world] (evaluate_traj) and the predictions are all-gathered for the metric:
+    # N ranks = 1/N of the work each, one metric (handsonvlm_trainer.py:241-251)
     res = evaluate_traj(model, samples, batch_size=a.batch_size, **kw)
     if rank == 0:
         print(json.dumps(res), flush=True)

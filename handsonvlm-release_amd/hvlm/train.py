@@ -49,7 +49,8 @@ def latest_checkpoint(output_dir):
 
 
 def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_steps=None, lr=2e-5, warmup_ratio=0.03,
-          weight_decay=0.0, save_every_epoch=True, save_steps=None, log_every=10, seed=0, num_workers=0, stop_after=None):
+          weight_decay=0.0, save_every_epoch=True, save_steps=None, log_every=10, seed=0, num_workers=0, stop_after=None,
+          model_max_length=2048):
     """One process per GPU.  Auto-resume (handsonvlm/train/train.py:399-402: `trainer.train(resume_from_checkpoint=True)`
     when output_dir holds a checkpoint-*): weights, the optimizer's fp32 master weights / moments / step count, the CVAE
     head's optimizer, the position in the cosine schedule, the data order (epoch + batches already consumed) and each
@@ -62,9 +63,14 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
         model.load_state_dict(checkpoint.load_state(resume))          # BEFORE the optimizer clones its fp32 masters
     opt = AdamW(model, lr=lr, weight_decay=weight_decay, overlap=True)
     buckets = dp.attach(model, dp.GradBuckets(), opt)
+    if buckets.active:
+        dp.check_topology()                  # rank 0 prints the device map; two ranks on one GPU abort here, not after an epoch
     # a seeded sampler also at world size 1: the data order is a function of (seed, epoch), never of global RNG state
     sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=seed)
-    collate = DataCollatorForSupervisedDataset(num_frames=model.config.num_frames)
+    # --model_max_length is the TOKENIZER's truncation length in the reference (handsonvlm/train/train.py:243-249,
+    # hybrid_dataset.py:127-129): it bounds the collated ids, never the checkpoint's max_position_embeddings / RoPE table
+    collate = DataCollatorForSupervisedDataset(num_frames=model.config.num_frames, model_max_length=model_max_length,
+                                               image_size=model.config.vision.image_size)
     batches = torch.utils.data.BatchSampler(sampler, per_device_batch, drop_last=True)
     per_epoch = len(batches)
     assert per_epoch > 0, "dataset smaller than one per-device batch"
@@ -155,10 +161,12 @@ def build_parser():
     ap.add_argument("--lambda_traj", type=float, default=None)
     ap.add_argument("--lambda_traj_kl", type=float, default=None)
     ap.add_argument("--hoi_lambda", type=float, default=None)
-    ap.add_argument("--traj_decoder", default="CVAE")
-    ap.add_argument("--fuse_input_mode", default="origin")
-    ap.add_argument("--video_arch", default="temporal_spatial_pool")
-    ap.add_argument("--mm_vision_select_layer", type=int, default=-2)
+    # architecture flags: None = "not given" -> a loaded checkpoint's config.json decides (random-init models take the
+    # reference's script values: CVAE, origin, temporal_spatial_pool, -2)
+    ap.add_argument("--traj_decoder", default=None)
+    ap.add_argument("--fuse_input_mode", default=None)
+    ap.add_argument("--video_arch", default=None)
+    ap.add_argument("--mm_vision_select_layer", type=int, default=None)
     ap.add_argument("--samples_per_epoch", "--samples", dest="samples", type=int, default=48296, help="scripts/finetune.sh:56")
     ap.add_argument("--save_strategy", default="epoch", help='"epoch" (scripts/finetune.sh:27) | "steps" (then --save_steps applies, as in HF)')
     ap.add_argument("--save_steps", type=int, default=None)
@@ -174,13 +182,15 @@ def build_parser():
 
 def build_model(a, device):
     from .model import HandsOnVLMForCausalLM
+    # only flags that were GIVEN override the configuration (a checkpoint's config.json carries its own traj_decoder_name,
+    # fuse_input_mode, ...); --model_max_length is not a model property at all (see train(): it truncates the collated ids)
     over = {}
-    for k in ("lambda_traj", "lambda_traj_kl", "hoi_lambda"):
-        if getattr(a, k) is not None:
-            over[k] = getattr(a, k)
-    over.update(traj_decoder_name=a.traj_decoder, fuse_input_mode=a.fuse_input_mode, video_compress_mode=a.video_arch,
-                mm_vision_select_layer=a.mm_vision_select_layer, max_position_embeddings=a.model_max_length,
-                dedup_frames=a.dedup_frames, lm_head_labelled_rows=a.labelled_rows, activation_recompute=a.gradient_checkpointing)
+    for flag, field in (("lambda_traj", "lambda_traj"), ("lambda_traj_kl", "lambda_traj_kl"), ("hoi_lambda", "hoi_lambda"),
+                        ("traj_decoder", "traj_decoder_name"), ("fuse_input_mode", "fuse_input_mode"),
+                        ("video_arch", "video_compress_mode"), ("mm_vision_select_layer", "mm_vision_select_layer")):
+        if getattr(a, flag) is not None:
+            over[field] = getattr(a, flag)
+    over.update(dedup_frames=a.dedup_frames, lm_head_labelled_rows=a.labelled_rows, activation_recompute=a.gradient_checkpointing)
     if a.model_name_or_path:
         return checkpoint.from_pretrained(a.model_name_or_path, device=device, training=True, mm_projector_bin=a.pretrain_mm_mlp_adapter,
                                           vision_tower_path=a.vision_tower, **over)
@@ -213,7 +223,8 @@ def main(argv=None, dataset=None):
     return train(model, ds, a.output_dir, a.per_device_train_batch_size, a.num_train_epochs, a.steps, a.learning_rate,
                  warmup_ratio=a.warmup_ratio, weight_decay=a.weight_decay, save_steps=a.save_steps if a.save_strategy == "steps" else None,
                  save_every_epoch=a.save_strategy != "no", seed=a.seed,
-                 num_workers=a.dataloader_num_workers, stop_after=a.stop_after, log_every=1 if (a.steps or 0) and a.steps <= 10 else 10)
+                 num_workers=a.dataloader_num_workers, stop_after=a.stop_after, log_every=1 if (a.steps or 0) and a.steps <= 10 else 10,
+                 model_max_length=a.model_max_length)
 
 
 if __name__ == "__main__":

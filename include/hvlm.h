@@ -36,7 +36,12 @@ extern "C" {
 #define HVLM_ACT_NONE 0
 #define HVLM_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): transformers CLIP `quick_gelu` (clip_encoder.py:48) */
 
-#define HVLM_ABI_VERSION 1
+/* Bumped whenever an exported symbol is added, removed or changes meaning, so that a host built against an older header
+ * fails its version check instead of binding a different function set.
+ *   1: rounds 1-3.
+ *   2: round 4 (hvlm_gemm_set_sched_ws replaced by hvlm_create / hvlm_destroy, hvlm_debug_occupy left production builds,
+ *      hvlm_patch_im2col_f16 and hvlm_temporal_spatial_pool_fwd_f16 added) and round 5 (library switch "attn_fwd_asm"). */
+#define HVLM_ABI_VERSION 2
 
 int hvlm_abi_version(void);
 const char* hvlm_last_error(void);

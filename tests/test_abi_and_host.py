@@ -31,7 +31,7 @@ def test_header_symbols_all_exported(lib):
     cdll = ctypes.CDLL(str(lib.LIB_PATH))
     for name in protos:
         assert hasattr(cdll, name), f"{name} declared in include/hvlm.h but not exported"
-    assert lib.load().hvlm_abi_version() == 1
+    assert lib.load().hvlm_abi_version() == 2
     # workspace queries are pure host functions
     l = lib.load()
     # forward: no workspace is used (a token size keeps callers passing a valid pointer); backward: delta[B, H, S] in fp32
