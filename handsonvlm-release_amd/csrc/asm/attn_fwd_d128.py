@@ -49,8 +49,12 @@ KERNARG_BYTES = 64
 
 
 class Gen:
-    def __init__(self, debug_serial=False):
+    def __init__(self, debug_serial=False, abl=(), prof=False):
+        """abl: timing-only ablations (WRONG RESULTS): 'nosm' no softmax stream, 'nodma' no LDS-DMA in the loop, 'nolds' no
+        fragment reloads, 'nomfma' no MFMAs, 'noqk' / 'nopv' one MFMA family only.  prof: s_memtime stamps (entry, after the
+        prologue loads, loop entry, loop exit, end) stored per wave through the extra kernel argument."""
         self.debug_serial = debug_serial
+        self.abl, self.prof = set(abl), prof
         self.report = []
         self.site = 0
         self.ool = []                     # out-of-line blocks (slow paths), appended behind the main code
@@ -90,6 +94,9 @@ class Gen:
         self.s_so = S.alloc("soffset tmp", 1)
         self.s_lsebase = S.alloc("(b*H+h)*S_max", 1)
         self.s_outrow = S.alloc("H*256", 1)
+        self.s_prof = S.alloc("prof buffer", 2, 2)
+        self.s_stamp = [S.alloc(f"stamp{i}", 2, 2) for i in range(5)]
+        self.s_it = S.alloc("iteration stamp", 2, 2)
         # ---- AccVGPRs: exactly 256 ---------------------------------------------------------------------------------
         self.aO = [A.alloc(f"O qb{q}", 64) for q in range(2)]
         self.aQ = [A.alloc(f"Q qb{q}", 32) for q in range(2)]
@@ -115,6 +122,7 @@ class Gen:
         self.vVOFF = V.alloc("V DMA voffset", 1)
         self.vLANE = V.alloc("lane", 1); self.vL31 = V.alloc("lane & 31", 1); self.vHI = V.alloc("lane >> 5", 1)
         self.vX = V.alloc("scratch", 12, 4)
+        self.vPROF = [V.alloc(f"iteration stamps {i} (lane = iteration)", 1) for i in range(4)]
 
     # ---------------------------------------------------------------------------------------------------------------
     def new_site(self):
@@ -275,18 +283,24 @@ class Gen:
         early = []
         # canonical LDS order K0, V0, K1, V1, ... (identical in every body: the lgkmcnt arithmetic relies on it)
         for j in range(8):
+            if "nolds" in self.abl: break
             early.append(Filler([self.k_read(j, half)], after=k_after[j], prio=0))
             sp, db = j >> 2, j & 3
             early.append(Filler(self.v_reads(sp, db, half), after=v_after[(sp, db)], prio=0))
-        if first:
-            for gi, grp in enumerate(self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd)):
+        if first and "nodma" not in self.abl:
+            groups = self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd)
+            if "nodmak" in self.abl: groups = groups[4:]
+            if "nodmav" in self.abl: groups = groups[:4]
+            for gi, grp in enumerate(groups):
                 early.append(Filler(grp, after=gi, prio=0))
         stream = []
+        n_ool = len(self.ool)
         # masks first (they branch out of line only on the last two steps of a block), then the softmax chains
         for qb in (qbs if mode == "S" else (0,)):
             n = self.s_n0 if qb == 0 else self.s_n1
             stream.append(Filler(self.mask_block(qb, 1 - p, n, f"mask qb{qb}"), cost=3))
         chains = [self.sm_stream(qb, 1 - p) for qb in qbs]
+        if "nosm" in self.abl: chains, stream, self.ool = [[] for _ in qbs], [], self.ool[:n_ool]
         if len(chains) == 2:                      # interleave the two blocks' chains instruction by instruction (ILP)
             a, b = chains
             for i in range(max(len(a), len(b))):
@@ -300,6 +314,9 @@ class Gen:
                 for hf in range(2): tog.append(I("v_xor_b32", self.vVADDR[db][hf], 0x8000, self.vVADDR[db][hf]))
             # after the last LDS read of the step
             stream.append(Filler(tog, after=len(mf) - 1))
+        if "nomfma" in self.abl: mf = [s_nop(0) for _ in mf]
+        if "noqk" in self.abl: mf = [m if (isinstance(m, Ins) and m.ops[0].kind == "a") else s_nop(0) for m in mf]
+        if "nopv" in self.abl: mf = [m if (isinstance(m, Ins) and m.ops[0].kind == "v") else s_nop(0) for m in mf]
         items = self.rescale_check(qbs) + interleave(mf, early, stream, head_room=2)
         if not first:
             # the toggles must follow every ds_read of the body: move them to the very end
@@ -317,6 +334,10 @@ class Gen:
         # ------------------------------------------------------------------ arguments, mapping
         add(I("s_load_dwordx8", sa0, self.s_karg, 0x0))
         add(I("s_load_dwordx8", sa1, self.s_karg, 0x20))
+        if self.prof:
+            add(I("s_load_dwordx2", self.s_prof, self.s_karg, 0x40))
+            add(I("s_memtime", self.s_stamp[0]))
+            for k in range(4): add(I("v_mov_b32", self.vPROF[k], 0))
         add(I("v_and_b32", self.vLANE, 63, self.v_tid))
         add(I("v_lshrrev_b32", self.vX[0], 6, self.v_tid))
         add(I("v_and_b32", self.vL31, 31, self.vLANE))
@@ -436,6 +457,7 @@ class Gen:
             add(I("v_mov_b32", self.vL[qb], 0)); add(I("v_mov_b32", self.vALPHA[qb], 1.0))
         add(I("s_mov_b32", self.s_pend, 0)); add(I("s_mov_b32", self.s_step, 0)); add(I("s_mov_b32", self.s_U, 0))
         add(s_waitcnt(vm=0)); add(I("s_barrier", ndef=0))
+        if self.prof: add(I("s_memtime", self.s_stamp[1])); add(s_waitcnt(lgkm=0))
         # idle wave (no valid block): it still serves the barriers and its share of the DMA
         add(I("s_cmp_eq_u32", self.s_n1, 0, ndef=0)); add(I("s_cbranch_scc1", "L_loop", ndef=0))
         # QK of steps 0 and 1 from K tile 0 (staging), softmax of step 0, fragments for step 0's body
@@ -467,13 +489,26 @@ class Gen:
         add(I("s_cmp_lg_u32", self.s_n0, 0, ndef=0)); add(I("s_cbranch_scc0", "L_step0_S", ndef=0))
         self.bodies = {}
         b = self.finish_body(self.body("D", first=False), "step0_D"); add(b)
-        add(I("s_branch", "L_loop", ndef=0))
+        add(I("s_branch", "L_loop_entry" if self.prof else "L_loop", ndef=0))
         P.label("L_step0_S")
         b = self.finish_body(self.body("S", first=False), "step0_S"); add(b)
         # ------------------------------------------------------------------ main loop: iteration U = steps 2U+1, 2U+2 on stage U+1
+        if self.prof:
+            add(I("s_branch", "L_loop_entry", ndef=0))
         P.label("L_loop")
+        if self.prof:
+            add(I("s_branch", "L_loop2", ndef=0))
+            P.label("L_loop_entry")
+            add(s_waitcnt(lgkm=0)); add(I("s_memtime", self.s_stamp[2])); add(s_waitcnt(lgkm=0))
+            P.label("L_loop2")
         add(I("s_cmp_ge_u32", self.s_U, self.s_nT, ndef=0)); add(I("s_cbranch_scc1", "L_epilogue", ndef=0))
+        def itstamp(k):
+            if self.prof:
+                add(s_waitcnt(lgkm=0)); add(I("s_memtime", self.s_it)); add(s_waitcnt(lgkm=0))
+                add(I("s_mov_b32", M0, self.s_U)); add(I("v_writelane_b32", self.vPROF[k], self.s_it[0], M0, rw=True))
+        itstamp(0)
         add(s_waitcnt(vm=0)); add(I("s_barrier", ndef=0))
+        itstamp(1)
         # the stage issued now is U + 2 (K tile U+3, V tile U+2): nothing to fetch once U + 2 >= nT
         add(I("s_add_u32", t[0], self.s_U, 2)); add(I("s_cmp_lt_u32", t[0], self.s_nT, ndef=0)); add(I("s_cselect_b32", self.s_rd[2], self.s_numrec, 0))
         add(I("s_lshl_b32", t[1], self.s_U, 1)); add(I("s_add_u32", self.s_step, t[1], 1))
@@ -485,6 +520,7 @@ class Gen:
             P.label(lbl)
         for g in self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd): add(g)   # idle wave: DMA only
         P.label("L_second")
+        itstamp(2)
         add(I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile)); add(I("s_add_u32", self.s_vtile, self.s_vtile, self.s_tile))
         add(I("s_xor_b32", self.s_m0k, self.s_m0k, SLOT)); add(I("s_xor_b32", self.s_m0v, self.s_m0v, SLOT))
         add(I("s_add_u32", self.s_step, self.s_step, 1))
@@ -495,12 +531,36 @@ class Gen:
             add(I("s_branch", "L_iter_end", ndef=0))
             P.label(lbl)
         P.label("L_iter_end")
+        itstamp(3)
         add(I("s_add_u32", self.s_U, self.s_U, 1)); add(I("s_branch", "L_loop", ndef=0))
         # ------------------------------------------------------------------ epilogue
         P.label("L_epilogue")
         add(s_nop(15))
         add(s_waitcnt(vm=0, lgkm=0))
+        if self.prof: add(I("s_memtime", self.s_stamp[3])); add(s_waitcnt(lgkm=0))
         for qb in range(2): add(self.epilogue(qb))
+        if self.prof:
+            X = self.vX
+            add(s_waitcnt(vm=0)); add(I("s_memtime", self.s_stamp[4])); add(s_waitcnt(lgkm=0))
+            add(I("s_cmp_eq_u64", self.s_prof, 0, ndef=0)); add(I("s_cbranch_scc1", "L_exit", ndef=0))
+            # 8 dwords per wave: [t1-t0, t2-t1, t3-t2, t4-t3, n0, n1, nT, j] at prof + (wg * 4 + w) * 32
+            for i in range(4):
+                add(I("s_sub_u32", t[i], self.s_stamp[i + 1][0], self.s_stamp[i][0]))
+            vals = [t[0], t[1], t[2], t[3], self.s_n0, self.s_n1, self.s_nT, self.s_j]
+            for i, sv in enumerate(vals): add(I("v_mov_b32", X[i], sv))
+            add(I("s_lshl_b32", t[4], self.s_wg, 2)); add(I("s_add_u32", t[4], t[4], self.s_w)); add(I("s_lshl_b32", t[4], t[4], 5))
+            add(I("v_mov_b32", X[8], t[4]))
+            add(I("v_cmp_eq_u32", self.s_m64, 0, self.vLANE))
+            add(I("s_and_saveexec_b64", self.s_exec, self.s_m64, xdef=[EXEC]))
+            add(I("global_store_dwordx4", X[8], X[0:4], self.s_prof, ndef=0))
+            add(I("global_store_dwordx4", X[8], X[4:8], self.s_prof, ndef=0, mods="offset:16"))
+            add(I("s_mov_b64", EXEC, self.s_exec))
+            # iteration stamps behind the summary records: base = total_wgs * 4 * 32 bytes
+            add(I("s_lshl_b32", t[5], self.s_total, 7)); add(I("s_lshl_b32", t[6], t[4], 5))      # (wg*4+w)*32 -> *1024
+            add(I("s_add_u32", t[5], t[5], t[6]))
+            add(I("v_lshlrev_b32", X[9], 2, self.vLANE)); add(I("v_add_u32", X[9], t[5], X[9]))
+            for k in range(4):
+                add(I("global_store_dword", X[9], self.vPROF[k], self.s_prof, ndef=0, mods=f"offset:{256 * k}"))
         P.label("L_exit")
         add(s_waitcnt(vm=0))
         add(I("s_endpgm", ndef=0))
@@ -580,21 +640,44 @@ class Gen:
         return fix_hazards(out, f"epilogue{qb}", self.report)
 
 
-def generate(debug_serial=False):
-    g = Gen(debug_serial=debug_serial)
+def generate(debug_serial=False, abl=(), prof=False, name=KNAME):
+    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     body = render(items)
     hdr = ("// GENERATED by csrc/asm/attn_fwd_d128.py — do not edit.  Register map:\n" + g.S.listing() + "\n" + g.V.listing() + "\n"
            + g.A.listing() + "\n// hazard pads inserted: " + ", ".join(f"{t}={n}" for t, n in g.report))
     n_mfma = sum(1 for x in items if isinstance(x, Ins) and x.is_mfma)
-    text = kernel_text(KNAME, body, lds_bytes=LDS_BYTES, kernarg_bytes=KERNARG_BYTES, n_arch_vgpr=g.V.next, n_acc_vgpr=256,
-                       n_sgpr=g.S.next + 2, args_meta=ARGS, header_comment=hdr)
+    args = ARGS + ([(8, 64, "global_buffer")] if prof else [])
+    text = kernel_text(name, body, lds_bytes=LDS_BYTES, kernarg_bytes=KERNARG_BYTES + (8 if prof else 0), n_arch_vgpr=g.V.next,
+                       n_acc_vgpr=256, n_sgpr=g.S.next + 2, args_meta=args, header_comment=hdr)
     return text, g, n_mfma
+
+
+# development variants (make DEV=1): cycle stamps and timing-only ablations, selected by the switch attn_fwd_asm = 2 + index
+DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
+                ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
+                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("noqk", dict(prof=True, abl=("noqk",))),
+                ("nopv", dict(prof=True, abl=("nopv",))), ("nodmak", dict(prof=True, abl=("nodmak",))),
+                ("nodmav", dict(prof=True, abl=("nodmav",)))]
+
+
+def unique_labels(text, suffix):
+    import re
+    return re.sub(r"\bL_([A-Za-z0-9_]+)", lambda m: f"L{suffix}_{m.group(1)}", text)
 
 
 if __name__ == "__main__":
     text, g, n = generate(debug_serial="--serial" in sys.argv)
+    if "--dev" in sys.argv:
+        # one code object with the production kernel and every development variant (labels made unique per kernel)
+        parts = [text]
+        for i, (vn, kw) in enumerate(DEV_VARIANTS):
+            vt, _, _ = generate(name=f"{KNAME}_{vn}", **kw)
+            vt = unique_labels(vt, f"v{i}")
+            vt = "\n".join(l for l in vt.split("\n") if not l.startswith(".amdgcn_target") and not l.startswith(".amdhsa_code_object_version"))
+            parts.append(vt)
+        text = "\n".join(parts)
     out = [a for a in sys.argv[1:] if not a.startswith("--")]
     if out:
         with open(out[0], "w") as f: f.write(text)

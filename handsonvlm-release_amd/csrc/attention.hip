@@ -34,7 +34,7 @@
 namespace hvlm {
 // attention_asm.hip
 int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, int B, int S_max, int H, int ld, float scale_log2,
-                             const int32_t* cu, hipStream_t st);
+                             const int32_t* cu, hipStream_t st, int variant = 0, void* prof = nullptr);
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

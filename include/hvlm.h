@@ -51,6 +51,13 @@ int hvlm_device_info(int device, int* cu_count, int* lds_bytes, char* arch, int 
 /* Development builds only (`make DEV=1`): keeps `workgroups` CUs busy (64 KiB LDS each) for about `cycles` shader clocks on
  * `stream` — a stand-in for a collective running beside the compute stream (tools/contention_bench.py). */
 int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
+/* Development builds only: the hand-scheduled dh = 128 causal forward (hvlm_attn_fwd's default path, csrc/asm/attn_fwd_d128.py) in
+ * its cycle-stamped form (variant 1) or as a timing-only ablation (variant >= 2: WRONG results — no softmax stream, no DMA, no
+ * fragment reloads, no MFMAs, ...; tools/attn_asm_prof.py lists them).  prof: NULL or a device buffer of
+ * B * H * ceil(S / 256) * 4 waves x 8 uint32 = {prologue loads, prologue compute + step 0, loop, epilogue} in shader cycles,
+ * n0, n1, nT, j of the wave.  Padded batch only. */
+int hvlm_attn_fwd_asm_dev(const void* qkv, void* out, float* lse, void* prof, int B, int S, int H, int ld, float scale,
+                          int variant, void* stream);
 #endif
 
 /* Per-device handle — the ONLY mutable state the library keeps between calls: which block of device memory
