@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Causal flash-attention FORWARD for dh = 128, bf16, gfx950 — hand-allocated registers, one wave per SIMD.
+"""Causal flash-attention FORWARD for dh = 128, bf16, gfx950 — hand-allocated registers, one wave per SIMD, persistent.
 
 Replaces, for the decoder's shapes, attn_fwd_kernel<128, true, 4> of attention.hip (same operands, same results to rounding):
     softmax(Q K^T / sqrt(dh) + causal mask) V          (transformers LlamaAttention; the flash path of the reference,
@@ -7,11 +7,11 @@ Replaces, for the decoder's shapes, attn_fwd_kernel<128, true, 4> of attention.h
 reading q / k / v straight from the token-major fused buffer qkv[tokens, ld] and writing O[tokens, H*128] and lse[B, H, S_max].
 
 Structure (why it is not the C++ kernel re-typed):
-  * workgroup = 4 waves = ONE wave per SIMD, 512 registers each; a workgroup owns 256 query rows = eight 32-row blocks and wave w
-    owns blocks w and w + 4 ("qb0", "qb1"): near the diagonal every wave still has work, so the lock-step K/V stream wastes
-    2 of (16 j + 12) half-units instead of a whole wave (DESIGN.md "attention, round 5" has the count);
+  * workgroup = 4 waves = ONE wave per SIMD, 512 registers each; a work ITEM is 256 query rows of one (sample, head) = eight
+    32-row blocks, and wave w owns blocks w and w + 4 ("qb0", "qb1"): near the diagonal every wave still has work, so the
+    lock-step K/V stream wastes 3 of (16 j + 12) half-units instead of a whole wave;
   * per wave:  O (2 x 64) , Q (2 x 32), K fragments (32) and V fragments (32) live in AccVGPRs — exactly 256 — and the scores,
-    probabilities and softmax state in ~140 arch VGPRs;
+    probabilities, softmax state and the NEXT item's Q in ~230 arch VGPRs;
   * a step = 32 keys.  Three-stage software pipeline with NO dependency inside a step:
         MFMA stream :  QK^T of step s+2  (-> S[p])   alternating with   P V of step s  (<- P[p])
         VALU stream :  softmax of step s+1  (S[1-p] -> P[1-p], running max / sum)
@@ -19,13 +19,18 @@ Structure (why it is not the C++ kernel re-typed):
     so the matrix pipe never waits for the exponentials of its own tile (what bounded the C++ kernels: r03d_valu_mfma_probe);
   * the running maximum is only RAISED when some score exceeds it by 2^THR (THR = 8): the O rescale (128 AccVGPRs through the
     VALU) is an out-of-line slow path, applied at the next step boundary when every P V of the old scale has been issued;
-  * K / V tiles (64 keys) arrive by LDS-DMA into a two-stage ring, stage X = {K tile X+1, V tile X}: one barrier per tile,
-    the next stage's DMA issued as MFMA fillers right behind it.  K's LDS image is [half][ks][hi][key] so that a fragment read
-    is base + immediate (one address register); V keeps the XOR-swizzled row-major image that ds_read_b64_tr_b16 needs.
+  * K / V tiles (64 keys) arrive by LDS-DMA into a THREE-slot ring, stage X = {K tile X+1, V tile X}, issued two iterations
+    ahead of their first read (LDS-DMA takes ~3400 cycles issue -> landed under load, profiles/r05b): one barrier per tile and
+    a counted vmcnt.  K's LDS image is [half][ks][hi][key] so that a fragment read is base + immediate; V keeps the
+    XOR-swizzled row-major image that ds_read_b64_tr_b16 needs;
+  * PERSISTENT: one workgroup per CU pulls items from a per-XCD queue (heaviest block of a group of 8 (sample, head) pairs first:
+    the pairs of a group share one L2) and, during the last iterations of an item, issues the NEXT item's first K tile, its
+    first three stages and its Q rows — version 1 spent 44 % of its cycles in per-workgroup prologue loads and epilogues.
 
 The file is a GENERATOR: `python3 attn_fwd_d128.py out.s` writes the assembly (asmgen.py pads hazards and derives the lgkmcnt
 waits); the Makefile assembles it into a code object that attention_asm.hip embeds and launches through hipModuleLaunchKernel.
 """
+import re
 import sys
 from asmgen import (Reg, RegFile, Program, I, Ins, Label, Raw, Filler, VCC, M0, EXEC, s_nop, s_waitcnt, mfma_bf16, interleave,
                     fix_hazards, add_lgkm_waits, render, kernel_text)
@@ -36,67 +41,85 @@ NEG_INF = 0xff800000
 LN2 = 0x3f317218
 
 # LDS map -------------------------------------------------------------------------------------------------------------
-SLOT = 32768                   # stage = K tile (16 KiB) + V tile (16 KiB)
+SLOT = 32768                   # stage = K tile (16 KiB) + V tile (16 KiB); three slots
 V_IN_SLOT = 16384
-STAGING = 65536                # 4 x 8 KiB wave-private blocks for the O epilogue; K tile 0 sits here during the prologue
-LDS_BYTES = STAGING + 4 * 8192
+K0AREA = 3 * SLOT              # the first K tile of an item (read by its prologue only)
+OSTAGE = K0AREA + 16384        # 4 x 8 KiB wave-private blocks for the O epilogue
+BCAST = OSTAGE + 4 * 8192      # two words: the queue index of the next item, wave 0 -> everybody
+LDS_BYTES = BCAST + 64
 
 # kernel arguments ------------------------------------------------------------------------------------------------------
 ARGS = [(8, 0, "global_buffer"), (8, 8, "global_buffer"), (8, 16, "global_buffer"), (8, 24, "global_buffer"),
         (4, 32, "by_value"), (4, 36, "by_value"), (4, 40, "by_value"), (4, 44, "by_value"),
-        (4, 48, "by_value"), (4, 52, "by_value"), (4, 56, "by_value"), (4, 60, "by_value")]
-KERNARG_BYTES = 64
+        (4, 48, "by_value"), (4, 52, "by_value"), (4, 56, "by_value"), (4, 60, "by_value"),
+        (8, 64, "global_buffer"), (4, 72, "by_value"), (4, 76, "by_value")]
+KERNARG_BYTES = 80
 
 
 class Gen:
     def __init__(self, debug_serial=False, abl=(), prof=False):
         """abl: timing-only ablations (WRONG RESULTS): 'nosm' no softmax stream, 'nodma' no LDS-DMA in the loop, 'nolds' no
-        fragment reloads, 'nomfma' no MFMAs, 'noqk' / 'nopv' one MFMA family only.  prof: s_memtime stamps (entry, after the
-        prologue loads, loop entry, loop exit, end) stored per wave through the extra kernel argument."""
+        fragment reloads, 'nomfma' no MFMAs.  prof: s_memtime cycle sums per workgroup phase through the extra kernel argument."""
         self.debug_serial = debug_serial
         self.abl, self.prof = set(abl), prof
         self.report = []
         self.site = 0
         self.ool = []                     # out-of-line blocks (slow paths), appended behind the main code
-        S = self.S = RegFile("s", 0, 100)
+        S = self.S = RegFile("s", 0, 102)
         V = self.V = RegFile("v", 0, 256)
         A = self.A = RegFile("a", 0, 256)
         # ---- SGPRs ------------------------------------------------------------------------------------------------
         self.s_karg = S.alloc("kernarg", 2)
         self.s_wg = S.alloc("workgroup id", 1)
-        S.alloc("pad", 1)
-        self.s_rq = S.alloc("rsrc qkv (sample rows)", 4, 4)
+        self.s_bc = S.alloc("broadcast word in use (0 / 4)", 1)
+        self.s_rq = S.alloc("rsrc qkv (this item's sample rows)", 4, 4)
         self.s_args0 = S.alloc("args 0..7: qkv, out, lse, cu", 8, 4)
-        self.s_args1 = S.alloc("args 8..15: S_max H ld scale nqb total magic_nqb magic_H", 8, 4)
+        self.s_args1 = S.alloc("args 8..15: S_max H ld scale nqb BH magic_nqb magic_H", 8, 4)
+        self.s_args2 = S.alloc("args: queue, G, pad", 4, 4)
         self.s_ro = S.alloc("rsrc out (sample rows)", 4, 4)
-        self.s_rd = S.alloc("rsrc for DMA (num_records zeroed past the last tile)", 4, 4)
+        self.s_rd = S.alloc("rsrc of the DMA stream (this item's, then the next item's)", 4, 4)
+        self.s_rn = S.alloc("rsrc qkv of the NEXT item", 4, 4)
         self.s_qkv, self.s_out, self.s_lse, self.s_cu = (self.s_args0.sub(0, 2), self.s_args0.sub(2, 2), self.s_args0.sub(4, 2),
                                                          self.s_args0.sub(6, 2))
-        (self.s_smax, self.s_H, self.s_ld, self.s_scale, self.s_nqb, self.s_total, self.s_magq, self.s_magh) = [self.s_args1[i] for i in range(8)]
+        (self.s_smax, self.s_H, self.s_ld, self.s_scale, self.s_nqb, self.s_BH, self.s_magq, self.s_magh) = [self.s_args1[i] for i in range(8)]
+        self.s_queue = self.s_args2.sub(0, 2); self.s_G = self.s_args2[2]; self.s_cs0 = self.s_args2[3]   # (pad word reused: ring slot at item start)
         self.s_t = [S.alloc(f"tmp{i}", 1) for i in range(8)]
-        self.s_t64 = S.alloc("tmp64", 2, 2)
+        self.s_t64 = S.alloc("tmp64 / mask64", 2, 2)
         self.s_exec = S.alloc("saved exec", 2, 2)
-        self.s_m64 = S.alloc("mask64", 2, 2)
-        self.s_b = S.alloc("b", 1); self.s_h = S.alloc("h", 1); self.s_j = S.alloc("j (256-row block)", 1)
-        self.s_S = S.alloc("S (this sample)", 1); self.s_tok0 = S.alloc("tok0", 1)
+        self.s_m64 = self.s_t64                      # (the s_load pair of emit_params and the epilogue's lane mask are never live together)
+        self.s_h = S.alloc("h", 1); self.s_j = S.alloc("j (256-row block)", 1)
+        self.s_S = S.alloc("S (this sample)", 1)
         self.s_w = S.alloc("wave", 1)
         self.s_n0 = S.alloc("n0: steps of qb0", 1); self.s_n1 = S.alloc("n1: steps of qb1", 1)
         self.s_rb0 = S.alloc("first row of qb0", 1); self.s_rb1 = S.alloc("first row of qb1", 1)
-        self.s_nT = S.alloc("key tiles of the workgroup", 1)
+        self.s_nT = S.alloc("key tiles of the item", 1)
         self.s_U = S.alloc("iteration", 1); self.s_step = S.alloc("step", 1)
         self.s_pend = S.alloc("pending O rescale bits", 1)
         self.s_ld2 = S.alloc("ld * 2 bytes", 1)
         self.s_kcol = S.alloc("K soffset base of this wave", 1); self.s_vcol = S.alloc("V soffset base", 1)
         self.s_tile = S.alloc("64 * ld * 2", 1); self.s_r16 = S.alloc("16 * ld * 2", 1)
-        self.s_ktile = S.alloc("soffset of the next K tile", 1); self.s_vtile = S.alloc("soffset of the next V tile", 1)
-        self.s_m0k = S.alloc("m0 base K pieces", 1); self.s_m0v = S.alloc("m0 base V pieces", 1)
+        self.s_ktile = S.alloc("DMA stream: soffset of the next K tile", 1); self.s_vtile = S.alloc("DMA stream: next V tile", 1)
+        self.s_m0k = S.alloc("DMA stream: m0 of this wave's first K piece", 1); self.s_m0v = S.alloc("DMA stream: first V piece", 1)
+        self.s_dslot = S.alloc("DMA stream: ring slot", 1)
+        self.s_dso = S.alloc("DMA stream: next own stage", 1); self.s_nu = S.alloc("DMA stream: next-item units issued", 1)
         self.s_numrec = S.alloc("num_records qkv", 1)
         self.s_so = S.alloc("soffset tmp", 1)
         self.s_lsebase = S.alloc("(b*H+h)*S_max", 1)
         self.s_outrow = S.alloc("H*256", 1)
-        self.s_prof = S.alloc("prof buffer", 2, 2)
-        self.s_stamp = [S.alloc(f"stamp{i}", 2, 2) for i in range(5)]
-        self.s_it = S.alloc("iteration stamp", 2, 2)
+        self.s_cs = S.alloc("consumer ring slot", 1)
+        self.s_li = S.alloc("queue index of this item", 1); self.s_lin = S.alloc("queue index of the next item", 1)
+        self.s_items = S.alloc("items of this XCD's queue", 1); self.s_nwg = S.alloc("workgroups on this queue", 1)
+        self.s_bh0 = S.alloc("first (sample, head) pair of this XCD", 1)
+        self.s_split = S.alloc("queue index where the last (short) group starts", 1); self.s_rem = S.alloc("pairs in the last group", 1)
+        self.s_qx = S.alloc("this XCD's queue counter", 2, 2)
+        self.s_kcoln = S.alloc("next item: K soffset base", 1); self.s_vcoln = S.alloc("next item: V soffset base", 1)
+        self.s_rb0n = S.alloc("next item: first row of qb0", 1); self.s_rb1n = S.alloc("next item: first row of qb1", 1)
+        self.s_hqn = S.alloc("next item: h * 256", 1)
+        self.s_delta = S.alloc("ring address step", 1)
+        if prof:
+            self.s_prof = S.alloc("prof buffer", 2, 2)
+            self.s_tm = self.s_karg                  # (the kernarg pointer is dead once the arguments are loaded)
+            self.s_t0 = S.alloc("previous stamp", 1)
         # ---- AccVGPRs: exactly 256 ---------------------------------------------------------------------------------
         self.aO = [A.alloc(f"O qb{q}", 64) for q in range(2)]
         self.aQ = [A.alloc(f"Q qb{q}", 32) for q in range(2)]
@@ -121,32 +144,68 @@ class Gen:
         self.vKOFF = V.alloc("K DMA voffset", 1)
         self.vVOFF = V.alloc("V DMA voffset", 1)
         self.vLANE = V.alloc("lane", 1); self.vL31 = V.alloc("lane & 31", 1); self.vHI = V.alloc("lane >> 5", 1)
+        self.vATOM = V.alloc("queue atomic result", 1)
         self.vX = V.alloc("scratch", 12, 4)
-        self.vPROF = [V.alloc(f"iteration stamps {i} (lane = iteration)", 1) for i in range(4)]
+        self.vQN = V.alloc("Q of the NEXT item (2 qb x 8 ks x 4)", 64, 4)
+        self.vPACC = V.alloc("prof: cycle sums (lane k = phase k)", 1)
 
     # ---------------------------------------------------------------------------------------------------------------
     def new_site(self):
         self.site += 1
         return self.site
 
-    # ---- DMA of one stage (K tile X+1, V tile X) by this wave: 8 pieces -------------------------------------------------
-    def dma_stage_ins(self, slot_sgpr_k, slot_sgpr_v, ktile, vtile, rsrc):
-        """8 groups of (m0, soffset, buffer_load lds).  slot_sgpr_k / _v: SGPRs holding the LDS byte address of this wave's
-        first K / V piece in the target slot."""
+    # ---- DMA of one stage (K tile X+1, V tile X) by this wave: 8 pieces, driven by the DMA-stream registers ---------------
+    def dma_stage_ins(self):
         g = []
         for i in range(4):
-            g.append([I("s_add_u32", M0, slot_sgpr_k, 0x400 * i) if i else I("s_mov_b32", M0, slot_sgpr_k),
-                      I("s_add_u32", self.s_so, ktile, 32 * i) if i else I("s_mov_b32", self.s_so, ktile),
-                      I("buffer_load_dwordx4", self.vKOFF, rsrc, self.s_so, ndef=0, mods="offen lds", xuse=[M0])])
+            g.append([I("s_add_u32", M0, self.s_m0k, 0x400 * i) if i else I("s_mov_b32", M0, self.s_m0k),
+                      I("s_add_u32", self.s_so, self.s_ktile, 32 * i) if i else I("s_mov_b32", self.s_so, self.s_ktile),
+                      I("buffer_load_dwordx4", self.vKOFF, self.s_rd, self.s_so, ndef=0, mods="offen lds", xuse=[M0])])
         for i in range(4):
-            g.append([I("s_add_u32", M0, slot_sgpr_v, 0x1000 * i) if i else I("s_mov_b32", M0, slot_sgpr_v),
-                      I("s_add_u32", self.s_so, self.s_so, self.s_r16) if i else I("s_mov_b32", self.s_so, vtile),
-                      I("buffer_load_dwordx4", self.vVOFF, rsrc, self.s_so, ndef=0, mods="offen lds", xuse=[M0])])
+            g.append([I("s_add_u32", M0, self.s_m0v, 0x1000 * i) if i else I("s_mov_b32", M0, self.s_m0v),
+                      I("s_add_u32", self.s_so, self.s_so, self.s_r16) if i else I("s_mov_b32", self.s_so, self.s_vtile),
+                      I("buffer_load_dwordx4", self.vVOFF, self.s_rd, self.s_so, ndef=0, mods="offen lds", xuse=[M0])])
         return g
 
+    def dma_k0_ins(self, kcol, rsrc):
+        """The item's first K tile -> K0AREA (4 pieces of this wave)."""
+        out = [I("s_lshl_b32", self.s_t[6], self.s_w, 12), I("s_add_u32", self.s_t[6], self.s_t[6], K0AREA)]
+        for i in range(4):
+            out += [I("s_add_u32", M0, self.s_t[6], 0x400 * i), I("s_add_u32", self.s_so, kcol, 32 * i),
+                    I("buffer_load_dwordx4", self.vKOFF, rsrc, self.s_so, ndef=0, mods="offen lds", xuse=[M0])]
+        return out
+
+    def dma_advance(self):
+        """DMA stream: one stage issued -> next tile, next ring slot."""
+        t = self.s_t
+        return [I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile), I("s_add_u32", self.s_vtile, self.s_vtile, self.s_tile),
+                I("s_add_u32", self.s_m0k, self.s_m0k, SLOT), I("s_add_u32", self.s_m0v, self.s_m0v, SLOT),
+                I("s_add_u32", self.s_dslot, self.s_dslot, 1),
+                I("s_cmp_lt_u32", self.s_dslot, 3, ndef=0), I("s_cbranch_scc1", f"L_dadv_{self.new_site()}", ndef=0),
+                I("s_mov_b32", self.s_dslot, 0), I("s_sub_u32", self.s_m0k, self.s_m0k, 3 * SLOT), I("s_sub_u32", self.s_m0v, self.s_m0v, 3 * SLOT),
+                Label(f"L_dadv_{self.site}")]
+
+    def dma_set_slot(self, slot):
+        """m0 bases of the DMA stream from a ring slot index held in `slot`."""
+        t = self.s_t
+        return [I("s_mov_b32", self.s_dslot, slot), I("s_lshl_b32", t[6], slot, 15),
+                I("s_lshl_b32", t[7], self.s_w, 12), I("s_add_u32", self.s_m0k, t[6], t[7]),
+                I("s_lshl_b32", t[7], self.s_w, 10), I("s_add_u32", t[7], t[7], V_IN_SLOT), I("s_add_u32", self.s_m0v, t[6], t[7])]
+
+    def consumer_advance(self):
+        st = self.new_site()
+        out = [I("s_mov_b32", self.s_delta, SLOT), I("s_add_u32", self.s_cs, self.s_cs, 1),
+               I("s_cmp_lt_u32", self.s_cs, 3, ndef=0), I("s_cbranch_scc1", f"L_cadv_{st}", ndef=0),
+               I("s_mov_b32", self.s_cs, 0), I("s_mov_b32", self.s_delta, (-2 * SLOT) & 0xffffffff),
+               Label(f"L_cadv_{st}"),
+               I("v_add_u32", self.vKADDR, self.s_delta, self.vKADDR)]
+        for db in range(4):
+            for hf in range(2): out.append(I("v_add_u32", self.vVADDR[db][hf], self.s_delta, self.vVADDR[db][hf]))
+        return out
+
     # ---- fragment reads -------------------------------------------------------------------------------------------
-    def k_read(self, ks, half, addr=None, extra=0):
-        return I("ds_read_b128", self.aK.sub(4 * ks, 4), addr or self.vKADDR, mods=f"offset:{extra + half * 8192 + ks * 1024}")
+    def k_read(self, ks, half, addr=None):
+        return I("ds_read_b128", self.aK.sub(4 * ks, 4), addr or self.vKADDR, mods=f"offset:{half * 8192 + ks * 1024}")
 
     def v_reads(self, sp, db, half):
         off = V_IN_SLOT + half * 8192 + sp * 4096
@@ -164,7 +223,6 @@ class Gen:
 
     # ---- softmax of one 32-row block on 32 keys: S[qb][p] -> P[qb][p] -----------------------------------------------------
     def sm_stream(self, qb, p, init=False):
-        """returns (list of Filler in order, out-of-line slow path)"""
         x = self.vS[qb][p]; P = self.vP[qb][p]; t = self.vT[qb]; acc = self.vACC[qb]
         m, negm, mt, l = self.vM[qb], self.vNEGM[qb], self.vMT[qb], self.vL[qb]
         sc = self.s_scale
@@ -263,8 +321,8 @@ class Gen:
 
     # ---- one step body ----------------------------------------------------------------------------------------------
     def body(self, mode, first):
-        """mode 'D': both blocks, 'S': qb1 only.  first: odd step of an iteration (p = 1, fragment half 0, carries the DMA
-        issue of the next stage); second: even step (p = 0, half 1, toggles the LDS slot of the address registers at its end)."""
+        """mode 'D': both blocks, 'S': qb1 only.  first: odd step of an iteration (p = 1, fragment half 0, carries the iteration's
+        8 DMA pieces as fillers); second: even step (p = 0, half 1)."""
         p = 1 if first else 0
         half = 0 if first else 1
         qbs = (0, 1) if mode == "D" else (1,)
@@ -288,10 +346,7 @@ class Gen:
             sp, db = j >> 2, j & 3
             early.append(Filler(self.v_reads(sp, db, half), after=v_after[(sp, db)], prio=0))
         if first and "nodma" not in self.abl:
-            groups = self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd)
-            if "nodmak" in self.abl: groups = groups[4:]
-            if "nodmav" in self.abl: groups = groups[:4]
-            for gi, grp in enumerate(groups):
+            for gi, grp in enumerate(self.dma_stage_ins()):
                 early.append(Filler(grp, after=gi, prio=0))
         stream = []
         n_ool = len(self.ool)
@@ -308,101 +363,157 @@ class Gen:
                 if i < len(b): stream.append(b[i])
         else:
             stream += chains[0]
-        if not first:
-            tog = [I("v_xor_b32", self.vKADDR, 0x8000, self.vKADDR)]
-            for db in range(4):
-                for hf in range(2): tog.append(I("v_xor_b32", self.vVADDR[db][hf], 0x8000, self.vVADDR[db][hf]))
-            # after the last LDS read of the step
-            stream.append(Filler(tog, after=len(mf) - 1))
         if "nomfma" in self.abl: mf = [s_nop(0) for _ in mf]
-        if "noqk" in self.abl: mf = [m if (isinstance(m, Ins) and m.ops[0].kind == "a") else s_nop(0) for m in mf]
-        if "nopv" in self.abl: mf = [m if (isinstance(m, Ins) and m.ops[0].kind == "v") else s_nop(0) for m in mf]
-        items = self.rescale_check(qbs) + interleave(mf, early, stream, head_room=2)
-        if not first:
-            # the toggles must follow every ds_read of the body: move them to the very end
-            togs = [x for x in items if isinstance(x, Ins) and x.op == "v_xor_b32" and x.ops[1] == 0x8000]
-            items = [x for x in items if not (isinstance(x, Ins) and x.op == "v_xor_b32" and x.ops[1] == 0x8000)] + togs
+        return self.rescale_check(qbs) + interleave(mf, early, stream, head_room=2)
+
+    def finish_body(self, items, tag):
+        # the entry state of every body: the 24 reloads of the previous step in canonical order, all possibly outstanding
+        canon = []
+        for j in range(8):
+            canon.append(self.aK.sub(4 * j, 4).ids())
+            base = self.aV.sub(4 * j, 4)
+            canon += [base.sub(0, 2).ids(), base.sub(2, 2).ids()]
+        items, pend = add_lgkm_waits(items, initial=canon)
+        tail = [x for x in items if isinstance(x, Ins)][-20:]
+        items = fix_hazards(items, tag, self.report, carry=tail)
+        if self.debug_serial:
+            out = []
+            for x in items:
+                out.append(x)
+                if isinstance(x, Ins) and (x.is_mfma or x.is_lds or x.is_valu): out += [s_waitcnt(lgkm=0), s_nop(15)]
+            items = out
         return items
+
+    # ---- item parameters from a queue index ------------------------------------------------------------------------------
+    def emit_params(self, P, li, nxt):
+        """li (queue index inside this XCD's chunk) -> (pair, block) -> descriptors and offsets.  nxt = False: this item's full set;
+        True: the subset the prefetch needs (s_rn, s_kcoln, s_vcoln, s_rb0n, s_rb1n, s_hqn).  Clobbers s_t[0..7], s_t64, lgkmcnt."""
+        add = P.add
+        t = self.s_t
+        st = self.new_site()
+        bh, jj, b, h, j, S_, tok0 = t[0], t[1], t[2], t[3], t[4], t[5], t[6]
+        # groups of 8 pairs, heaviest block of every pair first: li = g * 8 nqb + jj * 8 + bi  (the last group may hold fewer pairs)
+        add(I("s_cmp_lt_u32", li, self.s_split, ndef=0)); add(I("s_cbranch_scc0", f"L_par_short_{st}", ndef=0))
+        add(I("s_lshr_b32", t[7], li, 3)); add(I("s_and_b32", bh, li, 7))
+        add(I("s_cmp_eq_u32", self.s_nqb, 1, ndef=0)); add(I("s_cbranch_scc1", f"L_par_nqb1_{st}", ndef=0))
+        add(I("s_mul_hi_u32", t[2], t[7], self.s_magq)); add(I("s_mul_i32", t[3], t[2], self.s_nqb)); add(I("s_sub_u32", jj, t[7], t[3]))
+        add(I("s_branch", f"L_par_g_{st}", ndef=0))
+        P.label(f"L_par_nqb1_{st}"); add(I("s_mov_b32", t[2], t[7])); add(I("s_mov_b32", jj, 0))
+        P.label(f"L_par_g_{st}")
+        add(I("s_lshl_b32", t[2], t[2], 3)); add(I("s_add_u32", bh, bh, t[2]))
+        add(I("s_branch", f"L_par_bh_{st}", ndef=0))
+        P.label(f"L_par_short_{st}")                                   # r = li - split; jj = r / rem; bi = r % rem  (rem in 1..7)
+        add(I("s_sub_u32", bh, li, self.s_split)); add(I("s_mov_b32", jj, 0))
+        P.label(f"L_par_div_{st}")
+        add(I("s_cmp_lt_u32", bh, self.s_rem, ndef=0)); add(I("s_cbranch_scc1", f"L_par_divd_{st}", ndef=0))
+        add(I("s_sub_u32", bh, bh, self.s_rem)); add(I("s_add_u32", jj, jj, 1)); add(I("s_branch", f"L_par_div_{st}", ndef=0))
+        P.label(f"L_par_divd_{st}")
+        add(I("s_lshr_b32", t[2], self.s_split, 3)); add(I("s_cmp_eq_u32", self.s_nqb, 1, ndef=0)); add(I("s_cbranch_scc1", f"L_par_s1_{st}", ndef=0))
+        add(I("s_mul_hi_u32", t[2], t[2], self.s_magq))                                    # full groups = split / (8 nqb)
+        P.label(f"L_par_s1_{st}")
+        add(I("s_lshl_b32", t[2], t[2], 3)); add(I("s_add_u32", bh, bh, t[2]))
+        P.label(f"L_par_bh_{st}")
+        add(I("s_add_u32", bh, bh, self.s_bh0))
+        add(I("s_sub_u32", j, self.s_nqb, jj)); add(I("s_sub_u32", j, j, 1))                 # heaviest block first
+        add(I("s_cmp_eq_u32", self.s_H, 1, ndef=0)); add(I("s_cbranch_scc1", f"L_par_h1_{st}", ndef=0))
+        add(I("s_mul_hi_u32", b, bh, self.s_magh)); add(I("s_mul_i32", t[7], b, self.s_H)); add(I("s_sub_u32", h, bh, t[7]))
+        add(I("s_branch", f"L_par_hd_{st}", ndef=0))
+        P.label(f"L_par_h1_{st}"); add(I("s_mov_b32", b, bh)); add(I("s_mov_b32", h, 0))
+        P.label(f"L_par_hd_{st}")
+        # sequence: padded [B, S_max] or packed (cu_seqlens)
+        add(I("s_cmp_eq_u64", self.s_cu, 0, ndef=0)); add(I("s_cbranch_scc1", f"L_par_pad_{st}", ndef=0))
+        add(I("s_lshl_b32", t[7], b, 2)); add(I("s_load_dwordx2", self.s_t64, self.s_cu, t[7])); add(s_waitcnt(lgkm=0))
+        add(I("s_mov_b32", tok0, self.s_t64[0])); add(I("s_sub_u32", S_, self.s_t64[1], self.s_t64[0]))
+        add(I("s_branch", f"L_par_seq_{st}", ndef=0))
+        P.label(f"L_par_pad_{st}"); add(I("s_mul_i32", tok0, b, self.s_smax)); add(I("s_mov_b32", S_, self.s_smax))
+        P.label(f"L_par_seq_{st}")
+        rq = self.s_rn if nxt else self.s_rq
+        add(I("s_mul_i32", t[7], tok0, self.s_ld2)); add(I("s_mul_hi_u32", t[0], tok0, self.s_ld2))           # (bh is dead from here)
+        add(I("s_add_u32", rq[0], self.s_qkv[0], t[7])); add(I("s_addc_u32", rq[1], self.s_qkv[1], t[0]))
+        add(I("s_and_b32", rq[1], rq[1], 0xffff))
+        add(I("s_mul_i32", rq[2], S_, self.s_ld2)); add(I("s_mov_b32", rq[3], 0x00020000))
+        if not nxt:
+            add(I("s_mov_b32", self.s_numrec, rq[2])); add(I("s_mov_b32", self.s_S, S_)); add(I("s_mov_b32", self.s_h, h)); add(I("s_mov_b32", self.s_j, j))
+            add(I("s_mul_i32", t[7], tok0, self.s_outrow)); add(I("s_mul_hi_u32", t[0], tok0, self.s_outrow))
+            add(I("s_add_u32", self.s_ro[0], self.s_out[0], t[7])); add(I("s_addc_u32", self.s_ro[1], self.s_out[1], t[0]))
+            add(I("s_and_b32", self.s_ro[1], self.s_ro[1], 0xffff))
+            add(I("s_mul_i32", self.s_ro[2], S_, self.s_outrow)); add(I("s_mov_b32", self.s_ro[3], 0x00020000))
+            add(I("s_mul_i32", t[7], b, self.s_H)); add(I("s_add_u32", t[7], t[7], h)); add(I("s_mul_i32", self.s_lsebase, t[7], self.s_smax))
+        # K / V column offsets of this wave's DMA pieces
+        kcol, vcol = (self.s_kcoln, self.s_vcoln) if nxt else (self.s_kcol, self.s_vcol)
+        add(I("s_add_u32", t[7], self.s_H, h)); add(I("s_lshl_b32", t[7], t[7], 8))
+        add(I("s_lshr_b32", t[0], self.s_w, 1)); add(I("s_lshl_b32", t[1], self.s_ld2, 5)); add(I("s_mul_i32", t[0], t[0], t[1]))
+        add(I("s_and_b32", t[1], self.s_w, 1)); add(I("s_lshl_b32", t[1], t[1], 7))
+        add(I("s_add_u32", kcol, t[7], t[0])); add(I("s_add_u32", kcol, kcol, t[1]))
+        add(I("s_lshl_b32", t[7], self.s_H, 1)); add(I("s_add_u32", t[7], t[7], h)); add(I("s_lshl_b32", vcol, t[7], 8))
+        if nxt: add(I("s_lshl_b32", self.s_hqn, h, 8))
+        # this wave's blocks: bA = 8 j + w, bB = bA + 4
+        rb0, rb1 = (self.s_rb0n, self.s_rb1n) if nxt else (self.s_rb0, self.s_rb1)
+        add(I("s_add_u32", t[0], S_, 31)); add(I("s_lshr_b32", t[0], t[0], 5))                             # nblk
+        add(I("s_lshl_b32", t[1], j, 3)); add(I("s_add_u32", t[2], t[1], self.s_w)); add(I("s_add_u32", t[3], t[2], 4))
+        add(I("s_lshl_b32", rb0, t[2], 5)); add(I("s_lshl_b32", t[7], t[3], 5))
+        if nxt:
+            add(I("s_cmp_lt_u32", t[3], t[0], ndef=0)); add(I("s_cselect_b32", rb1, t[7], rb0))
+        else:
+            add(I("s_add_u32", t[5], t[2], 1)); add(I("s_add_u32", t[6], t[3], 1))                         # bA + 1, bB + 1  (S_, tok0 are dead)
+            add(I("s_cmp_lt_u32", t[2], t[0], ndef=0)); add(I("s_cselect_b32", t[4], t[5], 0))             # validA ? bA + 1 : 0  (j is dead)
+            add(I("s_cmp_lt_u32", t[3], t[0], ndef=0))
+            add(I("s_cselect_b32", self.s_n1, t[6], t[4])); add(I("s_cselect_b32", self.s_n0, t[5], 0))
+            add(I("s_cselect_b32", rb1, t[7], rb0))
+            # key tiles of the item: ceil(min(8 j + 8, nblk) / 2), none if the block lies past the sequence
+            add(I("s_add_u32", t[2], t[1], 8)); add(I("s_min_u32", t[2], t[2], t[0])); add(I("s_add_u32", t[2], t[2], 1)); add(I("s_lshr_b32", t[2], t[2], 1))
+            add(I("s_cmp_lt_u32", t[1], t[0], ndef=0)); add(I("s_cselect_b32", self.s_nT, t[2], 0))
+
+    def q_prefetch(self, rsrc, rb0, rb1, hq):
+        """16 loads: the Q rows of both blocks -> vQN."""
+        X = self.vX
+        out = []
+        for qb, rb in ((0, rb0), (1, rb1)):
+            out += [I("v_add_u32", X[0], rb, self.vL31), I("v_mul_lo_u32", X[0], X[0], self.s_ld2),
+                    I("v_lshlrev_b32", X[1], 4, self.vHI), I("v_add3_u32", X[2 + qb], X[0], X[1], hq)]
+            for ks in range(8):
+                out.append(I("buffer_load_dwordx4", self.vQN.sub(32 * qb + 4 * ks, 4), X[2 + qb], rsrc, 0, mods=f"offen offset:{32 * ks}"))
+        return out
+
+    def queue_pop(self):
+        """wave 0, lane 0: vATOM = fetch_add(queue[xcd], 1) (device scope); consumed one item later."""
+        st = self.new_site()
+        return [I("s_cmp_eq_u32", self.s_w, 0, ndef=0), I("s_cbranch_scc0", f"L_pop_{st}", ndef=0),
+                I("s_mov_b64", EXEC, 1), I("v_mov_b32", self.vX[0], 0), I("v_mov_b32", self.vX[1], 1),
+                I("global_atomic_add", self.vATOM, self.vX[0], self.vX[1], self.s_qx, mods="sc0 sc1"),
+                I("s_mov_b64", EXEC, -1), Label(f"L_pop_{st}")]
+
+    def stamp(self, k):
+        """prof: add the cycles since the previous stamp to sum k."""
+        if not self.prof: return []
+        return [s_waitcnt(lgkm=0), I("s_memtime", self.s_tm), s_waitcnt(lgkm=0),
+                I("s_sub_u32", self.s_t[7], self.s_tm[0], self.s_t0), I("s_mov_b32", self.s_t0, self.s_tm[0]),
+                I("s_mov_b64", EXEC, 1 << k), I("v_add_u32", self.vPACC, self.s_t[7], self.vPACC), I("s_mov_b64", EXEC, -1)]
 
     # ---- the whole kernel ----------------------------------------------------------------------------------------------
     def build(self):
         P = Program()
-        s, v = self, self
         t = self.s_t
-        sa0, sa1 = self.s_args0, self.s_args1
         add = P.add
-        # ------------------------------------------------------------------ arguments, mapping
-        add(I("s_load_dwordx8", sa0, self.s_karg, 0x0))
-        add(I("s_load_dwordx8", sa1, self.s_karg, 0x20))
+        X = self.vX
+        # ------------------------------------------------------------------ arguments, per-lane constants
+        add(I("s_load_dwordx8", self.s_args0, self.s_karg, 0x0))
+        add(I("s_load_dwordx8", self.s_args1, self.s_karg, 0x20))
+        add(I("s_load_dwordx4", self.s_args2, self.s_karg, 0x40))
         if self.prof:
-            add(I("s_load_dwordx2", self.s_prof, self.s_karg, 0x40))
-            add(I("s_memtime", self.s_stamp[0]))
-            for k in range(4): add(I("v_mov_b32", self.vPROF[k], 0))
+            add(I("s_load_dwordx2", self.s_prof, self.s_karg, 0x50))
+            add(I("v_mov_b32", self.vPACC, 0))
         add(I("v_and_b32", self.vLANE, 63, self.v_tid))
-        add(I("v_lshrrev_b32", self.vX[0], 6, self.v_tid))
+        add(I("v_lshrrev_b32", X[0], 6, self.v_tid))
         add(I("v_and_b32", self.vL31, 31, self.vLANE))
         add(I("v_lshrrev_b32", self.vHI, 5, self.vLANE))
         add(s_nop(0))
-        add(I("v_readfirstlane_b32", self.s_w, self.vX[0]))
+        add(I("v_readfirstlane_b32", self.s_w, X[0]))
         add(s_waitcnt(lgkm=0))
-        # XCD-aware order: workgroup id -> logical id (consecutive logical ids on one XCD)
-        add(I("s_and_b32", t[0], self.s_wg, 7)); add(I("s_lshr_b32", t[1], self.s_total, 3)); add(I("s_and_b32", t[2], self.s_total, 7))
-        add(I("s_mul_i32", t[3], t[0], t[1])); add(I("s_min_u32", t[4], t[0], t[2])); add(I("s_add_u32", t[3], t[3], t[4]))
-        add(I("s_lshr_b32", t[4], self.s_wg, 3)); add(I("s_add_u32", t[3], t[3], t[4]))             # t3 = logical id
-        # bh = id / nqb, jj = id % nqb
-        add(I("s_cmp_eq_u32", self.s_nqb, 1, ndef=0)); add(I("s_cbranch_scc1", "L_nqb1", ndef=0))
-        add(I("s_mul_hi_u32", t[4], t[3], self.s_magq)); add(I("s_mul_i32", t[5], t[4], self.s_nqb)); add(I("s_sub_u32", t[5], t[3], t[5]))
-        add(I("s_branch", "L_nqb_done", ndef=0))
-        P.label("L_nqb1"); add(I("s_mov_b32", t[4], t[3])); add(I("s_mov_b32", t[5], 0))
-        P.label("L_nqb_done")
-        add(I("s_sub_u32", self.s_j, self.s_nqb, t[5])); add(I("s_sub_u32", self.s_j, self.s_j, 1))  # heaviest block first
-        add(I("s_cmp_eq_u32", self.s_H, 1, ndef=0)); add(I("s_cbranch_scc1", "L_h1", ndef=0))
-        add(I("s_mul_hi_u32", self.s_b, t[4], self.s_magh)); add(I("s_mul_i32", t[6], self.s_b, self.s_H)); add(I("s_sub_u32", self.s_h, t[4], t[6]))
-        add(I("s_branch", "L_h_done", ndef=0))
-        P.label("L_h1"); add(I("s_mov_b32", self.s_b, t[4])); add(I("s_mov_b32", self.s_h, 0))
-        P.label("L_h_done")
-        # sequence: padded [B, S_max] or packed (cu_seqlens)
-        add(I("s_cmp_eq_u64", self.s_cu, 0, ndef=0)); add(I("s_cbranch_scc1", "L_padded", ndef=0))
-        add(I("s_lshl_b32", t[0], self.s_b, 2)); add(I("s_load_dwordx2", self.s_t64, self.s_cu, t[0])); add(s_waitcnt(lgkm=0))
-        add(I("s_mov_b32", self.s_tok0, self.s_t64[0])); add(I("s_sub_u32", self.s_S, self.s_t64[1], self.s_t64[0]))
-        add(I("s_branch", "L_seq_done", ndef=0))
-        P.label("L_padded"); add(I("s_mul_i32", self.s_tok0, self.s_b, self.s_smax)); add(I("s_mov_b32", self.s_S, self.s_smax))
-        P.label("L_seq_done")
-        add(I("s_lshl_b32", t[0], self.s_j, 8)); add(I("s_cmp_ge_u32", t[0], self.s_S, ndef=0)); add(I("s_cbranch_scc1", "L_exit", ndef=0))
-        # descriptors over this sample's rows
-        add(I("s_lshl_b32", self.s_ld2, self.s_ld, 1))
-        add(I("s_mul_i32", t[0], self.s_tok0, self.s_ld2)); add(I("s_mul_hi_u32", t[1], self.s_tok0, self.s_ld2))
-        add(I("s_add_u32", self.s_rq[0], self.s_qkv[0], t[0])); add(I("s_addc_u32", self.s_rq[1], self.s_qkv[1], t[1]))
-        add(I("s_and_b32", self.s_rq[1], self.s_rq[1], 0xffff))
-        add(I("s_mul_i32", self.s_numrec, self.s_S, self.s_ld2)); add(I("s_mov_b32", self.s_rq[2], self.s_numrec)); add(I("s_mov_b32", self.s_rq[3], 0x00020000))
-        add(I("s_mov_b32", self.s_rd[0], self.s_rq[0])); add(I("s_mov_b32", self.s_rd[1], self.s_rq[1]))
-        add(I("s_mov_b32", self.s_rd[2], self.s_numrec)); add(I("s_mov_b32", self.s_rd[3], 0x00020000))
-        add(I("s_lshl_b32", self.s_outrow, self.s_H, 8))
-        add(I("s_mul_i32", t[0], self.s_tok0, self.s_outrow)); add(I("s_mul_hi_u32", t[1], self.s_tok0, self.s_outrow))
-        add(I("s_add_u32", self.s_ro[0], self.s_out[0], t[0])); add(I("s_addc_u32", self.s_ro[1], self.s_out[1], t[1]))
-        add(I("s_and_b32", self.s_ro[1], self.s_ro[1], 0xffff))
-        add(I("s_mul_i32", self.s_ro[2], self.s_S, self.s_outrow)); add(I("s_mov_b32", self.s_ro[3], 0x00020000))
-        add(I("s_mul_i32", t[0], self.s_b, self.s_H)); add(I("s_add_u32", t[0], t[0], self.s_h)); add(I("s_mul_i32", self.s_lsebase, t[0], self.s_smax))
-        # this wave's blocks
-        add(I("s_add_u32", t[0], self.s_S, 31)); add(I("s_lshr_b32", t[0], t[0], 5))                      # nblk
-        add(I("s_lshl_b32", t[1], self.s_j, 3)); add(I("s_add_u32", t[2], t[1], self.s_w)); add(I("s_add_u32", t[3], t[2], 4))   # bA, bB
-        add(I("s_lshl_b32", self.s_rb0, t[2], 5))
-        add(I("s_add_u32", t[4], t[2], 1)); add(I("s_add_u32", t[5], t[3], 1))                             # bA + 1, bB + 1
-        add(I("s_lshl_b32", t[7], t[3], 5))                                                            # (SALU shifts / adds clobber SCC:
-        add(I("s_cmp_lt_u32", t[2], t[0], ndef=0)); add(I("s_cselect_b32", t[6], t[4], 0))                   #  compare and selects stay adjacent)
-        add(I("s_cmp_lt_u32", t[3], t[0], ndef=0))
-        add(I("s_cselect_b32", self.s_n1, t[5], t[6])); add(I("s_cselect_b32", self.s_n0, t[4], 0))
-        add(I("s_cselect_b32", self.s_rb1, t[7], self.s_rb0))
-        add(I("s_add_u32", t[1], t[1], 8)); add(I("s_min_u32", t[1], t[1], t[0])); add(I("s_add_u32", t[1], t[1], 1)); add(I("s_lshr_b32", self.s_nT, t[1], 1))
-        # DMA constants
+        if self.prof:
+            add(I("s_memtime", self.s_tm)); add(s_waitcnt(lgkm=0)); add(I("s_mov_b32", self.s_t0, self.s_tm[0]))
+        add(I("s_lshl_b32", self.s_ld2, self.s_ld, 1)); add(I("s_lshl_b32", self.s_outrow, self.s_H, 8))
         add(I("s_lshl_b32", self.s_tile, self.s_ld2, 6)); add(I("s_lshl_b32", self.s_r16, self.s_ld2, 4))
-        add(I("s_add_u32", t[0], self.s_H, self.s_h)); add(I("s_lshl_b32", t[0], t[0], 8))                  # K column bytes
-        add(I("s_lshr_b32", t[1], self.s_w, 1)); add(I("s_lshl_b32", t[2], self.s_ld2, 5)); add(I("s_mul_i32", t[1], t[1], t[2]))
-        add(I("s_and_b32", t[2], self.s_w, 1)); add(I("s_lshl_b32", t[2], t[2], 7))                         # 4 (w & 1) * 32
-        add(I("s_add_u32", self.s_kcol, t[0], t[1])); add(I("s_add_u32", self.s_kcol, self.s_kcol, t[2]))
-        add(I("s_lshl_b32", t[0], self.s_H, 1)); add(I("s_add_u32", t[0], t[0], self.s_h)); add(I("s_lshl_b32", self.s_vcol, t[0], 8))
-        # per-lane constants
-        X = self.vX
         add(I("v_mov_b32", self.vNINF, NEG_INF))
         add(I("v_lshlrev_b32", X[0], 2, self.vHI)); add(I("v_sub_u32", self.vLIM, self.vL31, X[0]))
         add(I("v_lshlrev_b32", self.vKADDR, 4, self.vLANE))
@@ -428,47 +539,82 @@ class Gen:
         add(I("v_lshl_or_b32", X[2], X[0], 2, self.s_w))                                        # swz = ((lane >> 4) << 2) | w
         add(I("v_and_b32", X[3], 15, self.vLANE)); add(I("v_xor_b32", X[3], X[3], X[2]))
         add(I("v_lshl_add_u32", self.vVOFF, X[3], 4, X[1]))
-        # ------------------------------------------------------------------ prologue DMA: K tile 0 -> staging, stages 0 and 1
-        add(I("s_lshl_b32", t[0], self.s_w, 12))                                                # 4 w * 1024
-        add(I("s_lshl_b32", t[1], self.s_w, 10))
-        add(I("s_mov_b32", self.s_ktile, self.s_kcol)); add(I("s_mov_b32", self.s_vtile, self.s_vcol))
-        add(I("s_add_u32", self.s_m0k, t[0], STAGING)); add(I("s_mov_b32", self.s_m0v, 0))
-        k0 = self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd)[:4]          # K tile 0 only
-        for g in k0: add(g)
-        add(I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile))                            # stage 0 = K1, V0 -> slot 0
-        add(I("s_mov_b32", self.s_m0k, t[0])); add(I("s_add_u32", self.s_m0v, t[1], V_IN_SLOT))
-        for g in self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd): add(g)
-        add(I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile)); add(I("s_add_u32", self.s_vtile, self.s_vtile, self.s_tile))
-        add(I("s_add_u32", self.s_m0k, self.s_m0k, SLOT)); add(I("s_add_u32", self.s_m0v, self.s_m0v, SLOT))     # stage 1 -> slot 1
-        for g in self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd): add(g)
-        add(I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile)); add(I("s_add_u32", self.s_vtile, self.s_vtile, self.s_tile))
-        add(I("s_sub_u32", self.s_m0k, self.s_m0k, SLOT)); add(I("s_sub_u32", self.s_m0v, self.s_m0v, SLOT))     # next: stage 2 -> slot 0
-        # Q fragments straight into AccVGPRs
+        # ------------------------------------------------------------------ this XCD's queue
+        # workgroup g runs on XCD g % 8 (observed, for L2 locality only: correctness rests on the queue counter being device scope);
+        # XCD x owns the pairs [bh0, bh0 + nbh) and its workgroups pop queue[x]
+        add(I("s_and_b32", t[0], self.s_wg, 7)); add(I("s_lshr_b32", t[1], self.s_wg, 3))                  # x, c
+        add(I("s_lshr_b32", t[2], self.s_G, 3)); add(I("s_and_b32", t[3], self.s_G, 7))
+        add(I("s_cmp_lt_u32", t[0], t[3], ndef=0)); add(I("s_cselect_b32", t[3], 1, 0)); add(I("s_add_u32", self.s_nwg, t[2], t[3]))
+        add(I("s_lshr_b32", t[2], self.s_BH, 3)); add(I("s_and_b32", t[3], self.s_BH, 7))
+        add(I("s_mul_i32", t[4], t[0], t[2])); add(I("s_min_u32", t[5], t[0], t[3])); add(I("s_add_u32", self.s_bh0, t[4], t[5]))
+        add(I("s_cmp_lt_u32", t[0], t[3], ndef=0)); add(I("s_cselect_b32", t[3], 1, 0)); add(I("s_add_u32", t[2], t[2], t[3]))   # nbh
+        add(I("s_mul_i32", self.s_items, t[2], self.s_nqb))
+        add(I("s_and_b32", self.s_rem, t[2], 7)); add(I("s_lshr_b32", t[3], t[2], 3)); add(I("s_lshl_b32", t[3], t[3], 3))
+        add(I("s_mul_i32", self.s_split, t[3], self.s_nqb))
+        add(I("s_lshl_b32", t[4], t[0], 6)); add(I("s_add_u32", self.s_qx[0], self.s_queue[0], t[4])); add(I("s_addc_u32", self.s_qx[1], self.s_queue[1], 0))
+        add(I("s_cmp_ge_u32", t[1], self.s_items, ndef=0)); add(I("s_cbranch_scc1", "L_exit", ndef=0))
+        add(I("s_mov_b32", self.s_li, t[1]))
+        add(self.queue_pop())                                                                   # the index of the second item
+        add(I("s_mov_b32", self.s_bc, 0)); add(I("s_mov_b32", self.s_cs, 0))
+        self.emit_params(P, self.s_li, nxt=False)
+        # first item: nothing was prefetched by a predecessor -> first K tile, stages 0..2, Q now
+        add(I("s_mov_b32", self.s_rd[0], self.s_rq[0])); add(I("s_mov_b32", self.s_rd[1], self.s_rq[1]))
+        add(I("s_mov_b32", self.s_rd[2], self.s_rq[2])); add(I("s_mov_b32", self.s_rd[3], self.s_rq[3]))
+        add(self.dma_k0_ins(self.s_kcol, self.s_rd))
+        add(I("s_add_u32", self.s_ktile, self.s_kcol, self.s_tile)); add(I("s_mov_b32", self.s_vtile, self.s_vcol))
+        add(I("s_mov_b32", t[5], 0)); add(self.dma_set_slot(t[5]))
+        for _ in range(3):
+            for g in self.dma_stage_ins(): add(g)
+            add(self.dma_advance())
+        add(I("s_lshl_b32", t[5], self.s_h, 8))
+        add(self.q_prefetch(self.s_rq, self.s_rb0, self.s_rb1, t[5]))
+        # ================================================================== item
+        P.label("L_item")
+        add(s_waitcnt(vm=0))                              # this item's Q (vQN), first K tile and stages (this wave's pieces), the queue pop
+        st = self.new_site()
+        add(I("s_cmp_eq_u32", self.s_w, 0, ndef=0)); add(I("s_cbranch_scc0", f"L_bc_{st}", ndef=0))
+        add(s_nop(0)); add(I("v_readfirstlane_b32", t[0], self.vATOM)); add(I("s_add_u32", t[0], t[0], self.s_nwg))
+        add(I("v_mov_b32", X[0], t[0])); add(I("s_add_u32", t[1], self.s_bc, BCAST)); add(I("v_mov_b32", X[1], t[1]))
+        add(I("ds_write_b32", X[1], X[0], ndef=0))
+        P.label(f"L_bc_{st}")
         for qb in range(2):
-            rb = self.s_rb0 if qb == 0 else self.s_rb1
-            add(I("v_add_u32", X[0], rb, self.vL31)); add(I("v_mul_lo_u32", X[0], X[0], self.s_ld2))
-            add(I("s_lshl_b32", t[2], self.s_h, 8))
-            add(I("v_lshlrev_b32", X[1], 4, self.vHI)); add(I("v_add3_u32", X[2 + qb], X[0], X[1], t[2]))
-            for ks in range(8):
-                add(I("buffer_load_dwordx4", self.aQ[qb].sub(4 * ks, 4), X[2 + qb], self.s_rq, 0, mods=f"offen offset:{32 * ks}"))
-        # O = 0, softmax state
+            for i in range(32): add(I("v_accvgpr_write_b32", self.aQ[qb][i], self.vQN[32 * qb + i]))
         for qb in range(2):
             for i in range(64): add(I("v_accvgpr_write_b32", self.aO[qb][i], 0))
             add(I("v_mov_b32", self.vL[qb], 0)); add(I("v_mov_b32", self.vALPHA[qb], 1.0))
         add(I("s_mov_b32", self.s_pend, 0)); add(I("s_mov_b32", self.s_step, 0)); add(I("s_mov_b32", self.s_U, 0))
-        add(s_waitcnt(vm=0)); add(I("s_barrier", ndef=0))
-        if self.prof: add(I("s_memtime", self.s_stamp[1])); add(s_waitcnt(lgkm=0))
+        add(I("s_mov_b32", self.s_cs0, self.s_cs))
+        add(s_waitcnt(lgkm=0)); add(I("s_barrier", ndef=0))
+        add(self.stamp(0))
+        # the next item: queue index from wave 0, then the parameters its prefetch needs
+        add(I("s_add_u32", t[1], self.s_bc, BCAST)); add(I("v_mov_b32", X[1], t[1])); add(I("ds_read_b32", X[0], X[1])); add(s_waitcnt(lgkm=0))
+        add(I("v_readfirstlane_b32", self.s_lin, X[0])); add(I("s_xor_b32", self.s_bc, self.s_bc, 4))
+        add(I("s_cmp_lt_u32", self.s_lin, self.s_items, ndef=0)); add(I("s_cbranch_scc1", "L_next_valid", ndef=0))
+        for i in range(4): add(I("s_mov_b32", self.s_rn[i], self.s_rq[i]))
+        add(I("s_mov_b32", self.s_rn[2], 0))                                                    # no next item: its loads fetch nothing
+        add(I("s_mov_b32", self.s_kcoln, 0)); add(I("s_mov_b32", self.s_vcoln, 0)); add(I("s_mov_b32", self.s_rb0n, 0)); add(I("s_mov_b32", self.s_rb1n, 0))
+        add(I("s_mov_b32", self.s_hqn, 0))
+        add(I("s_branch", "L_next_done", ndef=0))
+        P.label("L_next_valid")
+        self.emit_params(P, self.s_lin, nxt=True)
+        P.label("L_next_done")
+        # the DMA stream continues with this item's stage 3 (stages 0..2 were issued by the predecessor)
+        for i in range(4): add(I("s_mov_b32", self.s_rd[i], self.s_rq[i]))
+        add(I("s_lshl_b32", t[0], self.s_tile, 2)); add(I("s_add_u32", self.s_ktile, self.s_kcol, t[0]))
+        add(I("s_sub_u32", t[0], t[0], self.s_tile)); add(I("s_add_u32", self.s_vtile, self.s_vcol, t[0]))
+        add(self.dma_set_slot(self.s_cs))
+        add(I("s_mov_b32", self.s_dso, 3)); add(I("s_mov_b32", self.s_nu, 0))
         # idle wave (no valid block): it still serves the barriers and its share of the DMA
-        add(I("s_cmp_eq_u32", self.s_n1, 0, ndef=0)); add(I("s_cbranch_scc1", "L_loop", ndef=0))
-        # QK of steps 0 and 1 from K tile 0 (staging), softmax of step 0, fragments for step 0's body
+        add(I("s_cmp_eq_u32", self.s_n1, 0, ndef=0)); add(I("s_cbranch_scc1", "L_after_step0", ndef=0))
+        # QK of steps 0 and 1 from the first K tile, softmax of step 0, fragments for step 0's body
         pro = []
-        add(I("v_add_u32", X[9], STAGING, self.vKADDR))
+        add(I("v_lshlrev_b32", X[9], 4, self.vLANE)); add(I("v_add_u32", X[9], K0AREA, X[9]))
         for half in range(2):
             for ks in range(8): pro.append(self.k_read(ks, half, addr=X[9]))
             for ks in range(8):
                 for qb in range(2): pro.append(self.qk(qb, half, ks))
         for ks in range(8): pro.append(self.k_read(ks, 0))                                      # K tile 1 half 0 -> QK of step 2
-        for j in range(8): pro += self.v_reads(j >> 2, j & 3, 0)                                # V tile 0 half 0 -> PV of step 0
+        for jx in range(8): pro += self.v_reads(jx >> 2, jx & 3, 0)                             # V tile 0 half 0 -> PV of step 0
         pro, _ = add_lgkm_waits(pro)
         add(pro)
         add(s_nop(15))
@@ -485,32 +631,26 @@ class Gen:
             for fl in self.sm_stream(qb, 0, init=True): add(fl.ins)
             P.label(f"L_pro_skip_{st}")
         add(s_waitcnt(lgkm=0))
-        # step 0 = a "second" body on slot 0
+        # step 0 = a "second" body
         add(I("s_cmp_lg_u32", self.s_n0, 0, ndef=0)); add(I("s_cbranch_scc0", "L_step0_S", ndef=0))
-        self.bodies = {}
-        b = self.finish_body(self.body("D", first=False), "step0_D"); add(b)
-        add(I("s_branch", "L_loop_entry" if self.prof else "L_loop", ndef=0))
+        add(self.finish_body(self.body("D", first=False), "step0_D"))
+        add(I("s_branch", "L_after_step0", ndef=0))
         P.label("L_step0_S")
-        b = self.finish_body(self.body("S", first=False), "step0_S"); add(b)
+        add(self.finish_body(self.body("S", first=False), "step0_S"))
+        P.label("L_after_step0")
+        add(self.stamp(1))
+        add(I("s_cmp_eq_u32", self.s_nT, 0, ndef=0)); add(I("s_cbranch_scc1", "L_flush", ndef=0))
+        add(self.consumer_advance())
         # ------------------------------------------------------------------ main loop: iteration U = steps 2U+1, 2U+2 on stage U+1
-        if self.prof:
-            add(I("s_branch", "L_loop_entry", ndef=0))
         P.label("L_loop")
-        if self.prof:
-            add(I("s_branch", "L_loop2", ndef=0))
-            P.label("L_loop_entry")
-            add(s_waitcnt(lgkm=0)); add(I("s_memtime", self.s_stamp[2])); add(s_waitcnt(lgkm=0))
-            P.label("L_loop2")
-        add(I("s_cmp_ge_u32", self.s_U, self.s_nT, ndef=0)); add(I("s_cbranch_scc1", "L_epilogue", ndef=0))
-        def itstamp(k):
-            if self.prof:
-                add(s_waitcnt(lgkm=0)); add(I("s_memtime", self.s_it)); add(s_waitcnt(lgkm=0))
-                add(I("s_mov_b32", M0, self.s_U)); add(I("v_writelane_b32", self.vPROF[k], self.s_it[0], M0, rw=True))
-        itstamp(0)
-        add(s_waitcnt(vm=0)); add(I("s_barrier", ndef=0))
-        itstamp(1)
-        # the stage issued now is U + 2 (K tile U+3, V tile U+2): nothing to fetch once U + 2 >= nT
-        add(I("s_add_u32", t[0], self.s_U, 2)); add(I("s_cmp_lt_u32", t[0], self.s_nT, ndef=0)); add(I("s_cselect_b32", self.s_rd[2], self.s_numrec, 0))
+        add(s_waitcnt(vm=8))                              # everything but the 8 pieces of the previous iteration has landed
+        add(I("s_barrier", ndef=0))
+        # what the DMA stream issues in this iteration: the item's next stage, or a unit of the NEXT item
+        add(I("s_cmp_lt_u32", self.s_dso, self.s_nT, ndef=0)); add(I("s_cbranch_scc0", "L_duty_next", ndef=0))
+        add(I("s_add_u32", self.s_dso, self.s_dso, 1)); add(I("s_branch", "L_duty_done", ndef=0))
+        P.label("L_duty_next")
+        add(self.next_unit_prepare("loop"))
+        P.label("L_duty_done")
         add(I("s_lshl_b32", t[1], self.s_U, 1)); add(I("s_add_u32", self.s_step, t[1], 1))
         for mode, lbl in (("D", "L_first_S"), ("S", "L_first_idle")):
             n = self.s_n0 if mode == "D" else self.s_n1
@@ -518,11 +658,10 @@ class Gen:
             add(self.finish_body(self.body(mode, first=True), f"first_{mode}"))
             add(I("s_branch", "L_second", ndef=0))
             P.label(lbl)
-        for g in self.dma_stage_ins(self.s_m0k, self.s_m0v, self.s_ktile, self.s_vtile, self.s_rd): add(g)   # idle wave: DMA only
+        if "nodma" not in self.abl:
+            for g in self.dma_stage_ins(): add(g)                                                # idle wave: DMA only
         P.label("L_second")
-        itstamp(2)
-        add(I("s_add_u32", self.s_ktile, self.s_ktile, self.s_tile)); add(I("s_add_u32", self.s_vtile, self.s_vtile, self.s_tile))
-        add(I("s_xor_b32", self.s_m0k, self.s_m0k, SLOT)); add(I("s_xor_b32", self.s_m0v, self.s_m0v, SLOT))
+        add(self.dma_advance())
         add(I("s_add_u32", self.s_step, self.s_step, 1))
         for mode, lbl in (("D", "L_second_S"), ("S", "L_second_idle")):
             n = self.s_n0 if mode == "D" else self.s_n1
@@ -531,59 +670,63 @@ class Gen:
             add(I("s_branch", "L_iter_end", ndef=0))
             P.label(lbl)
         P.label("L_iter_end")
-        itstamp(3)
-        add(I("s_add_u32", self.s_U, self.s_U, 1)); add(I("s_branch", "L_loop", ndef=0))
-        # ------------------------------------------------------------------ epilogue
+        add(I("s_add_u32", self.s_U, self.s_U, 1))
+        add(I("s_cmp_ge_u32", self.s_U, self.s_nT, ndef=0)); add(I("s_cbranch_scc1", "L_flush", ndef=0))
+        add(self.consumer_advance())                      # (not after the last iteration: the ring position of the next item's stage 0)
+        add(I("s_branch", "L_loop", ndef=0))
+        # ------------------------------------------------------------------ what is left of the next item's units (short items)
+        P.label("L_flush")
+        add(self.stamp(2))
+        add(I("s_cmp_ge_u32", self.s_nu, 3, ndef=0)); add(I("s_cbranch_scc1", "L_epilogue", ndef=0))
+        add(self.next_unit_prepare("flush"))
+        for g in self.dma_stage_ins(): add(g)
+        add(self.dma_advance())
+        add(I("s_branch", "L_flush", ndef=0))
+        # ------------------------------------------------------------------ epilogue, next item
         P.label("L_epilogue")
         add(s_nop(15))
-        add(s_waitcnt(vm=0, lgkm=0))
-        if self.prof: add(I("s_memtime", self.s_stamp[3])); add(s_waitcnt(lgkm=0))
+        add(s_waitcnt(lgkm=0))
         for qb in range(2): add(self.epilogue(qb))
+        add(self.stamp(3))
+        add(I("s_cmp_lt_u32", self.s_lin, self.s_items, ndef=0)); add(I("s_cbranch_scc0", "L_done", ndef=0))
+        add(I("s_mov_b32", self.s_li, self.s_lin))
+        self.emit_params(P, self.s_li, nxt=False)
+        add(self.stamp(4))
+        add(I("s_branch", "L_item", ndef=0))
+        P.label("L_done")
         if self.prof:
-            X = self.vX
-            add(s_waitcnt(vm=0)); add(I("s_memtime", self.s_stamp[4])); add(s_waitcnt(lgkm=0))
+            add(s_waitcnt(vm=0))
             add(I("s_cmp_eq_u64", self.s_prof, 0, ndef=0)); add(I("s_cbranch_scc1", "L_exit", ndef=0))
-            # 8 dwords per wave: [t1-t0, t2-t1, t3-t2, t4-t3, n0, n1, nT, j] at prof + (wg * 4 + w) * 32
-            for i in range(4):
-                add(I("s_sub_u32", t[i], self.s_stamp[i + 1][0], self.s_stamp[i][0]))
-            vals = [t[0], t[1], t[2], t[3], self.s_n0, self.s_n1, self.s_nT, self.s_j]
-            for i, sv in enumerate(vals): add(I("v_mov_b32", X[i], sv))
+            # 8 dwords per wave at prof + (wg * 4 + w) * 32: lane k < 5 stores cycle sum k
             add(I("s_lshl_b32", t[4], self.s_wg, 2)); add(I("s_add_u32", t[4], t[4], self.s_w)); add(I("s_lshl_b32", t[4], t[4], 5))
-            add(I("v_mov_b32", X[8], t[4]))
-            add(I("v_cmp_eq_u32", self.s_m64, 0, self.vLANE))
-            add(I("s_and_saveexec_b64", self.s_exec, self.s_m64, xdef=[EXEC]))
-            add(I("global_store_dwordx4", X[8], X[0:4], self.s_prof, ndef=0))
-            add(I("global_store_dwordx4", X[8], X[4:8], self.s_prof, ndef=0, mods="offset:16"))
-            add(I("s_mov_b64", EXEC, self.s_exec))
-            # iteration stamps behind the summary records: base = total_wgs * 4 * 32 bytes
-            add(I("s_lshl_b32", t[5], self.s_total, 7)); add(I("s_lshl_b32", t[6], t[4], 5))      # (wg*4+w)*32 -> *1024
-            add(I("s_add_u32", t[5], t[5], t[6]))
-            add(I("v_lshlrev_b32", X[9], 2, self.vLANE)); add(I("v_add_u32", X[9], t[5], X[9]))
-            for k in range(4):
-                add(I("global_store_dword", X[9], self.vPROF[k], self.s_prof, ndef=0, mods=f"offset:{256 * k}"))
+            add(I("v_lshlrev_b32", X[8], 2, self.vLANE)); add(I("v_add_u32", X[8], t[4], X[8]))
+            add(I("s_mov_b64", EXEC, 0xff))
+            add(I("global_store_dword", X[8], self.vPACC, self.s_prof, ndef=0))
+            add(I("s_mov_b64", EXEC, -1))
         P.label("L_exit")
         add(s_waitcnt(vm=0))
         add(I("s_endpgm", ndef=0))
         add(self.ool)
         return P
 
-    def finish_body(self, items, tag):
-        # the entry state of every body: the 24 reloads of the previous step in canonical order, all possibly outstanding
-        canon = []
-        for j in range(8):
-            canon.append(self.aK.sub(4 * j, 4).ids())
-            base = self.aV.sub(4 * j, 4)
-            canon += [base.sub(0, 2).ids(), base.sub(2, 2).ids()]
-        items, pend = add_lgkm_waits(items, initial=canon)
-        tail = [x for x in items if isinstance(x, Ins)][-20:]
-        items = fix_hazards(items, tag, self.report, carry=tail)
-        if self.debug_serial:
-            out = []
-            for x in items:
-                out.append(x)
-                if isinstance(x, Ins) and (x.is_mfma or x.is_lds or x.is_valu): out += [s_waitcnt(lgkm=0), s_nop(15)]
-            items = out
-        return items
+    def next_unit_prepare(self, tag):
+        """Set the DMA stream up for unit s_nu of the NEXT item (0: first K tile + stage 0, 1: stage 1, 2: stage 2 + Q rows + the
+        queue pop for the item after), then count it.  The 8 stage pieces themselves are issued by the caller."""
+        t = self.s_t
+        st = self.new_site()
+        out = [I("s_cmp_eq_u32", self.s_nu, 0, ndef=0), I("s_cbranch_scc0", f"L_nu_not0_{st}", ndef=0)]
+        for i in range(4): out.append(I("s_mov_b32", self.s_rd[i], self.s_rn[i]))
+        # ring slot of the next item's stage 0 = (slot at this item's start + nT) mod 3
+        out += [I("s_add_u32", t[5], self.s_cs0, self.s_nT), I("s_mul_hi_u32", t[4], t[5], 0x55555556), I("s_mul_i32", t[4], t[4], 3),
+                I("s_sub_u32", t[5], t[5], t[4])]
+        out += self.dma_set_slot(t[5])
+        out += self.dma_k0_ins(self.s_kcoln, self.s_rd)
+        out += [I("s_add_u32", self.s_ktile, self.s_kcoln, self.s_tile), I("s_mov_b32", self.s_vtile, self.s_vcoln)]
+        out += [Label(f"L_nu_not0_{st}"), I("s_cmp_eq_u32", self.s_nu, 2, ndef=0), I("s_cbranch_scc0", f"L_nu_not2_{st}", ndef=0)]
+        out += self.q_prefetch(self.s_rn, self.s_rb0n, self.s_rb1n, self.s_hqn)
+        out += self.queue_pop()
+        out += [Label(f"L_nu_not2_{st}"), I("s_add_u32", self.s_nu, self.s_nu, 1)]
+        return out
 
     def epilogue(self, qb):
         st = self.new_site()
@@ -610,7 +753,7 @@ class Gen:
         # O * (1/l) -> bf16 -> wave-private LDS block [32 rows][256 B], chunk c of row r at c ^ (r & 15)
         out += [I("v_lshlrev_b32", X[4], 8, self.vL31), I("v_lshl_add_u32", X[4], self.vHI, 3, X[4]),
                 I("v_and_b32", X[5], 15, self.vL31), I("v_lshl_add_u32", X[4], X[5], 4, X[4]),
-                I("s_lshl_b32", t[0], self.s_w, 13), I("s_add_u32", t[0], t[0], STAGING), I("v_add_u32", X[4], t[0], X[4])]
+                I("s_lshl_b32", t[0], self.s_w, 13), I("s_add_u32", t[0], t[0], OSTAGE), I("v_add_u32", X[4], t[0], X[4])]
         for db in range(4):
             for g in range(4):
                 c = 4 * db + g
@@ -621,7 +764,7 @@ class Gen:
                         I("v_xor_b32", X[5], c << 4, X[4]),
                         I("ds_write_b64", X[5], X[6:8], ndef=0)]
         out += [s_waitcnt(lgkm=0)]
-        # rows back out: instruction `it` covers rows 4 it + (lane >> 4), 16 B per lane
+        # rows back out: instruction `it` covers rows 4 it + (lane >> 4), 16 B per lane; all eight reads, then all eight stores
         out += [I("v_lshrrev_b32", X[0], 4, self.vLANE), I("v_and_b32", X[3], 15, self.vLANE),
                 I("v_xor_b32", X[5], X[3], X[0]), I("v_lshlrev_b32", X[5], 4, X[5]), I("v_lshl_add_u32", X[5], X[0], 8, X[5]),
                 I("v_add_u32", X[5], t[0], X[5]),
@@ -629,14 +772,15 @@ class Gen:
                 I("v_mul_lo_u32", X[2], X[0], self.s_outrow), I("v_lshl_add_u32", X[2], X[3], 4, X[2]),
                 I("s_mul_i32", t[1], rb, self.s_outrow), I("s_lshl_b32", t[2], self.s_h, 8), I("s_add_u32", t[1], t[1], t[2]),
                 I("s_lshl_b32", t[3], self.s_outrow, 2)]
+        buf = self.vS[0][0], self.vS[0][1]                    # (the score registers are free here: 8 x 4 registers of row data)
+        regs = [buf[it >> 2].sub(4 * (it & 3), 4) for it in range(8)]
         for it in range(8):
-            out += [I("v_xor_b32", X[4], (it & 3) << 6, X[5]),
-                    I("ds_read_b128", X[8:12], X[4], mods=f"offset:{1024 * it}"),
-                    s_waitcnt(lgkm=0),
-                    I("buffer_store_dwordx4", X[8:12], X[2], self.s_ro, t[1], ndef=0, mods="offen"),
-                    s_nop(1),
+            out += [I("v_xor_b32", X[4], (it & 3) << 6, X[5]), I("ds_read_b128", regs[it], X[4], mods=f"offset:{1024 * it}")]
+        for it in range(8):
+            out += [s_waitcnt(lgkm=7 - it),
+                    I("buffer_store_dwordx4", regs[it], X[2], self.s_ro, t[1], ndef=0, mods="offen"),
                     I("s_add_u32", t[1], t[1], t[3])]
-        out += [s_waitcnt(vm=0), Label(f"L_epi_skip_{st}")]
+        out += [s_nop(1), Label(f"L_epi_skip_{st}")]
         return fix_hazards(out, f"epilogue{qb}", self.report)
 
 
@@ -648,22 +792,19 @@ def generate(debug_serial=False, abl=(), prof=False, name=KNAME):
     hdr = ("// GENERATED by csrc/asm/attn_fwd_d128.py — do not edit.  Register map:\n" + g.S.listing() + "\n" + g.V.listing() + "\n"
            + g.A.listing() + "\n// hazard pads inserted: " + ", ".join(f"{t}={n}" for t, n in g.report))
     n_mfma = sum(1 for x in items if isinstance(x, Ins) and x.is_mfma)
-    args = ARGS + ([(8, 64, "global_buffer")] if prof else [])
+    args = ARGS + ([(8, 80, "global_buffer")] if prof else [])
     text = kernel_text(name, body, lds_bytes=LDS_BYTES, kernarg_bytes=KERNARG_BYTES + (8 if prof else 0), n_arch_vgpr=g.V.next,
                        n_acc_vgpr=256, n_sgpr=g.S.next + 2, args_meta=args, header_comment=hdr)
     return text, g, n_mfma
 
 
-# development variants (make DEV=1): cycle stamps and timing-only ablations, selected by the switch attn_fwd_asm = 2 + index
+# development variants (make DEV=1): cycle sums and timing-only ablations (hvlm_attn_fwd_asm_dev)
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
-                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("noqk", dict(prof=True, abl=("noqk",))),
-                ("nopv", dict(prof=True, abl=("nopv",))), ("nodmak", dict(prof=True, abl=("nodmak",))),
-                ("nodmav", dict(prof=True, abl=("nodmav",)))]
+                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds")))]
 
 
 def unique_labels(text, suffix):
-    import re
     return re.sub(r"\bL_([A-Za-z0-9_]+)", lambda m: f"L{suffix}_{m.group(1)}", text)
 
 

@@ -33,7 +33,7 @@
 
 namespace hvlm {
 // attention_asm.hip
-int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, int B, int S_max, int H, int ld, float scale_log2,
+int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, void* ws, int B, int S_max, int H, int ld, float scale_log2,
                              const int32_t* cu, hipStream_t st, int variant = 0, void* prof = nullptr);
 namespace {
 
@@ -1809,7 +1809,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   }
   if constexpr (DH == 128 && CAUSAL && !F16) {
     // the decoder's forward: hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_fwd_d128.py, attention_asm.hip)
-    if (config().attn_fwd_asm) return attn_fwd_d128_causal_asm(qkv, out, lse, B, S, H, ld, scale * LOG2E, cu, st);
+    if (config().attn_fwd_asm) return attn_fwd_d128_causal_asm(qkv, out, lse, ws, B, S, H, ld, scale * LOG2E, cu, st);
   }
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us
@@ -1917,7 +1917,7 @@ using namespace hvlm;
 // token amount is returned so callers keep passing a valid pointer), the backward only delta[B,H,S] fp32.
 extern "C" size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh) {
   (void)B; (void)S; (void)H; (void)dh;
-  return 256;
+  return 1024;            // the eight per-XCD work-queue counters of the persistent dh = 128 forward (64 bytes apart), zeroed per call
 }
 extern "C" size_t hvlm_attn_bwd_ws_bytes(int B, int S, int H, int dh) {
   (void)dh;

@@ -231,15 +231,24 @@ class HandsOnVLMForCausalLM:
     # ------------------------------------------------------------------------------------------
     # visual tokens (VisualToTokenHelper.pipeline, 'origin' + 'temporal_spatial_pool')
     # ------------------------------------------------------------------------------------------
-    def visual_tokens(self, image: torch.Tensor, keep_for_backward: bool = False, fp8: bool = False) -> torch.Tensor:
+    def visual_tokens(self, image: Optional[torch.Tensor], keep_for_backward: bool = False, fp8: bool = False,
+                      image_frames=None) -> torch.Tensor:
+        """image [B, T, 3, H, W] — or image_frames = (distinct frames [n, 3, H, W], frame index int32 [B * T], (B, T)), both on the
+        device: what hvlm.prefetch.DevicePrefetcher uploads when the collator's 10 x 10 tiling is found on the host (the index
+        replaces the device-side hash + verify of config.dedup_frames; frame (b, t) = distinct frame index[b * T + t])."""
         cfg = self.config
-        B, T = image.shape[:2]
         assert cfg.fuse_input_mode == "origin" and cfg.video_compress_mode == "temporal_spatial_pool", \
             "only fuse_input_mode='origin' + video_arch='temporal_spatial_pool' are on the hot path"
         d = cfg.mm_hidden_size
-        frames = image.reshape(B * T, *image.shape[2:])
         inv = None
-        if cfg.dedup_frames:
+        if image_frames is not None:
+            frames, inv, (B, T) = image_frames
+            assert frames.dim() == 4 and inv.numel() == B * T and frames.device == self.device and inv.device == self.device
+            inv = inv.to(torch.int64)
+        else:
+            B, T = image.shape[:2]
+            frames = image.reshape(B * T, *image.shape[2:])
+        if cfg.dedup_frames and image_frames is None:
             # EK100 clips repeat a 10-frame sequence 10x (handsonvlm/dataset/epic_dataset.py:90-95: [f0..f9]*10):
             # encode each distinct frame once.  Frames are matched by a 64-bit hash and then VERIFIED bit-for-bit,
             # so the result is identical to encoding all frames (falls back to no de-duplication otherwise).
@@ -461,14 +470,19 @@ class HandsOnVLMForCausalLM:
         read or clone the logits before calling backward, or pass keep_logits=True to get a detached copy."""
         cfg = self.config
         dev = self.device
-        B = image.shape[0]
+        image_frames = kwargs.get("image_frames")            # (distinct frames, frame index, (B, T)) from hvlm.prefetch, instead of `image`
+        B = image.shape[0] if image is not None else image_frames[2][0]
         if labels is not None:
             assert future_hands.shape == (B, 2, 5, 2), future_hands.shape
             assert contact_point is None or contact_point.shape == (B, 2), contact_point.shape
             assert future_valid.shape == (B, 2), future_valid.shape
             assert gt_label_valid is None or gt_label_valid.shape == (B,), gt_label_valid.shape
             future_hands = future_hands[:, :, 1:, :]
-        assert image.dim() == 5 and image.shape[:3] == (B, cfg.num_frames, 3), image.shape
+        if image is not None:
+            assert image.dim() == 5 and image.shape[:3] == (B, cfg.num_frames, 3), image.shape
+        else:
+            assert image_frames[2] == (B, cfg.num_frames) and image_frames[0].shape[1] == 3, image_frames[2]
+        n_frames = cfg.num_frames
         assert not use_cache and past_key_values is None, "KV cache is handled inside sample(); forward is cache-less"
         is_evaluate = kwargs.get("is_evaluate", False)
         training_pass = labels is not None and self.training
@@ -476,7 +490,7 @@ class HandsOnVLMForCausalLM:
 
         vis = kwargs.get("visual_tokens")
         G = cfg.vision.image_size // cfg.vision.patch_size
-        NV = vis.shape[1] if vis is not None else image.shape[1] + G * G      # temporal + spatial tokens (356 at 224 px)
+        NV = vis.shape[1] if vis is not None else n_frames + G * G      # temporal + spatial tokens (356 at 224 px)
         n_hands = 0 if future_hands is None else future_hands.shape[2]
         # packed (unpadded) rows: training passes only, opt-in (config.pack_sequences); logits / hidden states are then
         # returned packed too ([M, ...] with out.cu_seqlens), everything else is unchanged
@@ -489,7 +503,7 @@ class HandsOnVLMForCausalLM:
         if training_pass and self.on_token_ids is not None and plan.seg is not None:
             self.on_token_ids(plan.seg[2])
         if vis is None:
-            vis = self.visual_tokens(image.to(dev), keep_for_backward=training_pass)
+            vis = self.visual_tokens(image.to(dev) if image is not None else None, keep_for_backward=training_pass, image_frames=image_frames)
         assert vis.shape[1] == NV, (vis.shape, NV)
         S = plan.S
         assert S <= cfg.max_position_embeddings, f"spliced length {S} exceeds max_position_embeddings"
@@ -547,7 +561,7 @@ class HandsOnVLMForCausalLM:
             comps = {"text loss": loss_text, "traj_loss": tl["traj_loss"].detach(), "traj_kl_loss": tl["traj_kl_loss"].detach()}
             if training_pass:
                 self._ctx = dict(plan=plan, logits_p=logits_p, row_lse=row_lse, n_valid=acc[1:2], hidden=hidden, emb=emb, hidden_v=hidden_v, pruned=pruned,
-                                 head_loss=head_loss, B=B, S=S, NV=NV, T=image.shape[1], M=plan.M)
+                                 head_loss=head_loss, B=B, S=S, NV=NV, T=n_frames, M=plan.M)
                 loss = _EngineLoss.apply(self._anchor, self, value)
             else:
                 loss = value

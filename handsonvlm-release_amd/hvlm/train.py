@@ -23,6 +23,7 @@ from . import checkpoint, dp
 from .config import CLIPVisionConfig, HandsOnVLMConfig
 from .data import DataCollatorForSupervisedDataset, SyntheticEpicDataset
 from .optim import AdamW, cosine_lr
+from .prefetch import DevicePrefetcher
 
 
 class _SkipBatches:
@@ -107,7 +108,10 @@ def train(model, dataset, output_dir=None, per_device_batch=16, epochs=1, max_st
                                              collate_fn=collate, num_workers=num_workers,
                                              generator=torch.Generator().manual_seed(seed + 7919 * epoch))   # its base seed
                                              # must not be drawn from the global RNG (the CVAE noise's stream)
-        for batch in loader:
+        # the host -> device edge: batch i + 1 is staged in pinned memory and uploaded on a copy stream while step i computes;
+        # tiled EK100 clips cross the bus as their 10 distinct frames + an index (hvlm/prefetch.py).  CPU runs pass through.
+        feed = DevicePrefetcher(loader, model.device, dedup_period=10 if model.config.dedup_frames else None)
+        for batch in feed:
             if step >= total or (stop_after is not None and step >= stop_after):
                 break
             out = model(**batch)

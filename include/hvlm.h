@@ -54,9 +54,9 @@ int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
 /* Development builds only: the hand-scheduled dh = 128 causal forward (hvlm_attn_fwd's default path, csrc/asm/attn_fwd_d128.py) in
  * its cycle-stamped form (variant 1) or as a timing-only ablation (variant >= 2: WRONG results — no softmax stream, no DMA, no
  * fragment reloads, no MFMAs, ...; tools/attn_asm_prof.py lists them).  prof: NULL or a device buffer of
- * B * H * ceil(S / 256) * 4 waves x 8 uint32 = {prologue loads, prologue compute + step 0, loop, epilogue} in shader cycles,
- * n0, n1, nT, j of the wave.  Padded batch only. */
-int hvlm_attn_fwd_asm_dev(const void* qkv, void* out, float* lse, void* prof, int B, int S, int H, int ld, float scale,
+ * min(CUs, B * H * ceil(S / 256)) workgroups x 4 waves x 8 uint32: cycle sums of the item phases {start wait, prologue + step 0,
+ * loop, epilogue, item switch}.  ws as for hvlm_attn_fwd.  Padded batch only. */
+int hvlm_attn_fwd_asm_dev(const void* qkv, void* out, float* lse, void* ws, void* prof, int B, int S, int H, int ld, float scale,
                           int variant, void* stream);
 #endif
 
@@ -241,7 +241,8 @@ int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int3
  *   dh in {64, 128}.
  *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): the backward keeps
  *       delta = rowsum(dO*O) there, followed by the eight per-XCD entry counters of the persistent dK/dV kernel (zeroed by
- *       the call itself with a stream-ordered memset: no initialisation is asked of the caller); the forward needs none (the
+ *       the call itself with a stream-ordered memset: no initialisation is asked of the caller); the forward keeps the eight
+ *       work-queue counters of its persistent dh = 128 causal kernel there (64-byte aligned, zeroed by the call itself) (the
  *       transposed operands V^T, K^T, Q^T, dO^T are gathered inside the kernels with LDS transpose reads — the parameter
  *       stays for ABI stability).
  * bwd: dqkv (same layout as qkv, fully written for rows < S) from dout [B*S, H*dh].

@@ -1,0 +1,116 @@
+"""Round-5 GPU tests: the input edge (prefetched upload == synchronous upload, bit for bit) and the hand-scheduled attention
+forward against the C++ kernel it replaces and the fp32 oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import synth  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def tiny(training=False):
+    from test_gpu_model import tiny_model
+    return tiny_model(training=training)
+
+
+def _batch(B, T, seed, tiled):
+    from hvlm.data import tile_epic_frames
+    ids, labels, mask = synth.make_text_batch(B, T, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    if tiled:
+        f = torch.randn(B, 10, 3, 224, 224, generator=g).to(BF)
+        img = torch.stack([tile_epic_frames(f[b]) for b in range(B)])
+    else:
+        img = torch.randn(B, 100, 3, 224, 224, generator=g).to(BF)
+    return dict(input_ids=ids, labels=labels, attention_mask=mask, image=img, future_hands=torch.rand(B, 2, 5, 2, generator=g),
+                contact_point=torch.zeros(B, 2), future_valid=torch.ones(B, 2), gt_label_valid=torch.ones(B))
+
+
+@pytest.mark.parametrize("tiled,dedup", [(True, True), (True, False), (False, True)])
+def test_prefetch_bit_identical(tiled, dedup):
+    """hvlm.prefetch.DevicePrefetcher (pinned staging, copy stream, distinct frames + index when the collator's tiling is found)
+    feeds the model the same bits as `model(**cpu_batch)`: loss and gradients of three consecutive steps are identical."""
+    from hvlm.prefetch import DevicePrefetcher
+    m, cfg = tiny(training=True)
+    m.config.dedup_frames = dedup
+    batches = [_batch(2, 40 + 3 * i, seed=10 + i, tiled=tiled) for i in range(3)]
+
+    def run(feed):
+        out = []
+        for bt in feed:
+            torch.manual_seed(7); torch.cuda.manual_seed_all(7)               # the CVAE noise
+            o = m(**bt)
+            m.backward()
+            torch.cuda.synchronize()
+            out.append((float(o.loss.detach()), m.proj_w_g.clone(), m.stack.layers[0].flat_g.clone(), m.embed_g.clone()))
+        return out
+
+    ref = run([dict(b) for b in batches])
+    feed = DevicePrefetcher([dict(b) for b in batches], m.device, dedup_period=10 if dedup else None)
+    got = run(feed)
+    waits = feed.collect_wait_ms()
+    assert len(got) == 3 and len(waits) == 3
+    for (l0, a0, b0, c0), (l1, a1, b1, c1) in zip(ref, got):
+        assert l0 == l1
+        assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(c0, c1)
+    if tiled and dedup:
+        assert feed.bytes_last == 2 * 10 * 3 * 224 * 224 * 2                  # the distinct frames only crossed the bus
+    else:
+        assert feed.bytes_last == 2 * 100 * 3 * 224 * 224 * 2
+
+
+def _ref_attn(qkv, B, S, H, dh):
+    x = qkv.float().view(B, S, 3, H, dh)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    s = s.masked_fill(~torch.ones(S, S, device=qkv.device, dtype=torch.bool).tril(), float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H * dh), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 32, 1), (1, 33, 2), (2, 96, 1), (1, 257, 3), (2, 300, 2), (1, 867, 4), (3, 1024, 2), (1, 2048, 5)])
+def test_attn_fwd_asm_vs_oracle_and_cpp(B, S, H):
+    """The hand-scheduled persistent forward (csrc/asm/attn_fwd_d128.py) == softmax(QK^T/sqrt(dh) + causal) V within the C++
+    kernel's own error (both round P to bf16), every block class: single 32-row block, ragged last block, 1..8 blocks per item."""
+    from hvlm import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+    try:
+        _lib.configure("attn_fwd_asm", 0); o0, l0 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+        _lib.configure("attn_fwd_asm", 1); o1, l1 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+    finally:
+        _lib.configure("attn_fwd_asm", 0)
+    orf, lrf = _ref_attn(qkv, B, S, H, 128)
+    e0, e1 = (o0.float() - orf).abs().max().item(), (o1.float() - orf).abs().max().item()
+    assert torch.isfinite(o1.float()).all()
+    assert e1 <= max(1.5 * e0, 4e-3), (e1, e0)                               # tolerance: 4e-3 abs (bf16 outputs of O(1) values), the C++ kernel's bar
+    assert (l1 - lrf).abs().max().item() <= 2e-3
+
+
+def test_attn_fwd_asm_deferred_rescale_and_varlen():
+    """Late, large maxima force the deferred O rescale (slow path); packed rows (cu_seqlens) == padded rows bit for bit."""
+    from hvlm import _lib, ops
+    B, S, H = 2, 867, 4
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = (torch.randn(B * S, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+    x = qkv.view(B, S, 3, H, 128)
+    for t in range(40, S, 97):
+        x[:, t, 1] *= 6.0
+    try:
+        _lib.configure("attn_fwd_asm", 1)
+        o1, l1 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+        orf, lrf = _ref_attn(qkv, B, S, H, 128)
+        assert (o1.float() - orf).abs().max().item() <= 1.2e-2 and (l1 - lrf).abs().max().item() <= 2e-3
+        lens = [100, 867, 33, 512]
+        Sm = max(lens)
+        full = (torch.randn(len(lens) * Sm, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+        rows = torch.cat([torch.arange(b * Sm, b * Sm + n, device="cuda") for b, n in enumerate(lens)])
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+        op, lp = ops.attn_fwd(full[rows].contiguous(), len(lens), Sm, H, 128, True, 128 ** -0.5, cu_seqlens=cu)
+        of, lf = ops.attn_fwd(full, len(lens), Sm, H, 128, True, 128 ** -0.5)
+        assert torch.equal(op, of[rows])
+        assert all(torch.equal(lp[b, :, :n], lf[b, :, :n]) for b, n in enumerate(lens))
+    finally:
+        _lib.configure("attn_fwd_asm", 0)

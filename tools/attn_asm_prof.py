@@ -11,7 +11,8 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "noqk", "nopv", "nodmak", "nodmav"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly"]
+PHASES = ["item start wait", "prologue + step 0", "main loop", "flush + epilogue", "item switch"]
 
 def timeit(fn, n=20):
     for _ in range(3): fn()
@@ -27,15 +28,16 @@ for (B, S, H) in shapes:
     qkv = (torch.randn(B * S, 3 * H * 128, device="cuda") * 0.5).to(torch.bfloat16)
     out = torch.empty(B * S, H * 128, device="cuda", dtype=torch.bfloat16)
     lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
-    nwg = B * H * ((S + 255) // 256)
-    prof = torch.zeros(nwg * 4 * (8 + 256), device="cuda", dtype=torch.int32)
+    ws = torch.zeros(1024, device="cuda", dtype=torch.uint8)
+    nwg = min(256, B * H * ((S + 255) // 256))
+    prof = torch.zeros(nwg * 4 * 8, device="cuda", dtype=torch.int32)
     st = torch.cuda.current_stream().cuda_stream
     def run(v, p=None):
-        rc = lib.hvlm_attn_fwd_asm_dev(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), p.data_ptr() if p is not None else None, B, S, H,
-                                       qkv.stride(0), 128 ** -0.5, v, st)
+        rc = lib.hvlm_attn_fwd_asm_dev(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), ws.data_ptr(), p.data_ptr() if p is not None else None,
+                                       B, S, H, qkv.stride(0), 128 ** -0.5, v, st)
         assert rc == 0, _lib.last_error()
     fl = 4.0 * S * S * 128 * H * B * 0.5
-    print(f"== B={B} S={S} H={H}  ({nwg} workgroups)")
+    print(f"== B={B} S={S} H={H}  ({nwg} persistent workgroups)")
     assert lib.hvlm_configure(b"attn_fwd_asm", 0) == 0
     t = timeit(lambda: ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5))
     print(f"   c++ kernel            {t:8.1f} us  {fl / t / 1e6:7.0f} TF/s")
@@ -43,28 +45,9 @@ for (B, S, H) in shapes:
         t = timeit(lambda: run(v))
         print(f"   asm {name:12s}      {t:8.1f} us  {fl / t / 1e6:7.0f} TF/s (algorithmic)")
     prof.zero_(); run(1, prof); torch.cuda.synchronize()
-    raw = prof.cpu().numpy().astype("int64") & 0xffffffff
-    p = raw[: nwg * 4 * 8].reshape(nwg * 4, 8)
-    its = raw[nwg * 4 * 8:].reshape(nwg * 4, 4, 64)          # [wave, stamp kind, iteration]: top, after barrier, after first, after second
-    names = ["prologue loads", "prologue compute + step 0", "main loop", "epilogue"]
-    for j in sorted(set(p[:, 7].tolist())):
-        rows = p[(p[:, 7] == j) & (p[:, 6] > 0)]
-        if len(rows) == 0: continue
-        nT = rows[:, 6].mean(); steps = 2 * nT - 1
-        desc = "  ".join(f"{names[i]} {rows[:, i].mean():8.0f}" for i in range(4))
-        act = rows[rows[:, 5] > 0]
-        print(f"   j={j} nT={nT:4.1f} waves={len(rows)}: {desc}   loop cycles per step {rows[:, 2].mean() / max(1, steps):7.0f}  total {rows[:, :4].sum(1).mean():8.0f}")
-        # iteration anatomy per wave index (rows are ordered (workgroup, wave); the modes differ near the diagonal)
-        sel = (p[:, 7] == j) & (p[:, 6] > 0)
-        I4 = its[sel]; n_it = int(nT)
-        if n_it >= 2:
-            d = lambda a, b: ((b - a) & 0xffffffff).astype("float64")
-            fmt = lambda v: " ".join(f"{x:5.0f}" for x in v)
-            W = np.arange(len(p))[sel] % 4
-            for w in range(4):
-                m = W == w
-                if m.any():
-                    print(f"      wave {w}: wait   {fmt(d(I4[m][:, 0, :n_it], I4[m][:, 1, :n_it]).mean(0))}")
-                    print(f"              first  {fmt(d(I4[m][:, 1, :n_it], I4[m][:, 2, :n_it]).mean(0))}")
-                    print(f"              second {fmt(d(I4[m][:, 2, :n_it], I4[m][:, 3, :n_it]).mean(0))}")
-                    print(f"              ctl    {fmt(d(I4[m][:, 3, : n_it - 1], I4[m][:, 0, 1:n_it]).mean(0))}")
+    p = (prof.cpu().numpy().astype("int64") & 0xffffffff).reshape(nwg * 4, 8)
+    tot = p[:, :5].sum(1)
+    print("   cycle sums per wave (mean over the workgroups), whole kernel:")
+    for k, nm in enumerate(PHASES):
+        print(f"      {nm:20s} {p[:, k].mean():10.0f}  ({100.0 * p[:, k].mean() / tot.mean():5.1f} %)")
+    print(f"      total                {tot.mean():10.0f}   min {tot.min()}  max {tot.max()}")
