@@ -35,6 +35,8 @@ namespace hvlm {
 // attention_asm.hip
 int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, void* ws, int B, int S_max, int H, int ld, float scale_log2,
                              const int32_t* cu, hipStream_t st, int variant = 0, void* prof = nullptr);
+int attn_fwd_clip_s257_asm(const bf16_t* qkv, bf16_t* out, int B, int H, int ld, float scale_log2, hipStream_t st, int variant = 0,
+                           void* prof = nullptr);
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1795,6 +1797,10 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
       }
       const int nitems = B * H;
+      if constexpr (F16) {
+        // CLIP ViT-L/14 at 224 px, the tower's own dtype: the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_clip_d64.py)
+        if (S == 257 && !lse && config().attn_clip_asm) return attn_fwd_clip_s257_asm(qkv, out, B, H, ld, scale * LOG2E, st);
+      }
       if (S == 257) {                          // CLIP ViT-L/14 at 224 px: the unrolled, LDS-latency-pipelined schedule
         rc = set_lds(attn_fwd_resident_kernel<DH, F16, 257>, lds, "attn_fwd_resident");
         if (rc) return rc;
@@ -1809,7 +1815,8 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   }
   if constexpr (DH == 128 && CAUSAL && !F16) {
     // the decoder's forward: hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_fwd_d128.py, attention_asm.hip)
-    if (config().attn_fwd_asm) return attn_fwd_d128_causal_asm(qkv, out, lse, ws, B, S, H, ld, scale * LOG2E, cu, st);
+    // (its work-queue counters live in `ws`: a caller that sized / aligned the workspace for an older library gets the C++ kernel)
+    if (config().attn_fwd_asm && ws && !((uintptr_t)ws & 63)) return attn_fwd_d128_causal_asm(qkv, out, lse, ws, B, S, H, ld, scale * LOG2E, cu, st);
   }
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us

@@ -142,7 +142,8 @@ struct Config {
   int decode_unfused = 0;     // 1: RoPE and the split combine of the native decode step as separate launches
   int attn_delta_separate = 0;  // 1: delta = rowsum(O * dO) of the attention backward by its own pass instead of inside the dQ kernel
   int skinny_per = 0;         // weight-streaming GEMM: forced K-slice length (x 256 k), 0 = balance model
-  int attn_fwd_asm = 0;       // 0: the dh = 128 causal forward on the C++ kernel instead of the hand-scheduled one (attention_asm.hip)
+  int attn_clip_asm = 1;      // 1: the CLIP tower's attention (fp16, S = 257, dh = 64) on the hand-scheduled kernel (csrc/asm/attn_clip_d64.py)
+  int attn_fwd_asm = 1;       // 0: the dh = 128 causal forward on the C++ kernel instead of the hand-scheduled one (attention_asm.hip)
   // --- variants that exist in DEV builds only ---
   int gemm_tail_half = 0;     // 1: the last, partial round of tiles of an XCD's chunk runs as half-tile units (gemm_pp.hip)
   int gemm_epi_swap = 0;      // 1: register-exchange GEMM epilogue (v_permlane swaps) instead of the wave-private LDS buffers

@@ -36,7 +36,7 @@ const Key kKeys[] = {
     {"attn_no_resident", &Config::attn_no_resident, false, 0}, {"attn_fwd_pipe", &Config::attn_fwd_pipe, true, 0},
     {"decode_unfused", &Config::decode_unfused, false, 0}, {"skinny_per", &Config::skinny_per, false, 0},
     {"attn_delta_separate", &Config::attn_delta_separate, false, 0},
-    {"attn_fwd_asm", &Config::attn_fwd_asm, false, 0},
+    {"attn_fwd_asm", &Config::attn_fwd_asm, false, 1},     {"attn_clip_asm", &Config::attn_clip_asm, false, 1},
     {"gemm_dbg", &Config::gemm_dbg, true, 0},              {"gemm_seg4", &Config::gemm_seg4, true, 1},
     {"gemm_m16", &Config::gemm_m16, true, 1},              {"gemm_tn_seg4", &Config::gemm_tn_seg4, true, 1},
     {"gemm_fp8_m16", &Config::gemm_fp8_m16, true, 0},      {"attn_dkv_fused", &Config::attn_dkv_fused, true, 1},

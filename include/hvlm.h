@@ -58,6 +58,8 @@ int hvlm_debug_occupy(int workgroups, long cycles, void* stream);
  * loop, epilogue, item switch}.  ws as for hvlm_attn_fwd.  Padded batch only. */
 int hvlm_attn_fwd_asm_dev(const void* qkv, void* out, float* lse, void* ws, void* prof, int B, int S, int H, int ld, float scale,
                           int variant, void* stream);
+/* The same for the CLIP tower's attention (csrc/asm/attn_clip_d64.py: fp16, S = 257, dh = 64, non-causal; qkv [B * 257, ld]). */
+int hvlm_attn_clip_asm_dev(const void* qkv, void* out, void* prof, int B, int H, int ld, float scale, int variant, void* stream);
 #endif
 
 /* Per-device handle — the ONLY mutable state the library keeps between calls: which block of device memory
