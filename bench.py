@@ -242,6 +242,25 @@ def pmc_traffic(ev, args):
     return None, (f"GEMM shape {missing[1]} of this run is not in profiles/{missing[0]}" if missing else "no PMC table under profiles/")
 
 
+def pmc_mfma_busy(kernel_substr="gemm_pp4m_kernel", label_prefix="gemm bf16"):
+    """roofline.mfma_busy_frac: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the dominant kernel from the newest
+    committed counter table (tools/mfma_pmc.sh -> profiles/r*_mfma_pmc.json: the decoder's GEMM shapes, isolated launches; a --pmc pass
+    cannot wrap the ~3000-dispatch step on this pool), duration-weighted over the shapes.  (None, reason) without a table."""
+    import glob
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for path in sorted(glob.glob(os.path.join(pdir, "r*_mfma_pmc.json")), reverse=True):
+        rows = [r for r in json.load(open(path)).get("per_group", []) if kernel_substr in r["kernel"] and r.get("group", "").startswith(label_prefix)
+                and r.get("mfma_busy_frac")]
+        if not rows:
+            continue
+        w = [r.get("avg_us_unprofiled_pass") or 1.0 for r in rows]
+        v = sum(r["mfma_busy_frac"] * wi for r, wi in zip(rows, w)) / sum(w)
+        return v, (f"SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD cycles, {len(rows)} decoder GEMM shapes in isolation, duration-weighted "
+                   f"(profiles/{os.path.basename(path)}); cycle-based: under the power cap the clock is ~1.8 GHz, so this is higher than "
+                   "achieved / peak, which is priced at 2.4 GHz")
+    return None, "no profiles/r*_mfma_pmc.json"
+
+
 def fp8_pmc_traffic(shapes):
     """roofline.traffic of the e4m3 decoder-prefill GEMMs (BASELINE config 5): the per-shape PMC table written by
     `tools/gemm_traffic_all.py drive-fp8` (profiles/r*_gemm_traffic_fp8.json; FETCH_SIZE x2 + WRITE_SIZE, separate passes),
@@ -1024,10 +1043,12 @@ def main():
         if args.layers is not None:
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)
+        busy, busy_note = pmc_mfma_busy()
         if gs is not None:
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4m_kernel (v_mfma_f32_16x16x32; the CLIP tower runs its fp16 twin gemm_pp4m_f16_kernel)", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
+                               "mfma_busy_frac": busy, "mfma_busy_note": busy_note,
                                "launches": gs["launches"], "gemm_calls": gs["calls"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}

@@ -57,11 +57,18 @@ KERNARG_BYTES = 80
 
 
 class Gen:
-    def __init__(self, debug_serial=False, abl=(), prof=False):
+    def __init__(self, debug_serial=False, abl=(), prof=False, k_rows=False):
         """abl: timing-only ablations (WRONG RESULTS): 'nosm' no softmax stream, 'nodma' no LDS-DMA in the loop, 'nolds' no
         fragment reloads, 'nomfma' no MFMAs.  prof: s_memtime cycle sums per workgroup phase through the extra kernel argument."""
         self.debug_serial = debug_serial
         self.abl, self.prof = set(abl), prof
+        # k_rows: K tiles keep the row-major XOR-swizzled image of V (DMA lanes fetch whole 256-byte rows) instead of the
+        # [half][ks][hi][key] image whose fragment address is base + immediate but whose DMA fetches 32-byte granules of 32 rows per
+        # instruction (the CLIP kernel, which is HBM-bound, measured -14 % with whole rows: profiles/r05f).  Measured HERE
+        # (profiles/r05h_attn_fwd_k_image_ab.txt, same box, same launch): row image 178.2 / 212.7 us, granule image 172.3 / 210.0 us at
+        # S = 867 / 2048 — the decoder kernel is not HBM-bound (K / V of a (b, h) pair are re-read from L2 by its 4-7 workgroups) and the
+        # row image costs 8 address registers + a running soffset: the granule image stays the default, `krows` is the dev variant.
+        self.k_rows = k_rows
         self.report = []
         self.site = 0
         self.ool = []                     # out-of-line blocks (slow paths), appended behind the main code
@@ -140,6 +147,7 @@ class Gen:
         self.vLIM = V.alloc("l31 - 4 hi (triangular limit)", 1)
         self.vLIMC = V.alloc("limit in use", 1)
         self.vKADDR = V.alloc("K fragment LDS address (lane*16 + slot)", 1)
+        self.vKADDRS = [V.alloc(f"K fragment LDS address, row image, ks{ks}", 1) for ks in range(8)] if k_rows else []
         self.vVADDR = [[V.alloc(f"V tr-read address db{db} hf{hf}", 1) for hf in range(2)] for db in range(4)]
         self.vKOFF = V.alloc("K DMA voffset", 1)
         self.vVOFF = V.alloc("V DMA voffset", 1)
@@ -158,6 +166,11 @@ class Gen:
     def dma_stage_ins(self):
         g = []
         for i in range(4):
+            if self.k_rows:          # piece 4 i + w: rows 16 i + 4 w + (lane >> 4), like the V pieces (s_m0k = slot + w * 1024, s_ktile without the wave part)
+                g.append([I("s_add_u32", M0, self.s_m0k, 0x1000 * i) if i else I("s_mov_b32", M0, self.s_m0k),
+                          I("s_add_u32", self.s_t[3], self.s_t[3], self.s_r16) if i else I("s_mov_b32", self.s_t[3], self.s_ktile),
+                          I("buffer_load_dwordx4", self.vVOFF, self.s_rd, self.s_t[3], ndef=0, mods="offen lds", xuse=[M0])])
+                continue
             g.append([I("s_add_u32", M0, self.s_m0k, 0x400 * i) if i else I("s_mov_b32", M0, self.s_m0k),
                       I("s_add_u32", self.s_so, self.s_ktile, 32 * i) if i else I("s_mov_b32", self.s_so, self.s_ktile),
                       I("buffer_load_dwordx4", self.vKOFF, self.s_rd, self.s_so, ndef=0, mods="offen lds", xuse=[M0])])
@@ -169,6 +182,12 @@ class Gen:
 
     def dma_k0_ins(self, kcol, rsrc):
         """The item's first K tile -> K0AREA (4 pieces of this wave)."""
+        if self.k_rows:
+            out = [I("s_lshl_b32", self.s_t[6], self.s_w, 10), I("s_add_u32", self.s_t[6], self.s_t[6], K0AREA), I("s_mov_b32", self.s_so, kcol)]
+            for i in range(4):
+                out += [I("s_add_u32", M0, self.s_t[6], 0x1000 * i)] + ([I("s_add_u32", self.s_so, self.s_so, self.s_r16)] if i else [s_nop(0)]) + \
+                       [I("buffer_load_dwordx4", self.vVOFF, rsrc, self.s_so, ndef=0, mods="offen lds", xuse=[M0])]
+            return out
         out = [I("s_lshl_b32", self.s_t[6], self.s_w, 12), I("s_add_u32", self.s_t[6], self.s_t[6], K0AREA)]
         for i in range(4):
             out += [I("s_add_u32", M0, self.s_t[6], 0x400 * i), I("s_add_u32", self.s_so, kcol, 32 * i),
@@ -189,7 +208,7 @@ class Gen:
         """m0 bases of the DMA stream from a ring slot index held in `slot`."""
         t = self.s_t
         return [I("s_mov_b32", self.s_dslot, slot), I("s_lshl_b32", t[6], slot, 15),
-                I("s_lshl_b32", t[7], self.s_w, 12), I("s_add_u32", self.s_m0k, t[6], t[7]),
+                I("s_lshl_b32", t[7], self.s_w, 10 if self.k_rows else 12), I("s_add_u32", self.s_m0k, t[6], t[7]),
                 I("s_lshl_b32", t[7], self.s_w, 10), I("s_add_u32", t[7], t[7], V_IN_SLOT), I("s_add_u32", self.s_m0v, t[6], t[7])]
 
     def consumer_advance(self):
@@ -198,13 +217,16 @@ class Gen:
                I("s_cmp_lt_u32", self.s_cs, 3, ndef=0), I("s_cbranch_scc1", f"L_cadv_{st}", ndef=0),
                I("s_mov_b32", self.s_cs, 0), I("s_mov_b32", self.s_delta, (-2 * SLOT) & 0xffffffff),
                Label(f"L_cadv_{st}"),
-               I("v_add_u32", self.vKADDR, self.s_delta, self.vKADDR)]
+               I("v_add_u32", self.vKADDR, self.s_delta, self.vKADDR)] + [I("v_add_u32", r_, self.s_delta, r_) for r_ in self.vKADDRS]
         for db in range(4):
             for hf in range(2): out.append(I("v_add_u32", self.vVADDR[db][hf], self.s_delta, self.vVADDR[db][hf]))
         return out
 
     # ---- fragment reads -------------------------------------------------------------------------------------------
     def k_read(self, ks, half, addr=None):
+        if self.k_rows:                  # row (32 half + l31) * 256 + (((2 ks + hi) ^ swz(l31)) << 4); addr: scalar added by the caller's register set
+            base = self.vKADDRS[ks] if addr is None else addr[ks]
+            return I("ds_read_b128", self.aK.sub(4 * ks, 4), base, mods=f"offset:{half * 8192}")
         return I("ds_read_b128", self.aK.sub(4 * ks, 4), addr or self.vKADDR, mods=f"offset:{half * 8192 + ks * 1024}")
 
     def v_reads(self, sp, db, half):
@@ -444,7 +466,10 @@ class Gen:
         add(I("s_add_u32", t[7], self.s_H, h)); add(I("s_lshl_b32", t[7], t[7], 8))
         add(I("s_lshr_b32", t[0], self.s_w, 1)); add(I("s_lshl_b32", t[1], self.s_ld2, 5)); add(I("s_mul_i32", t[0], t[0], t[1]))
         add(I("s_and_b32", t[1], self.s_w, 1)); add(I("s_lshl_b32", t[1], t[1], 7))
-        add(I("s_add_u32", kcol, t[7], t[0])); add(I("s_add_u32", kcol, kcol, t[1]))
+        if self.k_rows:
+            add(I("s_mov_b32", kcol, t[7]))                                                   # (the wave's rows are in vVOFF)
+        else:
+            add(I("s_add_u32", kcol, t[7], t[0])); add(I("s_add_u32", kcol, kcol, t[1]))
         add(I("s_lshl_b32", t[7], self.s_H, 1)); add(I("s_add_u32", t[7], t[7], h)); add(I("s_lshl_b32", vcol, t[7], 8))
         if nxt: add(I("s_lshl_b32", self.s_hqn, h, 8))
         # this wave's blocks: bA = 8 j + w, bB = bA + 4
@@ -517,6 +542,11 @@ class Gen:
         add(I("v_mov_b32", self.vNINF, NEG_INF))
         add(I("v_lshlrev_b32", X[0], 2, self.vHI)); add(I("v_sub_u32", self.vLIM, self.vL31, X[0]))
         add(I("v_lshlrev_b32", self.vKADDR, 4, self.vLANE))
+        if self.k_rows:          # tile_addr<128>(l31, 2 ks + hi) = l31 * 256 + (((2 ks + hi) ^ swz(l31)) << 4), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3)
+            add(I("v_and_b32", X[0], 3, self.vL31)); add(I("v_bfe_u32", X[1], self.vL31, 2, 2)); add(I("v_lshl_or_b32", X[0], X[0], 2, X[1]))
+            for ks in range(8):
+                add(I("v_or_b32", X[1], 2 * ks, self.vHI)); add(I("v_xor_b32", X[1], X[1], X[0])); add(I("v_lshlrev_b32", X[1], 4, X[1]))
+                add(I("v_lshl_add_u32", self.vKADDRS[ks], self.vL31, 8, X[1]))
         # V tr-read addresses (attention.hip v_off): p16 = l & 15, g16 = (l & 31) >> 4
         p16, g16, r, c, sw = X[1], X[2], X[3], X[4], X[5]
         add(I("v_and_b32", p16, 15, self.vLANE)); add(I("v_lshrrev_b32", g16, 4, self.vL31))
@@ -608,9 +638,16 @@ class Gen:
         add(I("s_cmp_eq_u32", self.s_n1, 0, ndef=0)); add(I("s_cbranch_scc1", "L_after_step0", ndef=0))
         # QK of steps 0 and 1 from the first K tile, softmax of step 0, fragments for step 0's body
         pro = []
-        add(I("v_lshlrev_b32", X[9], 4, self.vLANE)); add(I("v_add_u32", X[9], K0AREA, X[9]))
+        if self.k_rows:
+            # addresses relative to the K0 area: the row-image registers minus the ring position (s_cs * SLOT)
+            add(I("s_lshl_b32", t[0], self.s_cs, 15)); add(I("s_sub_u32", t[0], K0AREA, t[0]))
+            k0 = [self.vQN[ks] for ks in range(8)]                               # (vQN is free here: Q was moved to the AccVGPRs above)
+            for ks in range(8): add(I("v_add_u32", k0[ks], t[0], self.vKADDRS[ks]))
+        else:
+            add(I("v_lshlrev_b32", X[9], 4, self.vLANE)); add(I("v_add_u32", X[9], K0AREA, X[9]))
+            k0 = X[9]
         for half in range(2):
-            for ks in range(8): pro.append(self.k_read(ks, half, addr=X[9]))
+            for ks in range(8): pro.append(self.k_read(ks, half, addr=k0))
             for ks in range(8):
                 for qb in range(2): pro.append(self.qk(qb, half, ks))
         for ks in range(8): pro.append(self.k_read(ks, 0))                                      # K tile 1 half 0 -> QK of step 2
@@ -784,8 +821,8 @@ class Gen:
         return fix_hazards(out, f"epilogue{qb}", self.report)
 
 
-def generate(debug_serial=False, abl=(), prof=False, name=KNAME):
-    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof)
+def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=False):
+    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof, k_rows=k_rows)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     body = render(items)
@@ -801,7 +838,7 @@ def generate(debug_serial=False, abl=(), prof=False, name=KNAME):
 # development variants (make DEV=1): cycle sums and timing-only ablations (hvlm_attn_fwd_asm_dev)
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
-                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds")))]
+                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("krows", dict(prof=True, k_rows=True))]
 
 
 def unique_labels(text, suffix):

@@ -626,7 +626,19 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
   // PEEL (the 16x16 kernels, see the tile loop): every epilogue path holds ONE full vmcnt(0) before its first store — behind the loads
   // it needs itself (bias, LayerNorm-fold vectors, first residual fragment), so that their latency and the landing of the pieces
   // staged for the next tile's first K-tile (HVLM_PHASE_SYNC_K relies on it) are waited for together
-  auto staged_landed = [&]() { if constexpr (M16) __builtin_amdgcn_s_waitcnt(0x0F70); };
+  // (nothing in the language enforces the invariant.  Development builds carry a flag that staged_landed() raises and the
+  //  peeled first K-tile consumes: an epilogue path that forgets the wait traps on the first tile it hands over instead of reading LDS
+  //  pieces that may not have landed (HVLM_LIB=lib/libhvlm_hip_dev.so python -m pytest tests -m gpu -k 'gemm or clip or layernorm_fold'
+  //  runs every epilogue variant through it: profiles/r05j_dev_invariant.txt).)
+#ifdef HVLM_DEV
+  bool dev_landed = true;                    // (the prologue's HVLM_VMCNT(0) covers the first tile)
+#endif
+  auto staged_landed = [&]() {
+    if constexpr (M16) __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef HVLM_DEV
+    dev_landed = true;
+#endif
+  };
   auto epilogue = [&](int m0, int n0, size_t c_slab, int i_lo, int i_hi) {   // row fragments i_lo .. i_hi - 1 (a half-tile unit: 2 of 4)
     if (!fast_ok || n0 + BN > p.N) {
       staged_landed();
@@ -1169,6 +1181,10 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
     };   // ktile
     auto run_k = [&](auto hm_tag) {
       if constexpr (PEEL) {
+#ifdef HVLM_DEV
+        if (!dev_landed) __builtin_trap();   // an epilogue path returned without staged_landed(): see there
+        dev_landed = false;
+#endif
         ktile(hm_tag, T1{}, 0);
         ++g;
         for (int kt = 1; kt < nk; ++kt, ++g) ktile(hm_tag, T0{}, kt);

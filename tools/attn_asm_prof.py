@@ -11,7 +11,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "krows"]
 PHASES = ["item start wait", "prologue + step 0", "main loop", "flush + epilogue", "item switch"]
 
 def timeit(fn, n=20):
