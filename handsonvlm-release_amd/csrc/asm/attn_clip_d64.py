@@ -12,9 +12,14 @@ construction (profiles/r03d: the C++ kernel's two waves per SIMD do not overlap 
 arranged for ONE instruction stream per SIMD that never stalls on the matrix pipe:
   * workgroup = 4 waves, wave w owns query rows [32 w, 32 w + 32) and [128 + 32 w, 160 + 32 w): eight full blocks, balanced;
   * three-stage pipeline inside an item:  QK^T of step t+2 | softmax of step t+1 | P V of step t  (as attn_fwd_d128.py);
-  * the 257th query (the class token's row) is computed by wave 3 with SWAPPED MFMA operands (lanes = keys: one score register
-    per step, 9 exponentials per lane instead of 144), reusing the K / V fragments already in registers; its probabilities reach
-    the k-slot order of the V^T fragments through a 64-byte LDS strip;
+  * the 257th query (the class token's row) is SHARED by the four waves, in the same code for all of them (solo_split): its
+    scores come from SWAPPED MFMA operands (lanes = keys) — wave w computes key steps w, w + 4 (and a third round) in the prologue
+    and leaves them in an LDS strip; one workgroup barrier; every wave then runs the 257-key softmax of that row itself (9 scores
+    per lane, NO running maximum — all scores are known) and writes the normalised fp16 probabilities to a strip in key order;
+    the P V product is split into (key half sp, head-dim half db) = wave: ONE extra MFMA per key step per wave on a V fragment
+    the wave reads through its own address; the two key halves are added through LDS after the NEXT item's barrier and stored
+    there.  (First version, kept as the dev variant `solo3`: wave 3 alone, 8 extra MFMAs + a serial softmax per step — the other
+    three waves waited ~4100 cycles per item for it, profiles/r05f_clip_attn_asm.txt.)
   * deferred running maximum (raised only when exceeded by 2^8) with the O rescale out of line, as in the decoder kernel;
   * outputs leave as 16-byte stores after a v_permlane32_swap exchange of the accumulator halves.
 """
@@ -32,8 +37,11 @@ KBYTES = NKB * 4096             # K image: row major [288][64] fp16 like V (whol
                                 # decoder kernel fetches 32-byte granules of 32 rows per instruction — measured slower here, the kernel is HBM-bound)
 VBYTES = NKB * 32 * 128         # V image: row major [288][64] fp16, 16-B chunks XOR-swizzled by row (attention.hip swz_bits<64>)
 BUF = KBYTES + VBYTES           # 73728
-STRIP = 2 * BUF                 # 2 x 64 B: wave 3's probabilities of the class-token row
-LDS_BYTES = STRIP + 256
+STRIP = 2 * BUF                 # 2 x 64 B: wave 3's probabilities of the class-token row (solo3 variant)
+SSTRIP = STRIP + 256            # class-token row, shared form: raw scores [12 key steps][32] f32 (steps 9..11: the idle third rounds)
+PSTRIP = SSTRIP + 1536          # its normalised probabilities [288] fp16, key order
+OSTRIP = PSTRIP + 576 + 64      # its partial outputs [item parity][wave][hi][16] f32
+LDS_BYTES = OSTRIP + 1024
 
 ARGS = [(8, 0, "global_buffer"), (8, 8, "global_buffer"), (4, 16, "by_value"), (4, 20, "by_value"), (4, 24, "by_value"), (4, 28, "by_value"),
         (4, 32, "by_value"), (4, 36, "by_value"), (4, 40, "by_value"), (4, 44, "by_value")]
@@ -46,8 +54,8 @@ def mfma_f16(d, a, b, c):
 
 
 class Gen:
-    def __init__(self, abl=(), prof=False, dma_steps=5):
-        self.abl, self.prof, self.dma_steps = set(abl), prof, dma_steps
+    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=True):
+        self.abl, self.prof, self.dma_steps, self.split = set(abl), prof, dma_steps, solo_split
         self.report, self.site, self.ool = [], 0, []
         S = self.S = RegFile("s", 0, 102)
         V = self.V = RegFile("v", 0, 256)
@@ -70,6 +78,9 @@ class Gen:
         self.s_so = S.alloc("soffset tmp", 1)
         self.s_vtail = S.alloc("V soffset of row 256", 1); self.s_ktail = S.alloc("K soffset of row 256", 1)
         self.s_exec = S.alloc("saved exec", 2, 2)
+        if solo_split:
+            self.s_oprev = S.alloc("previous item: byte offset in out", 1); self.s_havep = S.alloc("a previous item's class row is pending", 1)
+            self.s_opar = S.alloc("LDS parity offset of this item's partial class-row outputs (0 / 512)", 1)
         if prof:
             self.s_prof = S.alloc("prof", 2, 2); self.s_tm = self.s_karg; self.s_t0 = S.alloc("previous stamp", 1)
         # AccVGPRs
@@ -77,15 +88,25 @@ class Gen:
         self.aQ = [A.alloc(f"Q qb{q}", 16) for q in range(2)]
         self.aK = A.alloc("K fragments (4 ks x 4)", 16)
         self.aV = A.alloc("V fragments (2 sp x 2 db x 4)", 16)
-        self.aOS = A.alloc("O of the class-token row (wave 3)", 32)
+        self.aOS = A.alloc("O of the class-token row", 16 if solo_split else 32)
         self.aQS = A.alloc("Q of the class-token row", 16)
+        if solo_split:
+            self.aKS = A.alloc("K fragments of the class row's score rounds", 16)
+            self.aVS = [A.alloc(f"V fragment (sp_w, db_w) of the class row's P V, parity {i}", 4) for i in range(2)]
         self.vQN = A.alloc("next item's Q (2 qb x 16) + solo (16): prefetched into AccVGPRs", 48, 4)
         # arch VGPRs
         self.v_tid = V.alloc("tid", 1)
         self.vS = [[V.alloc(f"S qb{q} p{p}", 16, 4) for p in range(2)] for q in range(2)]
         self.vP = [[V.alloc(f"P qb{q} p{p}", 8, 4) for p in range(2)] for q in range(2)]
-        self.vSS = [V.alloc(f"S solo p{p}", 16, 4) for p in range(2)]
-        self.vPS = [V.alloc(f"P solo p{p} (2 sp x 4)", 8, 4) for p in range(2)]
+        self.vSS = [V.alloc(f"S solo p{p}", 16, 4) for p in range(1 if solo_split else 2)]
+        self.vPS = [V.alloc(f"P solo p{p}", 4 if solo_split else 8, 4) for p in range(2)]
+        if solo_split:
+            self.vKSADDR = [V.alloc(f"class row: K fragment address of key step w, ks{ks}", 1) for ks in range(4)]
+            self.vVSADDR = [V.alloc(f"class row: V tr-read address (sp_w, db_w) hf{hf}", 1) for hf in range(2)]
+            self.vSWR = V.alloc("class row: score write address", 1); self.vSRD = V.alloc("class row: score read address", 1)
+            self.vPWR = V.alloc("class row: P write address", 1); self.vPRD = V.alloc("class row: P fragment read address", 1)
+            self.vOWR = V.alloc("class row: partial O write / read address", 1); self.vOSOFF = V.alloc("class row: out byte offset of the lane", 1)
+            self.vSC = V.alloc("class row: score copies of the three rounds", 3)
         self.vM = [V.alloc(f"m {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vNEGM = [V.alloc(f"-m {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vMT = [V.alloc(f"m+THR {n}", 1) for n in ("qb0", "qb1", "solo")]
@@ -256,6 +277,95 @@ class Gen:
               I("ds_read_b64", d.sub(2, 2), self.vSTRIP[1], mods=f"offset:{so + 32 * sp + 16}"))
         return F
 
+    # ---- class-token row, shared by the four waves (solo_split) --------------------------------------------------------------
+    def solo_scores(self):
+        """Prologue: three rounds (key steps w, w + 4, w + 8: the third is real on wave 0 only, the others read past the K image —
+        finite garbage into strip slots nobody reads) of 4 K fragment reads + 4 swapped MFMAs; raw score of key l31 -> strip."""
+        out = []
+        d = self.vSS[0]
+        for i in range(3):
+            for ks in range(4):
+                out.append(I("ds_read_b128", self.aKS.sub(4 * ks, 4), self.vKSADDR[ks], mods=f"offset:{i * 16384}"))
+            for ks in range(4):
+                out.append(mfma_f16(d, self.aQS.sub(4 * ks, 4), self.aKS.sub(4 * ks, 4), 0 if ks == 0 else d))
+            out.append(I("v_mov_b32", self.vSC[i], d[0]))
+            out.append(I("ds_write_b32", self.vSWR, self.vSC[i], ndef=0, mods=f"offset:{i * 512}"))
+        return out
+
+    def solo_softmax(self):
+        """Step 0: softmax of the class row over all 257 keys, by every wave for itself (lane l31 of either half: keys 32 tau + l31).
+        Returns (early LDS reads, VALU stream).  Probabilities are NORMALISED before the fp16 rounding: P V needs no division."""
+        sc = [self.vSS[0][i] for i in range(9)]
+        t = self.vT[2]
+        scal = self.s_scale
+        early = [Filler([I("ds_read_b32", sc[tau], self.vSRD, mods=f"offset:{tau * 128}") for tau in range(3 * g, 3 * g + 3)], after=g, prio=0) for g in range(3)]
+        F = []
+        def f(*ins, **kw): F.append(Filler(list(ins), **kw))
+        f(I("v_cmp_eq_u32", VCC, 0, self.vL31), I("v_cndmask_b32", sc[8], self.vNINF, sc[8], VCC))     # key step 8: only key 256 exists
+        f(I("v_max3_f32", t[0], sc[0], sc[1], sc[2])); f(I("v_max3_f32", t[1], sc[3], sc[4], sc[5])); f(I("v_max3_f32", t[2], sc[6], sc[7], sc[8]))
+        f(I("v_max3_f32", t[0], t[0], t[1], t[2]))
+        for ctrl in ("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror"):
+            f(s_nop(1), I("v_max_f32_dpp", t[0], t[0], t[0], mods=f"{ctrl} row_mask:0xf bank_mask:0xf", rw=True))
+        f(s_nop(0), I("v_readlane_b32", self.s_t[0], t[0], 0), I("v_readlane_b32", self.s_t[1], t[0], 16))
+        f(I("v_mov_b32", t[1], self.s_t[1]), I("v_max_f32", t[0], self.s_t[0], t[1]))
+        f(I("v_mul_f32", t[0], scal, t[0])); f(I("v_xor_b32", t[1], 0x80000000, t[0]))                 # t1 = -m * scale
+        for tau in range(9): f(I("v_fma_f32", sc[tau], sc[tau], scal, t[1]))
+        for tau in range(9): f(I("v_exp_f32", sc[tau], sc[tau]))
+        f(s_nop(0), I("v_add_f32", t[2], sc[0], sc[1])); f(I("v_add_f32", t[3], sc[2], sc[3])); f(I("v_add_f32", t[2], t[2], sc[4])); f(I("v_add_f32", t[3], t[3], sc[5]))
+        f(I("v_add_f32", t[2], t[2], sc[6])); f(I("v_add_f32", t[3], t[3], sc[7])); f(I("v_add_f32", t[2], t[2], sc[8])); f(I("v_add_f32", t[2], t[2], t[3]))
+        for ctrl in ("quad_perm:[1,0,3,2]", "quad_perm:[2,3,0,1]", "row_half_mirror", "row_mirror"):
+            f(s_nop(1), I("v_add_f32_dpp", t[2], t[2], t[2], mods=f"{ctrl} row_mask:0xf bank_mask:0xf", rw=True))
+        f(s_nop(0), I("v_readlane_b32", self.s_t[0], t[2], 0), I("v_readlane_b32", self.s_t[1], t[2], 16))
+        f(I("v_mov_b32", t[3], self.s_t[1]), I("v_add_f32", t[2], self.s_t[0], t[3]), I("v_rcp_f32", t[3], t[2]))
+        f(s_nop(0), I("v_mul_f32", sc[0], sc[0], t[3]))
+        for tau in range(1, 9): f(I("v_mul_f32", sc[tau], sc[tau], t[3]))
+        for tau in range(9):
+            f(I("v_cvt_f16_f32", sc[tau], sc[tau]))
+        for tau in range(9):
+            f(I("ds_write_b16", self.vPWR, sc[tau], ndef=0, mods=f"offset:{tau * 64}"))
+        return early, F
+
+    def solo_pv(self, tau):
+        """(LDS reads, MFMA): the class row's P V on key step tau, this wave's (key half sp_w, head-dim half db_w)."""
+        i = tau & 1
+        rd = [I("ds_read_b64_tr_b16", self.aVS[i].sub(2 * hf, 2), self.vVSADDR[hf], mods=f"offset:{tau * 4096}") for hf in range(2)]
+        rd += [I("ds_read_b64", self.vPS[i].sub(0, 2), self.vPRD, mods=f"offset:{64 * tau}"),
+               I("ds_read_b64", self.vPS[i].sub(2, 2), self.vPRD, mods=f"offset:{64 * tau + 16}")]
+        return rd, mfma_f16(self.aOS, self.aVS[i], self.vPS[i], self.aOS)
+
+    def solo_partial_write(self):
+        """End of an item: this wave's partial class-row output (16 registers of lanes l31 == 0) -> LDS [parity][wave][hi][16]."""
+        T = self.vS[0][0]
+        out = [I("v_accvgpr_read_b32", T[k], self.aOS[k]) for k in range(16)]
+        out += [I("v_add_u32", self.vX[0], self.s_opar, self.vOWR)]
+        out += [I("v_cmp_eq_u32", VCC, 0, self.vL31), I("s_and_saveexec_b64", self.s_exec, VCC, xdef=[EXEC])]
+        out += [I("ds_write_b128", self.vX[0], T.sub(4 * k, 4), ndef=0, mods=f"offset:{16 * k}") for k in range(4)]
+        out += [I("s_mov_b64", EXEC, self.s_exec)]
+        return fix_hazards(out, "solo_partial", self.report)
+
+    def solo_merge(self, tag):
+        """Behind a workgroup barrier: waves 0 / 1 (sp = 0, db = w) add their own and wave w + 2's partial of the PREVIOUS item
+        (parity s_opar) and store head dims 32 db + 8 k + 4 hi + {0..3} of row 256: lanes l31 == 0, 8 bytes per k."""
+        A_, B_ = self.vS[0][0], self.vS[0][1]
+        X = self.vX
+        t = self.s_t
+        out = [I("s_cmp_eq_u32", self.s_havep, 0, ndef=0), I("s_cbranch_scc1", f"L_mrg_skip_{tag}", ndef=0),
+               I("s_cmp_ge_u32", self.s_w, 2, ndef=0), I("s_cbranch_scc1", f"L_mrg_skip_{tag}", ndef=0)]
+        body = [I("v_add_u32", X[8], self.s_opar, self.vOWR)]
+        body += [I("v_cmp_eq_u32", VCC, 0, self.vL31), I("s_and_saveexec_b64", self.s_exec, VCC, xdef=[EXEC])]
+        body += [I("ds_read_b128", A_.sub(4 * k, 4), X[8], mods=f"offset:{16 * k}") for k in range(4)]
+        body += [I("ds_read_b128", B_.sub(4 * k, 4), X[8], mods=f"offset:{256 + 16 * k}") for k in range(4)]
+        body += [I("s_lshl_b32", t[2], self.s_outrow, 8), I("s_add_u32", t[2], t[2], self.s_oprev)]            # row 256 of the previous item
+        for k in range(4):
+            body += [I("v_add_f32", A_[4 * k + j], A_[4 * k + j], B_[4 * k + j]) for j in range(4)]
+            body += [I("v_cvt_pk_f16_f32", X[2 * (k & 1)], A_[4 * k], A_[4 * k + 1]), I("v_cvt_pk_f16_f32", X[2 * (k & 1) + 1], A_[4 * k + 2], A_[4 * k + 3]),
+                     I("buffer_store_dwordx2", X[2 * (k & 1): 2 * (k & 1) + 2], self.vOSOFF, self.s_ro, t[2], ndef=0, mods=f"offen offset:{16 * k}"), s_nop(1)]
+        body += [I("s_mov_b64", EXEC, self.s_exec)]
+        body, _ = add_lgkm_waits(body)
+        out += fix_hazards(body, f"solo_merge_{tag}", self.report)
+        out += [Label(f"L_mrg_skip_{tag}")]
+        return out
+
     def rescale_check(self, solo):
         st = self.new_site()
         blk = [Label(f"L_resc_{st}"), s_nop(15)]
@@ -310,6 +420,19 @@ class Gen:
                 if i < len(b): stream.append(b[i])
                 if i % 4 == 3 and c: stream.append(c.pop(0))
             stream += c
+        if self.split:
+            if t == 0 and "nosm" not in self.abl:
+                e, c = self.solo_softmax()
+                early += e
+                merged, ci = [], 0                    # the class row's softmax rides between the two blocks' streams
+                for i, fl in enumerate(stream):
+                    merged.append(fl)
+                    if i % 3 == 2 and ci < len(c): merged.append(c[ci]); ci += 1
+                stream = merged + c[ci:]
+            for tau in ([t - 1] if 1 <= t < NKB - 1 else [NKB - 2, NKB - 1] if t == NKB - 1 else []):
+                rd, m_ = self.solo_pv(tau)
+                if "nolds" not in self.abl: early.append(Filler(rd, after=0, prio=0))
+                mf.append(m_)
         if "nosm" in self.abl: stream, self.ool = [], self.ool[:n_ool]
         if "nomfma" in self.abl: mf = [s_nop(0) for _ in mf]
         return self.rescale_check(solo) + interleave(mf, early, stream, head_room=2)
@@ -326,10 +449,12 @@ class Gen:
             for ks in range(4):
                 for qb in range(2): pro.append(self.qk(qb, t, ks))
                 if solo: pro.append(self.qk_solo(t, ks))
+        if self.split: pro += self.solo_scores()
         for ks in range(4): pro.append(self.k_read(2, ks))
         for sp in range(2):
             for db in range(2): pro += self.v_reads(0, sp, db)
         pro, _ = add_lgkm_waits(pro)
+        pro = fix_hazards(pro, f"prologue_{tag}", self.report)
         add(pro)
         add(s_nop(15))
         sm0 = []
@@ -338,6 +463,7 @@ class Gen:
         sm0, _ = add_lgkm_waits(sm0)
         add(sm0)
         add(s_waitcnt(lgkm=0))
+        if self.split: add(I("s_barrier", ndef=0))     # every wave's class-row scores are in the strip
         # The kernel moves 2.5 GB of q | k | v in and 0.8 GB out per call of the tower's shape (>= 540 us at the 6.3 TB/s a streaming
         # kernel reaches): the next item's 18 pieces are spread over the first `dma_steps` steps of this item.  Measured
         # (profiles/r05f_clip_attn_asm.txt): all in step 0: 976 us, 2 steps 933, 3 steps 923, 5 steps 879, 9 steps 910 — a burst stalls
@@ -467,6 +593,23 @@ class Gen:
         # strip: write at key * 2 (lane & 31), read at (4 hi) * 2 (+ 32 sp, + 16 for the second run)
         add(I("v_lshlrev_b32", self.vSTRIP[0], 1, self.vL31)); add(I("v_add_u32", self.vSTRIP[0], STRIP, self.vSTRIP[0]))
         add(I("v_lshlrev_b32", self.vSTRIP[1], 3, self.vHI)); add(I("v_add_u32", self.vSTRIP[1], STRIP, self.vSTRIP[1]))
+        if self.split:
+            # class row, shared form: per-wave addresses — the code is the same for the four waves
+            add(I("s_lshl_b32", t[0], self.s_w, 12))
+            for ks in range(4): add(I("v_add_u32", self.vKSADDR[ks], t[0], self.vKADDR[ks]))                   # key step w
+            add(I("s_lshr_b32", t[1], self.s_w, 1)); add(I("s_lshl_b32", t[1], t[1], 11))                      # sp_w * 16 rows * 128 B
+            add(I("s_and_b32", t[0], self.s_w, 1)); add(I("s_cmp_eq_u32", t[0], 1, ndef=0)); add(I("s_cselect_b64", VCC, -1, 0))
+            for hf in range(2):
+                add(I("v_cndmask_b32", self.vVSADDR[hf], self.vVADDR[0][hf], self.vVADDR[1][hf], VCC))          # db_w
+                add(I("v_add_u32", self.vVSADDR[hf], t[1], self.vVSADDR[hf]))
+            add(I("s_lshl_b32", t[2], self.s_w, 7)); add(I("v_lshl_add_u32", self.vSWR, self.vL31, 2, t[2])); add(I("v_add_u32", self.vSWR, SSTRIP, self.vSWR))
+            add(I("v_lshlrev_b32", self.vSRD, 2, self.vL31)); add(I("v_add_u32", self.vSRD, SSTRIP, self.vSRD))
+            add(I("v_lshlrev_b32", self.vPWR, 1, self.vL31)); add(I("v_add_u32", self.vPWR, PSTRIP, self.vPWR))
+            add(I("s_lshr_b32", t[1], self.s_w, 1)); add(I("s_lshl_b32", t[1], t[1], 5))                       # 32 sp_w
+            add(I("v_lshl_add_u32", self.vPRD, self.vHI, 3, t[1])); add(I("v_add_u32", self.vPRD, PSTRIP, self.vPRD))
+            add(I("v_lshl_add_u32", self.vOWR, self.vHI, 6, t[2])); add(I("v_add_u32", self.vOWR, OSTRIP, self.vOWR))
+            add(I("s_lshl_b32", t[0], t[0], 6)); add(I("v_lshl_add_u32", self.vOSOFF, self.vHI, 3, t[0]))      # 8 hi + 64 db_w
+            add(I("s_mov_b32", self.s_havep, 0)); add(I("s_mov_b32", self.s_opar, 0)); add(I("s_mov_b32", self.s_oprev, 0))
         # DMA source offsets.  K piece: row = 32 t + (L & 31), chunk 2 ks + (L >> 5).  V piece pi: row 8 pi + (L >> 3), chunk (L & 7) ^ swz64(row)
         add(I("v_mul_lo_u32", X[0], self.vL31, self.s_ld2)); add(I("v_lshl_add_u32", self.vKOFF, self.vHI, 4, X[0]))
         add(I("v_lshrrev_b32", X[0], 3, self.vLANE)); add(I("v_mul_lo_u32", X[1], X[0], self.s_ld2))
@@ -493,6 +636,9 @@ class Gen:
         P.label("L_item")
         add(s_waitcnt(vm=0)); add(I("s_barrier", ndef=0))
         add(self.stamp(0))
+        if self.split:
+            add(self.solo_merge("top"))
+            add(I("s_xor_b32", self.s_opar, self.s_opar, 512))
         # out offset of this item: (b * 257) * outrow + h * 128
         self.item_offsets(P, self.s_item, self.s_qbase)
         add(I("s_mul_i32", self.s_obase, t[2], self.s_outrow)); add(I("s_add_u32", self.s_obase, self.s_obase, t[3]))
@@ -501,7 +647,7 @@ class Gen:
         for i in range(16): add(I("v_accvgpr_mov_b32", self.aQS[i], self.vQN[32 + i]))
         for q in range(2):
             for i in range(32): add(I("v_accvgpr_write_b32", self.aO[q][i], 0))
-        for i in range(32): add(I("v_accvgpr_write_b32", self.aOS[i], 0))
+        for i in range(self.aOS.n): add(I("v_accvgpr_write_b32", self.aOS[i], 0))
         for q in range(3): add(I("v_mov_b32", self.vL[q], 0)); add(I("v_mov_b32", self.vALPHA[q], 1.0))
         add(I("s_mov_b32", self.s_pend, 0))
         # the next item (K / V into the other buffer during this item, Q into vQN); past the end: loads that fetch nothing
@@ -511,25 +657,38 @@ class Gen:
         self.item_offsets(P, t[4], self.s_nbase)
         add(self.dma_setup(self.s_nbase))
         add(self.q_prefetch(self.s_nbase))
-        add(I("s_cmp_eq_u32", self.s_w, 3, ndef=0)); add(I("s_cbranch_scc1", "L_item_solo", ndef=0))
-        self.item_body(P, solo=False)
-        add(self.stamp(1))
-        add(self.epilogue(False))
-        add(I("s_branch", "L_item_end", ndef=0))
-        P.label("L_item_solo")
-        self.item_body(P, solo=True)
-        add(self.stamp(1))
-        add(self.epilogue(True))
+        if self.split:
+            self.item_body(P, solo=False)
+            add(self.stamp(1))
+            add(self.solo_partial_write())
+            add(self.epilogue(False))
+            add(I("s_mov_b32", self.s_oprev, self.s_obase)); add(I("s_mov_b32", self.s_havep, 1))
+        else:
+            add(I("s_cmp_eq_u32", self.s_w, 3, ndef=0)); add(I("s_cbranch_scc1", "L_item_solo", ndef=0))
+            self.item_body(P, solo=False)
+            add(self.stamp(1))
+            add(self.epilogue(False))
+            add(I("s_branch", "L_item_end", ndef=0))
+            P.label("L_item_solo")
+            self.item_body(P, solo=True)
+            add(self.stamp(1))
+            add(self.epilogue(True))
         P.label("L_item_end")
         add(self.stamp(2))
         # swap buffers: fragment addresses move to the other buffer
         for ks in range(4): add(I("v_add_u32", self.vKADDR[ks], self.s_delta, self.vKADDR[ks]))
         for db in range(2):
             for hf in range(2): add(I("v_add_u32", self.vVADDR[db][hf], self.s_delta, self.vVADDR[db][hf]))
+        if self.split:
+            for ks in range(4): add(I("v_add_u32", self.vKSADDR[ks], self.s_delta, self.vKSADDR[ks]))
+            for hf in range(2): add(I("v_add_u32", self.vVSADDR[hf], self.s_delta, self.vVSADDR[hf]))
         add(I("s_sub_u32", self.s_delta, 0, self.s_delta))
         add(I("s_mov_b32", t[0], self.s_buf)); add(I("s_mov_b32", self.s_buf, self.s_nbuf)); add(I("s_mov_b32", self.s_nbuf, t[0]))
         add(I("s_mov_b32", self.s_item, self.s_next))
         add(I("s_cmp_lt_u32", self.s_item, self.s_nitems, ndef=0)); add(I("s_cbranch_scc1", "L_item", ndef=0))
+        if self.split:                                 # the last item's class row
+            add(s_waitcnt(lgkm=0)); add(I("s_barrier", ndef=0))
+            add(self.solo_merge("end"))
         if self.prof:
             add(s_waitcnt(vm=0))
             add(I("s_cmp_eq_u64", self.s_prof, 0, ndef=0)); add(I("s_cbranch_scc1", "L_exit", ndef=0))
@@ -543,8 +702,8 @@ class Gen:
         return P
 
 
-def generate(abl=(), prof=False, name=KNAME, dma_steps=5):
-    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps)
+def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=True):
+    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     hdr = ("// GENERATED by csrc/asm/attn_clip_d64.py — do not edit.  Register map:\n" + g.S.listing() + "\n" + g.V.listing() + "\n" + g.A.listing()
@@ -559,7 +718,7 @@ def generate(abl=(), prof=False, name=KNAME, dma_steps=5):
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
                 ("dma1", dict(prof=True, dma_steps=1)), ("dma2", dict(prof=True, dma_steps=2)), ("dma5", dict(prof=True, dma_steps=3)),
-                ("dma9", dict(prof=True, dma_steps=9))]
+                ("dma9", dict(prof=True, dma_steps=9)), ("solo3", dict(prof=True, solo_split=False))]
 
 
 def unique_labels(text, suffix):

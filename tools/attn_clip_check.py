@@ -26,7 +26,9 @@ def run(B, H, seed=0, spike=False, scale=1.0):
     _lib.configure("attn_clip_asm", 0)
     orf = ref(qkv, B, H)
     e0, e1 = (o0.float() - orf).abs().max().item(), (o1.float() - orf).abs().max().item()
-    ok = e1 <= max(2.0 * e0, 2e-3) and torch.isfinite(o1.float()).all().item()
+    import math
+    ulp = 2.0 ** (math.floor(math.log2(orf.abs().max().item())) - 10)       # fp16 ulp of the largest output (tests/test_gpu_r5.py)
+    ok = e1 <= max(2.0 * e0, 2e-3, 1.5 * ulp) and torch.isfinite(o1.float()).all().item()
     print("B=%4d H=%2d spike=%d: O err asm %.3e (c++ %.3e) %s" % (B, H, spike, e1, e0, "ok" if ok else "FAIL"), flush=True)
     if not ok:
         d = (o1.float() - orf).abs().view(B, 257, H, 64)

@@ -10,7 +10,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "solo3"]
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -34,10 +34,11 @@ print(flush=True, *[f"c++ resident kernel   {t:8.1f} us  {fl / t / 1e6:6.0f} TF/
 for v, name in enumerate(VARIANTS):
     t = timeit(lambda: run(v))
     print(flush=True, *[f"asm {name:12s}      {t:8.1f} us  {fl / t / 1e6:6.0f} TF/s"])
-prof.zero_(); run(1, prof); torch.cuda.synchronize()
-p = (prof.cpu().numpy().astype("int64") & 0xffffffff).reshape(256 * 4, 8)
 names = ["item start wait (vmcnt + barrier)", "setup + item body", "epilogue + buffer swap"]
-tot = p[:, :3].sum(1)
-for w in range(4):
-    pw = p[w::4]
-    print(flush=True, *[f"wave {w}: " + "  ".join(f"{names[k]} {pw[:, k].mean() / 100:8.0f}" for k in range(3)) + f"   per item {pw[:, :3].sum(1).mean() / 100:8.0f} cycles"])
+for v, label in ((1, "production (class row shared by the four waves)"), (VARIANTS.index("solo3"), "solo3 (class row on wave 3)")):
+    prof.zero_(); run(v, prof); torch.cuda.synchronize()
+    p = (prof.cpu().numpy().astype("int64") & 0xffffffff).reshape(256 * 4, 8)
+    print(f"cycle stamps, {label}:")
+    for w in range(4):
+        pw = p[w::4]
+        print(flush=True, *[f"  wave {w}: " + "  ".join(f"{names[k]} {pw[:, k].mean() / 100:8.0f}" for k in range(3)) + f"   per item {pw[:, :3].sum(1).mean() / 100:8.0f} cycles"])
