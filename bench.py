@@ -16,6 +16,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
   "cpu_baseline": the CPU oracle (oracle/ref_cpu.py, a port of the reference's eager fp32 path) timed on
                   this host's cores on a bounded sample and scaled to samples/s (rank 0, N=1 only).
+Further objects: "hbm" (the HBM-bound kernels against 8 TB/s), "h2d" (the same step fed from a CPU batch per step through
+hvlm.prefetch), "energy" (joules per step from the socket's accumulator: every kernel of this path runs at the power cap, so
+TFLOP per joule is what the step time follows), "eval" / "other_configs" (BASELINE configs 2, 4, 5 with their own rooflines).
 """
 import argparse
 import json
@@ -279,6 +282,31 @@ def fp8_pmc_traffic(shapes):
                                    f"profiles/{os.path.basename(path)}), weighted by this run's launches; algorithmic operand + output + scale bytes "
                                    f"per launch: {algo / len(shapes) / 1e9:.2f} GB")
     return None, "no profiles/r*_gemm_traffic_fp8.json covers this run's e4m3 shapes"
+
+
+class EnergyCounter:
+    """The socket's energy accumulator through librocm_smi64 (rsmi_dev_energy_count_get: a register read, microseconds — `rocm-smi` as a
+    child process takes ~0.5 s, which at 300 W idle is 2 % of a 20-step run).  Read right before and right after the timed region,
+    OUTSIDE the barrier / synchronize bracket.  None when the library or the counter is not there."""
+
+    def __init__(self, index=0):
+        self.ok, self.index = False, index
+        try:
+            import ctypes
+            self.ct = ctypes
+            self.lib = ctypes.CDLL("librocm_smi64.so")
+            self.ok = self.lib.rsmi_init(ctypes.c_uint64(0)) == 0
+        except Exception:  # noqa
+            self.ok = False
+
+    def joules(self):
+        if not self.ok:
+            return None
+        ct = self.ct
+        cnt, res, ts = ct.c_uint64(0), ct.c_float(0.0), ct.c_uint64(0)
+        if self.lib.rsmi_dev_energy_count_get(ct.c_uint32(self.index), ct.byref(cnt), ct.byref(res), ct.byref(ts)) != 0:
+            return None
+        return float(cnt.value) * float(res.value) * 1e-6          # counter x resolution = microjoules
 
 
 def _physical_cores():
@@ -853,6 +881,8 @@ def main():
     ev.enabled = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     segs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+    energy = EnergyCounter(local)
+    j0 = energy.joules()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -860,6 +890,8 @@ def main():
         marks[i + 1].record()                  # (no synchronisation: per-step GPU time for the `step_ms` diagnostic)
     barrier()
     dt = time.perf_counter() - t0
+    j1 = energy.joules()
+    dt_local = dt
     ev.enabled = False
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     rank_skew = None
@@ -1017,6 +1049,14 @@ def main():
             res["box_calibration"] = calib
         if h2d is not None:
             res["h2d"] = h2d
+        if j0 is not None and j1 is not None and j1 > j0:
+            jps = (j1 - j0) / args.steps
+            res["energy"] = {"joules_per_step": jps, "avg_power_w": (j1 - j0) / dt_local, "tflop_per_joule": step_flops / 1e12 / jps,
+                             "gpu": "rank 0's socket", "note": "socket energy accumulator (librocm_smi64 rsmi_dev_energy_count_get) read right before and right after "
+                             "the timed region.  Every kernel of this path runs at the ~1400 W cap when launched back to back (profiles/r05m_energy_probe.txt: "
+                             "GEMM, attention and the HBM-bound passes alike), so a kernel costs its JOULES, not its cycles: the hand-scheduled attention kernels need "
+                             "15-20 % fewer cycles than the C++ ones at S = 867, the same joules, and take the same time inside the step; the MFMA-only ceiling "
+                             "under the cap is 2132 TFLOP/s = 1.52 TFLOP/J (profiles/r02h_mfma_power_probe.txt), the GEMM kernel delivers 1.0"}
         res["step_tail_ms"] = tail_ms
         res["step_ms"] = [round(v, 1) for v in step_ms]      # every timed step on the compute stream (one-time costs show up here)
         res["device_allocs_in_timed_region"] = int(torch.cuda.memory_stats(device).get("num_device_alloc", 0) - segs0)   # hipMalloc calls of the caching allocator

@@ -12,14 +12,16 @@ construction (profiles/r03d: the C++ kernel's two waves per SIMD do not overlap 
 arranged for ONE instruction stream per SIMD that never stalls on the matrix pipe:
   * workgroup = 4 waves, wave w owns query rows [32 w, 32 w + 32) and [128 + 32 w, 160 + 32 w): eight full blocks, balanced;
   * three-stage pipeline inside an item:  QK^T of step t+2 | softmax of step t+1 | P V of step t  (as attn_fwd_d128.py);
-  * the 257th query (the class token's row) is SHARED by the four waves, in the same code for all of them (solo_split): its
-    scores come from SWAPPED MFMA operands (lanes = keys) — wave w computes key steps w, w + 4 (and a third round) in the prologue
-    and leaves them in an LDS strip; one workgroup barrier; every wave then runs the 257-key softmax of that row itself (9 scores
-    per lane, NO running maximum — all scores are known) and writes the normalised fp16 probabilities to a strip in key order;
-    the P V product is split into (key half sp, head-dim half db) = wave: ONE extra MFMA per key step per wave on a V fragment
-    the wave reads through its own address; the two key halves are added through LDS after the NEXT item's barrier and stored
-    there.  (First version, kept as the dev variant `solo3`: wave 3 alone, 8 extra MFMAs + a serial softmax per step — the other
-    three waves waited ~4100 cycles per item for it, profiles/r05f_clip_attn_asm.txt.)
+  * the 257th query (the class token's row) is computed by wave 3 with SWAPPED MFMA operands (lanes = keys: one score register
+    per step, 9 exponentials per lane instead of 144), reusing the K / V fragments already in registers; its probabilities reach
+    the k-slot order of the V^T fragments through a 64-byte LDS strip.  The other three waves wait ~4100 cycles per item for it.
+    A BALANCED form exists as the dev variant `split` (solo_split=True: every wave computes the scores of two or three key steps
+    in the prologue, one barrier, the 257-key softmax per wave, P V split into (key half, head-dim half) = wave, partial sums
+    merged through LDS after the next item's barrier — one code path for the four waves, half the code).  Measured
+    (profiles/r05m_clip_attn_split.txt): every wave 14.2k cycles of body instead of 11.9k / 15.2k, the same 17.3k cycles per
+    item, and 5 % MORE time per call (980 vs 933 us) — it issues 84 instead of 72 class-row MFMAs and four softmaxes instead of
+    one, and on this chip a call costs its JOULES (every kernel here runs at the 1400 W cap, tools/energy_probe.py), not the
+    cycles of its slowest wave: idle waves are nearly free, extra instructions are not.  Not adopted;
   * deferred running maximum (raised only when exceeded by 2^8) with the O rescale out of line, as in the decoder kernel;
   * outputs leave as 16-byte stores after a v_permlane32_swap exchange of the accumulator halves.
 """
@@ -37,8 +39,8 @@ KBYTES = NKB * 4096             # K image: row major [288][64] fp16 like V (whol
                                 # decoder kernel fetches 32-byte granules of 32 rows per instruction — measured slower here, the kernel is HBM-bound)
 VBYTES = NKB * 32 * 128         # V image: row major [288][64] fp16, 16-B chunks XOR-swizzled by row (attention.hip swz_bits<64>)
 BUF = KBYTES + VBYTES           # 73728
-STRIP = 2 * BUF                 # 2 x 64 B: wave 3's probabilities of the class-token row (solo3 variant)
-SSTRIP = STRIP + 256            # class-token row, shared form: raw scores [12 key steps][32] f32 (steps 9..11: the idle third rounds)
+STRIP = 2 * BUF                 # 2 x 64 B: wave 3's probabilities of the class-token row
+SSTRIP = STRIP + 256            # class-token row, `split` variant: raw scores [12 key steps][32] f32 (steps 9..11: the idle third rounds)
 PSTRIP = SSTRIP + 1536          # its normalised probabilities [288] fp16, key order
 OSTRIP = PSTRIP + 576 + 64      # its partial outputs [item parity][wave][hi][16] f32
 LDS_BYTES = OSTRIP + 1024
@@ -54,7 +56,7 @@ def mfma_f16(d, a, b, c):
 
 
 class Gen:
-    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=True):
+    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=False):
         self.abl, self.prof, self.dma_steps, self.split = set(abl), prof, dma_steps, solo_split
         self.report, self.site, self.ool = [], 0, []
         S = self.S = RegFile("s", 0, 102)
@@ -294,11 +296,13 @@ class Gen:
 
     def solo_softmax(self):
         """Step 0: softmax of the class row over all 257 keys, by every wave for itself (lane l31 of either half: keys 32 tau + l31).
-        Returns (early LDS reads, VALU stream).  Probabilities are NORMALISED before the fp16 rounding: P V needs no division."""
+        Returns (the nine score reads, VALU stream).  Probabilities are NORMALISED before the fp16 rounding: P V needs no division."""
         sc = [self.vSS[0][i] for i in range(9)]
         t = self.vT[2]
         scal = self.s_scale
-        early = [Filler([I("ds_read_b32", sc[tau], self.vSRD, mods=f"offset:{tau * 128}") for tau in range(3 * g, 3 * g + 3)], after=g, prio=0) for g in range(3)]
+        # (the reads head the item body as plain instructions, NOT as `early` fillers: the interleaver orders fillers of different
+        #  kinds by gap capacity only, and the first version's VALU stream reached the scores before their reads were issued)
+        early = [I("ds_read_b32", sc[tau], self.vSRD, mods=f"offset:{tau * 128}") for tau in range(9)]
         F = []
         def f(*ins, **kw): F.append(Filler(list(ins), **kw))
         f(I("v_cmp_eq_u32", VCC, 0, self.vL31), I("v_cndmask_b32", sc[8], self.vNINF, sc[8], VCC))     # key step 8: only key 256 exists
@@ -422,8 +426,7 @@ class Gen:
             stream += c
         if self.split:
             if t == 0 and "nosm" not in self.abl:
-                e, c = self.solo_softmax()
-                early += e
+                _, c = self.solo_softmax()            # (its score reads: item_body puts them in front of step 0)
                 merged, ci = [], 0                    # the class row's softmax rides between the two blocks' streams
                 for i, fl in enumerate(stream):
                     merged.append(fl)
@@ -431,7 +434,7 @@ class Gen:
                 stream = merged + c[ci:]
             for tau in ([t - 1] if 1 <= t < NKB - 1 else [NKB - 2, NKB - 1] if t == NKB - 1 else []):
                 rd, m_ = self.solo_pv(tau)
-                if "nolds" not in self.abl: early.append(Filler(rd, after=0, prio=0))
+                if "nolds" not in self.abl: early.append(Filler(rd, after=0, before=len(mf) - 1, prio=0))
                 mf.append(m_)
         if "nosm" in self.abl: stream, self.ool = [], self.ool[:n_ool]
         if "nomfma" in self.abl: mf = [s_nop(0) for _ in mf]
@@ -470,7 +473,7 @@ class Gen:
         # the issuing wave (in-order issue behind a full memory queue), the last pieces of a full spread land too late.
         dma = self.dma_groups()
         per = (len(dma) + self.dma_steps - 1) // self.dma_steps
-        body = []
+        body = list(self.solo_softmax()[0]) if (self.split and "nosm" not in self.abl) else []
         for t in range(NKB):
             body += self.step(t, solo, dma[per * t: per * (t + 1)])
         # lgkm entry state: everything the prologue issued has been waited for (lgkmcnt(0) above)
@@ -702,7 +705,7 @@ class Gen:
         return P
 
 
-def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=True):
+def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False):
     g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
@@ -718,7 +721,7 @@ def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=True):
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
                 ("dma1", dict(prof=True, dma_steps=1)), ("dma2", dict(prof=True, dma_steps=2)), ("dma5", dict(prof=True, dma_steps=3)),
-                ("dma9", dict(prof=True, dma_steps=9)), ("solo3", dict(prof=True, solo_split=False))]
+                ("dma9", dict(prof=True, dma_steps=9)), ("split", dict(prof=True, solo_split=True))]
 
 
 def unique_labels(text, suffix):

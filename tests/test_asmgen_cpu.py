@@ -169,13 +169,14 @@ def test_clip_generator_assembles_inside_the_budget(tmp_path):
     import attn_clip_d64 as gen
     text, g, n_mfma = gen.generate()
     _check_text(text)
-    # 16 QK MFMAs in the prologue + 7 x 16 + 2 x 8 in the steps, + the class-token row: 3 rounds x 4 for its scores, 9 for its P V
-    assert n_mfma == 16 + 7 * 16 + 2 * 8 + 12 + 9 == text.count("v_mfma_f32_32x32x16_f16")
-    assert text.count("s_barrier") == 3                                # item start, class-row scores, the last item's class row
+    # two bodies (waves 0-2 / wave 3): 16 QK MFMAs in the prologue + 7 x 16 + 2 x 8 in the steps; wave 3 adds 8 per step for the class row
+    assert n_mfma == 2 * 144 + 9 * 8 == text.count("v_mfma_f32_32x32x16_f16")
+    assert text.count("s_barrier") == 1
     _assemble(text, tmp_path, "clip")
-    text3, g3, n3 = gen.generate(solo_split=False)                      # first version: the class row on wave 3 (two bodies)
-    assert n3 == 2 * 144 + 9 * 8 and len(text3) > 1.7 * len(text)
-    _check_text(text3); _assemble(text3, tmp_path, "clip_solo3")
+    # the balanced dev variant: one body, + 3 rounds x 4 for the class row's scores and 9 for its P V on every wave
+    text2, g2, n2 = gen.generate(solo_split=True)
+    assert n2 == 144 + 12 + 9 and text2.count("s_barrier") == 3 and len(text) > 1.7 * len(text2)
+    _check_text(text2); _assemble(text2, tmp_path, "clip_split")
 
 
 @pytest.mark.skipif(shutil.which("make") is None or not os.path.exists(CLANG), reason="toolchain")

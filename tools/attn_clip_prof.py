@@ -10,7 +10,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "solo3"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split"]
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -35,7 +35,7 @@ for v, name in enumerate(VARIANTS):
     t = timeit(lambda: run(v))
     print(flush=True, *[f"asm {name:12s}      {t:8.1f} us  {fl / t / 1e6:6.0f} TF/s"])
 names = ["item start wait (vmcnt + barrier)", "setup + item body", "epilogue + buffer swap"]
-for v, label in ((1, "production (class row shared by the four waves)"), (VARIANTS.index("solo3"), "solo3 (class row on wave 3)")):
+for v, label in ((1, "production (class row on wave 3)"), (VARIANTS.index("split"), "split (class row shared by the four waves)")):
     prof.zero_(); run(v, prof); torch.cuda.synchronize()
     p = (prof.cpu().numpy().astype("int64") & 0xffffffff).reshape(256 * 4, 8)
     print(f"cycle stamps, {label}:")

@@ -97,6 +97,7 @@ def timed(n):
 
 for _ in range(3):
     step()
+timed(3)                                       # (the allocator still settles after the first recording step: one discarded leg)
 print(f"7B B={args.batch} T={args.text_len}: what-if runs, {wargs.steps} steps per leg, A = the step as it is, B = one family replayed from cache", flush=True)
 base = []
 for fam in wargs.what:
