@@ -260,3 +260,38 @@ def test_configure_switches_without_a_device(lib):
     src = os.path.join(os.path.dirname(str(lib.HEADER_PATH)), "..", "handsonvlm-release_amd", "csrc")
     users = [os.path.basename(f) for f in glob.glob(os.path.join(src, "*.hip")) if "getenv(" in open(f).read()]
     assert users == ["runtime.hip"], users
+
+
+def test_round5_switches_and_attention_workspace(lib):
+    """The hand-scheduled attention kernels are production switches (default on) and the decoder forward's work queue lives in the
+    caller's workspace: hvlm_attn_fwd_ws_bytes is non-zero and 64-byte granular (include/hvlm.h, ABI version 2)."""
+    l = lib.load()
+    assert l.hvlm_abi_version() == 2
+    assert lib.config_get("attn_fwd_asm") == 1 and lib.config_get("attn_clip_asm") == 1
+    with lib.configured(attn_fwd_asm=0, attn_clip_asm=0):
+        assert lib.config_get("attn_fwd_asm") == 0 and lib.config_get("attn_clip_asm") == 0
+    assert lib.config_get("attn_fwd_asm") == 1
+    n = l.hvlm_attn_fwd_ws_bytes(16, 867, 32, 128)
+    assert n >= 512 and n % 64 == 0
+    # both code objects are linked into the library (embedded byte arrays), their development entry points are not exported
+    import subprocess
+    blob = open(str(lib.LIB_PATH), "rb").read()
+    assert b"hvlm_fa_fwd_d128_causal" in blob and b"hvlm_fa_clip_d64_s257" in blob
+    if l.hvlm_is_dev_build() == 0:
+        syms = subprocess.run(["nm", "-D", str(lib.LIB_PATH)], capture_output=True, text=True).stdout
+        assert "hvlm_attn_fwd_asm_dev" not in syms and "hvlm_attn_clip_asm_dev" not in syms
+
+
+def test_bench_energy_counter_degrades_to_none():
+    """bench.py's `energy` object: without librocm_smi64 / without a device the reader returns None and the line simply has no `energy`."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ec = mod.EnergyCounter(0)
+    j = ec.joules()
+    assert j is None or j >= 0.0
+    ec.ok = False
+    assert ec.joules() is None
