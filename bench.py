@@ -630,7 +630,9 @@ def other_configs(args):
     import subprocess
     runs = {
         "config2_7b_inference_336px_b1": ["--eval-only", "--image-size", "336"],
-        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "3", "--warmup", "2", "--no-eval",
+        # (three warm-ups: at 13B the caching allocator still settles in the third step — 669-755 ms against 654-655 steady,
+        #  profiles/r05r_13b_attn_asm_ab.txt; with two, the 3-step mean of rounds 3-4 carried that step)
+        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "4", "--warmup", "3", "--no-eval",
                                      "--no-cpu-baseline", "--no-h2d"],
         # the headline workload with EXACT frame de-duplication: the reference's EK100 dataset always hands the model 10 distinct
         # frames tiled to 100 (handsonvlm/dataset/epic_dataset.py:90-95: image.unsqueeze(0).repeat(10, ...).reshape(100, ...)) and
@@ -1054,7 +1056,7 @@ def main():
             res["energy"] = {"joules_per_step": jps, "avg_power_w": (j1 - j0) / dt_local, "tflop_per_joule": step_flops / 1e12 / jps,
                              "gpu": "rank 0's socket", "note": "socket energy accumulator (librocm_smi64 rsmi_dev_energy_count_get) read right before and right after "
                              "the timed region.  Every kernel of this path runs at the ~1400 W cap when launched back to back (profiles/r05m_energy_probe.txt: "
-                             "GEMM, attention and the HBM-bound passes alike), so a kernel costs its JOULES, not its cycles: the hand-scheduled attention kernels need "
+                             "GEMM, attention and the HBM-bound passes alike), so a kernel costs its JOULES first (idle matrix-pipe time comes back as clock at ~0.6 of its share, profiles/r05s): the hand-scheduled attention kernels need "
                              "15-20 % fewer cycles than the C++ ones at S = 867, the same joules, and take the same time inside the step; the MFMA-only ceiling "
                              "under the cap is 2132 TFLOP/s = 1.52 TFLOP/J (profiles/r02h_mfma_power_probe.txt), the GEMM kernel delivers 1.0"}
         res["step_tail_ms"] = tail_ms

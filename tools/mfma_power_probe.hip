@@ -115,6 +115,61 @@ __global__ __launch_bounds__(512, 2) void probe(const unsigned short* __restrict
   out[t] = sum;
 }
 
+
+// Duty-cycle experiment (round 5): ONE wave per SIMD issues 32 independent v_mfma_f32_16x16x32_bf16 (512 matrix-pipe cycles) and then
+// sleeps 64 * SLEEP cycles, every CU busy.  If the chip is energy-limited, the idle share is returned as clock: the rate stays flat until the duty
+// cycle falls below (sustained clock / 2.4 GHz) — i.e. REMOVING idle matrix-pipe cycles from a power-capped kernel buys nothing.
+template <int SLEEP, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void probe_duty(const unsigned short* __restrict__ src, float* __restrict__ out, int iters) {
+  const int t = blockIdx.x * THREADS + threadIdx.x;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = *reinterpret_cast<const bf16x8*>(src + ((size_t)(t * 8 + i) * 8) % (1 << 24));
+    b[i] = *reinterpret_cast<const bf16x8*>(src + ((size_t)(t * 8 + 4 + i) * 8) % (1 << 24));
+  }
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+    if constexpr (THREADS > 256) __builtin_amdgcn_s_barrier();     // two waves per SIMD: they go idle together
+    if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += acc[i][r];
+  out[t] = sum;
+}
+
+template <int SLEEP, int THREADS>
+static void run_duty(const unsigned short* src, float* out, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int grid = 256;                      // one workgroup per CU: 4 waves = one wave per SIMD, 8 waves = two
+  probe_duty<SLEEP, THREADS><<<grid, THREADS>>>(src, out, iters / 10);
+  hipDeviceSynchronize();
+  for (int rep = 0; rep < 3; ++rep) probe_duty<SLEEP, THREADS><<<grid, THREADS>>>(src, out, iters);
+  hipEventRecord(e0);
+  for (int rep = 0; rep < 3; ++rep) probe_duty<SLEEP, THREADS><<<grid, THREADS>>>(src, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double fl = 3.0 * (double)grid * (THREADS / 64) * iters * 32.0 * 2 * 16 * 16 * 32;
+  // matrix-pipe cycles per iteration and SIMD: 512 per wave; nominal duty if nothing else interfered
+  const double busy = 512.0 * (THREADS / 256);
+  printf("%d wave(s)/SIMD  sleep %2d x 64 cyc  nominal duty %5.1f %%  %8.1f TFLOP/s   %7.1f ns per iteration  (%.1f ms per launch)\n", THREADS / 256, SLEEP,
+         100.0 * busy / (busy + 64.0 * SLEEP), fl / (ms * 1e-3) / 1e12, ms * 1e6 / (3.0 * iters), ms / 3);
+}
+
 template <int KIND>
 static void run8(const char* name, const unsigned short* src, float* out, int grid, int iters, double flops_per_iter_per_wave) {
   hipEvent_t e0, e1;
@@ -173,5 +228,10 @@ int main(int argc, char** argv) {
   // fp8: every byte a random e4m3 value in (-2, 2)-ish (the same bit patterns read as bytes)
   run8<0>("mfma_scale_32x32x64_fp8", d, out, grid, iters, 8.0 * 2 * 32 * 32 * 64);
   run8<1>("mfma_scale_16x16x128_fp8", d, out, grid, iters, 16.0 * 2 * 16 * 16 * 128);
+  printf("duty-cycle experiment: 32 x mfma_f32_16x16x32_bf16 per wave, then (barrier +) s_sleep; every CU busy\n");
+  run_duty<0, 256>(d, out, 16 * iters); run_duty<2, 256>(d, out, 16 * iters); run_duty<4, 256>(d, out, 16 * iters); run_duty<8, 256>(d, out, 12 * iters);
+  run_duty<0, 512>(d, out, 8 * iters); run_duty<1, 512>(d, out, 8 * iters); run_duty<2, 512>(d, out, 8 * iters); run_duty<4, 512>(d, out, 8 * iters);
+  run_duty<6, 512>(d, out, 8 * iters); run_duty<8, 512>(d, out, 6 * iters); run_duty<12, 512>(d, out, 6 * iters); run_duty<16, 512>(d, out, 4 * iters);
+  run_duty<32, 512>(d, out, 3 * iters);
   return 0;
 }
