@@ -843,11 +843,12 @@ def clip_embed_f16(patch_out, cls, pos, N: int, NP: int, D: int):
     return tokens
 
 
-def attn_fwd_f16(qkv, B: int, S: int, H: int, dh: int, scale: float):
+def attn_fwd_f16(qkv, B: int, S: int, H: int, dh: int, scale: float, out=None):
     _chk(qkv, F16, "attn_f16.qkv")
     assert qkv.dim() == 2 and qkv.shape[0] == B * S and qkv.stride(1) == 1
     lib = _lib.load()
-    o = torch.empty((B * S, H * dh), dtype=F16, device=qkv.device)
+    o = torch.empty((B * S, H * dh), dtype=F16, device=qkv.device) if out is None else out
+    assert o.shape == (B * S, H * dh) and o.dtype == F16 and o.is_contiguous()
     ws = torch.empty((lib.hvlm_attn_fwd_ws_bytes(B, S, H, dh),), dtype=torch.uint8, device=qkv.device)
     check(lib.hvlm_attn_fwd_f16(_p(qkv), _p(o), None, _p(ws), B, S, H, dh, qkv.stride(0), 0, scale, _stream()), "attn_fwd_f16")
     return o
