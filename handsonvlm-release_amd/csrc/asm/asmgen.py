@@ -223,6 +223,8 @@ TRANS_TO_VALU = 1
 VALU_TO_PERM = 2
 M0_TO_LDSDMA = 1
 VSGPR_TO_VMEM = 5
+DOT_TO_VALU_READ = 3         # v_dot2 result -> a different VALU reading it (or the same opcode reading it as A / B)
+DOT_TO_VALU_WRITE = 4        # v_dot2 result -> a different VALU overwriting it
 WINDOW = 16
 
 
@@ -243,6 +245,14 @@ def _need(prev: Ins, cur: Ins) -> int:
             overwrite = (cur.is_mfma and cur.ops[0].ids() == prev.ops[0].ids() and not (pd & cu))
             if not acc_chain and not overwrite:
                 need = max(need, MFMA_RESULT_STATES)
+    if prev.op.startswith("v_dot"):
+        # DOT results (LLVM GCNHazardRecognizer, gfx90a+ rules: DotWriteSameDotReadSrcAB = 3, DotWriteDifferentVALURead = 3,
+        # DotWriteDifferentVALUWrite = 4): back-to-back accumulation through SrcC of the SAME opcode is free, everything else waits
+        same_acc = (cur.op == prev.op and len(cur.ops) == 4 and hasattr(cur.ops[3], "ids") and cur.ops[3].ids() == prev.ops[0].ids()
+                    and not (pd & (cur.ops[1].ids() if hasattr(cur.ops[1], "ids") else set()))
+                    and not (pd & (cur.ops[2].ids() if hasattr(cur.ops[2], "ids") else set())))
+        if (cur.is_valu or cur.is_mfma) and (pd & cu) and not same_acc: need = max(need, DOT_TO_VALU_READ)
+        if (cur.is_valu or cur.is_mfma) and (pd & cd) and not same_acc: need = max(need, DOT_TO_VALU_WRITE)
     if prev.is_valu:
         if cur.is_mfma and (pd & cu): need = max(need, VALU_TO_MFMA)
         if (prev.is_trans or prev.is_cvtpk) and cur.is_valu and (pd & cu): need = max(need, TRANS_TO_VALU)

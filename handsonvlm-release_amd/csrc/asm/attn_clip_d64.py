@@ -18,10 +18,10 @@ arranged for ONE instruction stream per SIMD that never stalls on the matrix pip
     A BALANCED form exists as the dev variant `split` (solo_split=True: every wave computes the scores of two or three key steps
     in the prologue, one barrier, the 257-key softmax per wave, P V split into (key half, head-dim half) = wave, partial sums
     merged through LDS after the next item's barrier — one code path for the four waves, half the code).  Measured
-    (profiles/r05m_clip_attn_split.txt): every wave 14.2k cycles of body instead of 11.9k / 15.2k, the same 17.3k cycles per
-    item, and 5 % MORE time per call (980 vs 933 us) — it issues 84 instead of 72 class-row MFMAs and four softmaxes instead of
-    one, and on this chip a call costs its JOULES (every kernel here runs at the 1400 W cap, tools/energy_probe.py), not the
-    cycles of its slowest wave: idle waves are nearly free, extra instructions are not.  Not adopted;
+    (profiles/r05m_clip_attn_split.txt, r05z_attn_variant_energy.txt): every wave 14.2k cycles of body instead of 11.9k / 15.2k, the same
+    17.3k cycles per item; on a settled chip 927-929 vs 924-926 us and +0.6 % joules per call (5 % slower in 10-launch timing loops,
+    which do not settle the power manager) — it issues 84 instead of 72 class-row MFMAs and four softmaxes instead of one, and that
+    costs what the balance gains.  Not adopted;
   * deferred running maximum (raised only when exceeded by 2^8) with the O rescale out of line, as in the decoder kernel;
   * outputs leave as 16-byte stores after a v_permlane32_swap exchange of the accumulator halves.
 """
@@ -56,8 +56,8 @@ def mfma_f16(d, a, b, c):
 
 
 class Gen:
-    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=False):
-        self.abl, self.prof, self.dma_steps, self.split = set(abl), prof, dma_steps, solo_split
+    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=False, dot_sum=False):
+        self.abl, self.prof, self.dma_steps, self.split, self.dot_sum = set(abl), prof, dma_steps, solo_split, dot_sum
         self.report, self.site, self.ool = [], 0, []
         S = self.S = RegFile("s", 0, 102)
         V = self.V = RegFile("v", 0, 256)
@@ -80,6 +80,7 @@ class Gen:
         self.s_so = S.alloc("soffset tmp", 1)
         self.s_vtail = S.alloc("V soffset of row 256", 1); self.s_ktail = S.alloc("K soffset of row 256", 1)
         self.s_exec = S.alloc("saved exec", 2, 2)
+        self.s_ones = S.alloc("fp16 (1.0, 1.0): the row sum as a dot product of the ROUNDED probability pairs (dot_sum)", 1)
         if solo_split:
             self.s_oprev = S.alloc("previous item: byte offset in out", 1); self.s_havep = S.alloc("a previous item's class row is pending", 1)
             self.s_opar = S.alloc("LDS parity offset of this item's partial class-row outputs (0 / 512)", 1)
@@ -223,13 +224,22 @@ class Gen:
                          I("v_mul_f32", l, l, a), I("v_mul_f32", self.vALPHA[qb], self.vALPHA[qb], a),
                          I("s_bitset1_b32", self.s_pend, qb, rw=True), I("s_branch", f"L_slowret_{st}", ndef=0)]
         consumers = []
-        for k, (a_, b_) in enumerate([(0, 1), (2, 3), (4, 5), (6, 7)]): consumers.append((b_, I("v_add_f32", acc[k], x[a_], x[b_])))
-        for i in range(8, 16): consumers.append((i, I("v_add_f32", acc[i & 3], acc[i & 3], x[i])))
-        tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", acc[2], acc[2], acc[3]), I("v_add_f32", acc[0], acc[0], acc[2]),
-                I("v_add_f32", l, l, acc[0])]
-        for j in range(8):
+        if self.dot_sum:
+            # row sum over the fp16-ROUNDED pairs (what P V multiplies), one v_dot2_f32_f16 per pair instead of two v_add_f32 on the fp32 values
+            tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", l, l, acc[0])]
+        else:
+            for k, (a_, b_) in enumerate([(0, 1), (2, 3), (4, 5), (6, 7)]): consumers.append((b_, I("v_add_f32", acc[k], x[a_], x[b_])))
+            for i in range(8, 16): consumers.append((i, I("v_add_f32", acc[i & 3], acc[i & 3], x[i])))
+            tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", acc[2], acc[2], acc[3]), I("v_add_f32", acc[0], acc[0], acc[2]),
+                    I("v_add_f32", l, l, acc[0])]
+        order = sorted(range(8), key=lambda j: 8 * (j >> 2) + 2 * (j & 3) + 1)
+        for n_, j in enumerate(order):
             sp, k = j >> 2, j & 3
-            consumers.append((8 * sp + 2 * k + 1, I("v_cvt_pk_f16_f32", P[j], x[8 * sp + 2 * k], x[8 * sp + 2 * k + 1])))
+            need = 8 * sp + 2 * k + 1
+            consumers.append((need, I("v_cvt_pk_f16_f32", P[j], x[8 * sp + 2 * k], x[8 * sp + 2 * k + 1])))
+            if self.dot_sum:
+                a_ = acc[n_ & 1]
+                consumers.append((need + 0.5, I("v_dot2_f32_f16", a_, P[j], self.s_ones, 0 if n_ < 2 else a_)))
         consumers.sort(key=lambda c: c[0])
         for i in range(16): f(I("v_fma_f32", x[i], x[i], sc, negm))
         ci = 0
@@ -570,7 +580,7 @@ class Gen:
         add(I("s_lshl_b32", self.s_ld2, self.s_ld, 1)); add(I("s_lshl_b32", self.s_outrow, self.s_H, 7)); add(I("s_mov_b32", self.s_kcol, self.s_outrow))
         for r, base, nbytes in ((self.s_rq, self.s_qkv, self.s_qbytes), (self.s_ro, self.s_out, self.s_obytes)):
             add(I("s_mov_b32", r[0], base[0])); add(I("s_and_b32", r[1], base[1], 0xffff)); add(I("s_mov_b32", r[2], nbytes)); add(I("s_mov_b32", r[3], 0x00020000))
-        add(I("v_mov_b32", self.vNINF, NEG_INF))
+        add(I("v_mov_b32", self.vNINF, NEG_INF)); add(I("s_mov_b32", self.s_ones, 0x3C003C00))
         # K fragment addresses (attention.hip tile_addr<64>): row l31, chunk (2 ks + hi) ^ swz64(l31), swz64(r) = (((r >> 1) & 1) << 2) | ((r >> 2) & 3)
         add(I("v_bfe_u32", X[0], self.vL31, 1, 1)); add(I("v_bfe_u32", X[1], self.vL31, 2, 2)); add(I("v_lshl_or_b32", X[0], X[0], 2, X[1]))
         for ks in range(4):
@@ -705,8 +715,8 @@ class Gen:
         return P
 
 
-def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False):
-    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split)
+def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False, dot_sum=False):
+    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split, dot_sum=dot_sum)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     hdr = ("// GENERATED by csrc/asm/attn_clip_d64.py — do not edit.  Register map:\n" + g.S.listing() + "\n" + g.V.listing() + "\n" + g.A.listing()
@@ -721,7 +731,7 @@ def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False):
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
                 ("dma1", dict(prof=True, dma_steps=1)), ("dma2", dict(prof=True, dma_steps=2)), ("dma5", dict(prof=True, dma_steps=3)),
-                ("dma9", dict(prof=True, dma_steps=9)), ("split", dict(prof=True, solo_split=True))]
+                ("dma9", dict(prof=True, dma_steps=9)), ("split", dict(prof=True, solo_split=True)), ("dotsum", dict(prof=True, dot_sum=True))]
 
 
 def unique_labels(text, suffix):

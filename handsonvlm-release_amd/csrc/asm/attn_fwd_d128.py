@@ -57,18 +57,19 @@ KERNARG_BYTES = 80
 
 
 class Gen:
-    def __init__(self, debug_serial=False, abl=(), prof=False, k_rows=False):
+    def __init__(self, debug_serial=False, abl=(), prof=False, k_rows=True, dot_sum=False):
         """abl: timing-only ablations (WRONG RESULTS): 'nosm' no softmax stream, 'nodma' no LDS-DMA in the loop, 'nolds' no
         fragment reloads, 'nomfma' no MFMAs.  prof: s_memtime cycle sums per workgroup phase through the extra kernel argument."""
         self.debug_serial = debug_serial
         self.abl, self.prof = set(abl), prof
         # k_rows: K tiles keep the row-major XOR-swizzled image of V (DMA lanes fetch whole 256-byte rows) instead of the
         # [half][ks][hi][key] image whose fragment address is base + immediate but whose DMA fetches 32-byte granules of 32 rows per
-        # instruction (the CLIP kernel, which is HBM-bound, measured -14 % with whole rows: profiles/r05f).  Measured HERE
-        # (profiles/r05h_attn_fwd_k_image_ab.txt, same box, same launch): row image 178.2 / 212.7 us, granule image 172.3 / 210.0 us at
-        # S = 867 / 2048 — the decoder kernel is not HBM-bound (K / V of a (b, h) pair are re-read from L2 by its 4-7 workgroups) and the
-        # row image costs 8 address registers + a running soffset: the granule image stays the default, `krows` is the dev variant.
+        # instruction (the CLIP kernel, which is HBM-bound, measured -14 % with whole rows: profiles/r05f).  Measured HERE on a settled chip
+        # (1.5 s loops, time and joules per call, profiles/r05z_attn_variant_energy.txt): row image 163.0-164.6 us / 226-228 mJ against 166.9-167.5 us /
+        # 234-235 mJ for the granule image at S = 867, 201 vs 206 us at S = 2048: the row image is the default (dev variant `kgran` = the granule
+        # image).  A first A/B in 20-launch timing loops (profiles/r05h) had ranked them the other way round: such loops do not settle the chip.
         self.k_rows = k_rows
+        self.dot_sum = dot_sum      # row sum as v_dot2_f32_bf16 over the ROUNDED probability pairs (8 per block instead of 16 v_add_f32 on the fp32 values)
         self.report = []
         self.site = 0
         self.ool = []                     # out-of-line blocks (slow paths), appended behind the main code
@@ -144,6 +145,7 @@ class Gen:
         self.vT = [V.alloc(f"softmax temps qb{q}", 6) for q in range(2)]
         self.vACC = [V.alloc(f"partial sums qb{q}", 4) for q in range(2)]
         self.vNINF = V.alloc("-inf", 1)
+        if dot_sum: self.s_ones = V.alloc("bf16 (1.0, 1.0): operand of the row-sum dot products (a VGPR: the SGPR file is full)", 1)
         self.vLIM = V.alloc("l31 - 4 hi (triangular limit)", 1)
         self.vLIMC = V.alloc("limit in use", 1)
         self.vKADDR = V.alloc("K fragment LDS address (lane*16 + slot)", 1)
@@ -280,14 +282,22 @@ class Gen:
                          I("s_branch", f"L_slowret_{st}", ndef=0)]
         # p = exp2(s * scale - m); row sum; pack to bf16
         consumers = []          # (needs: highest x index, Ins)
-        pairs = [(0, 1), (2, 3), (4, 5), (6, 7)]
-        for k, (a_, b_) in enumerate(pairs): consumers.append((b_, I("v_add_f32", acc[k], x[a_], x[b_])))
-        for i in range(8, 16): consumers.append((i, I("v_add_f32", acc[i & 3], acc[i & 3], x[i])))
-        tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", acc[2], acc[2], acc[3]), I("v_add_f32", acc[0], acc[0], acc[2]),
-                I("v_add_f32", l, l, acc[0])]
-        for j in range(8):
+        if self.dot_sum:
+            tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", l, l, acc[0])]
+        else:
+            pairs = [(0, 1), (2, 3), (4, 5), (6, 7)]
+            for k, (a_, b_) in enumerate(pairs): consumers.append((b_, I("v_add_f32", acc[k], x[a_], x[b_])))
+            for i in range(8, 16): consumers.append((i, I("v_add_f32", acc[i & 3], acc[i & 3], x[i])))
+            tail = [I("v_add_f32", acc[0], acc[0], acc[1]), I("v_add_f32", acc[2], acc[2], acc[3]), I("v_add_f32", acc[0], acc[0], acc[2]),
+                    I("v_add_f32", l, l, acc[0])]
+        order = sorted(range(8), key=lambda j: 8 * (j >> 2) + 2 * (j & 3) + 1)
+        for n_, j in enumerate(order):
             sp, k = j >> 2, j & 3
-            consumers.append((8 * sp + 2 * k + 1, I("v_cvt_pk_bf16_f32", P[j], x[8 * sp + 2 * k], x[8 * sp + 2 * k + 1])))
+            need = 8 * sp + 2 * k + 1
+            consumers.append((need, I("v_cvt_pk_bf16_f32", P[j], x[8 * sp + 2 * k], x[8 * sp + 2 * k + 1])))
+            if self.dot_sum:
+                a_ = acc[n_ & 1]
+                consumers.append((need + 0.5, I("v_dot2_f32_bf16", a_, P[j], self.s_ones, 0 if n_ < 2 else a_)))
         consumers.sort(key=lambda c: c[0])
         for i in range(16): f(I("v_fma_f32", x[i], x[i], sc, negm))
         ci = 0
@@ -540,6 +550,7 @@ class Gen:
         add(I("s_lshl_b32", self.s_ld2, self.s_ld, 1)); add(I("s_lshl_b32", self.s_outrow, self.s_H, 8))
         add(I("s_lshl_b32", self.s_tile, self.s_ld2, 6)); add(I("s_lshl_b32", self.s_r16, self.s_ld2, 4))
         add(I("v_mov_b32", self.vNINF, NEG_INF))
+        if self.dot_sum: add(I("v_mov_b32", self.s_ones, 0x3F803F80))
         add(I("v_lshlrev_b32", X[0], 2, self.vHI)); add(I("v_sub_u32", self.vLIM, self.vL31, X[0]))
         add(I("v_lshlrev_b32", self.vKADDR, 4, self.vLANE))
         if self.k_rows:          # tile_addr<128>(l31, 2 ks + hi) = l31 * 256 + (((2 ks + hi) ^ swz(l31)) << 4), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3)
@@ -821,8 +832,8 @@ class Gen:
         return fix_hazards(out, f"epilogue{qb}", self.report)
 
 
-def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=False):
-    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof, k_rows=k_rows)
+def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=True, dot_sum=False):
+    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof, k_rows=k_rows, dot_sum=dot_sum)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     body = render(items)
@@ -838,7 +849,7 @@ def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=False):
 # development variants (make DEV=1): cycle sums and timing-only ablations (hvlm_attn_fwd_asm_dev)
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
-                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("krows", dict(prof=True, k_rows=True))]
+                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("kgran", dict(prof=True, k_rows=False)), ("dotsum", dict(prof=True, dot_sum=True)), ("kgrandot", dict(prof=True, dot_sum=True, k_rows=False))]
 
 
 def unique_labels(text, suffix):

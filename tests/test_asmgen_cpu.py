@@ -65,6 +65,12 @@ def test_hazard_pass_valu_rules():
     assert _states_between(fix_hazards([m0, dma]), m0, dma) == 1
     rl = I("v_readfirstlane_b32", _s(6), _v(13)); ld = I("buffer_load_dwordx4", _v(16, 4), _v(14), _s(8, 4), _s(6), mods="offen")
     assert _states_between(fix_hazards([rl, ld]), rl, ld) == ag.VSGPR_TO_VMEM == 5
+    # DOT results: accumulation through SrcC of the same opcode is free, a different VALU reading / overwriting the result waits 3 / 4
+    d0 = I("v_dot2_f32_f16", _v(40), _v(41), _s(7), 0); d1 = I("v_dot2_f32_f16", _v(40), _v(42), _s(7), _v(40))
+    rd2 = I("v_add_f32", _v(43), _v(40), _v(44)); ow = I("v_mov_b32", _v(40), 0)
+    assert all(not x.is_nop for x in fix_hazards([d0, d1]))
+    assert _states_between(fix_hazards([d1, rd2]), d1, rd2) == ag.DOT_TO_VALU_READ == 3
+    assert _states_between(fix_hazards([d1, ow]), d1, ow) == ag.DOT_TO_VALU_WRITE == 4
     # unrelated registers: nothing
     assert all(not x.is_nop for x in fix_hazards([w, mfma_bf16(_a(0, 16), _a(80, 4), _a(84, 4), 0), ex, I("v_add_f32", _v(30), _v(31), _v(32))]))
     # `carry`: the tail of a loop body is checked against its own head without being emitted
@@ -158,10 +164,10 @@ def test_decoder_forward_generator_assembles_inside_the_budget(tmp_path):
     # a clean schedule: the hazard pass found nothing to pad inside the two loop bodies
     loop_pads = [n for tag, n in g.report if tag.split("_")[0] in ("step0", "first", "second")]
     assert len(loop_pads) == 6 and max(loop_pads) <= 4, g.report
-    # the alternative K image (dev variant) is a different, valid program
-    text2, g2, _ = gen.generate(k_rows=True)
+    # the alternative K image (the granule image, dev variant `kgran`) is a different, valid program
+    text2, g2, _ = gen.generate(k_rows=False)
     assert text2 != text
-    _check_text(text2); _assemble(text2, tmp_path, "fwd_krows")
+    _check_text(text2); _assemble(text2, tmp_path, "fwd_kgran")
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not installed")

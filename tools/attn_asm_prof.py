@@ -11,7 +11,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "krows"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot"]
 PHASES = ["item start wait", "prologue + step 0", "main loop", "flush + epilogue", "item switch"]
 
 def timeit(fn, n=20):
@@ -44,6 +44,18 @@ for (B, S, H) in shapes:
     for v, name in enumerate(VARIANTS):
         t = timeit(lambda: run(v))
         print(f"   asm {name:12s}      {t:8.1f} us  {fl / t / 1e6:7.0f} TF/s (algorithmic)")
+    # the row-sum variant (v_dot2 over the rounded pairs) against production and against an fp64 reference on a slice
+    hs = min(H, 4)
+    xq = qkv.view(B, S, 3, H, 128)[:, :, :, :hs].double()
+    q_, k_, v_ = xq[:, :, 0].transpose(1, 2), xq[:, :, 1].transpose(1, 2), xq[:, :, 2].transpose(1, 2)
+    sc_ = (q_ @ k_.transpose(-1, -2)) * 128 ** -0.5
+    sc_ = sc_.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+    ref = (torch.softmax(sc_, -1) @ v_).transpose(1, 2)                                   # [B, S, hs, 128]
+    for name in ("production", "dotsum"):
+        run(VARIANTS.index(name)); torch.cuda.synchronize()
+        e = out.view(B, S, H, 128)[:, :, :hs].double() - ref
+        print(f"   error vs fp64 ({name:10s}): mean e {e.mean():+.2e}  mean |e| {e.abs().mean():.3e}  max |e| {e.abs().max():.2e}")
+    del xq, q_, k_, v_, sc_, ref
     prof.zero_(); run(1, prof); torch.cuda.synchronize()
     p = (prof.cpu().numpy().astype("int64") & 0xffffffff).reshape(nwg * 4, 8)
     tot = p[:, :5].sum(1)

@@ -16,12 +16,21 @@ for name, scale in (("randn", 1.0), ("randn x 2 (peaked softmax)", 2.0)):
     ref = (torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1) @ v).transpose(1, 2).reshape(B, 257, H, 64)
     best = ref.to(F16)                                    # the correctly rounded answer
     print(f"== {name}: |O| max {ref.abs().max():.2f}, mean {ref.abs().mean():.3f}")
-    for asm in (0, 1):
-        _lib.configure("attn_clip_asm", asm)
-        o = ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5).view(B, 257, H, 64)
+    lib = _lib.load()
+    dev_variants = [("dotsum", 11)] if lib.hvlm_is_dev_build() else []          # index in attention_asm.hip kClipVariants
+    for asm in [0, 1] + [v for _, v in dev_variants]:
+        if asm in (0, 1):
+            _lib.configure("attn_clip_asm", asm)
+            o = ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5).view(B, 257, H, 64)
+        else:
+            o = torch.empty(B * 257, H * 64, device="cuda", dtype=F16)
+            rc = lib.hvlm_attn_clip_asm_dev(qkv.data_ptr(), o.data_ptr(), None, B, H, qkv.stride(0), 64 ** -0.5, asm, torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            o = o.view(B, 257, H, 64)
         e = o.double() - ref
         rel = e / ref.abs().clamp_min(1e-3)
-        print(f"  {'asm' if asm else 'c++'}: mean e {e.mean():+.2e}  mean |e| {e.abs().mean():.2e}  max |e| {e.abs().max():.2e}  mean rel e {rel.mean():+.2e}  "
+        print(f"  {'c++' if asm == 0 else 'asm' if asm == 1 else 'asm variant %d' % asm}: mean e {e.mean():+.2e}  mean |e| {e.abs().mean():.2e}  max |e| {e.abs().max():.2e}  mean rel e {rel.mean():+.2e}  "
               f"!= correctly rounded: {100.0 * (o != best).double().mean():.1f} %")
         for lab, sl in (("rows 0-127", slice(0, 128)), ("rows 128-255", slice(128, 256)), ("class row 256", slice(256, 257))):
             ee = e[:, sl]
