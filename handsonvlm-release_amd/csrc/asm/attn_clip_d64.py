@@ -56,8 +56,8 @@ def mfma_f16(d, a, b, c):
 
 
 class Gen:
-    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=False, dot_sum=False):
-        self.abl, self.prof, self.dma_steps, self.split, self.dot_sum = set(abl), prof, dma_steps, solo_split, dot_sum
+    def __init__(self, abl=(), prof=False, dma_steps=5, solo_split=False, dot_sum=False, lazy_max=False):
+        self.abl, self.prof, self.dma_steps, self.split, self.dot_sum, self.lazy_max = set(abl), prof, dma_steps, solo_split, dot_sum, lazy_max
         self.report, self.site, self.ool = [], 0, []
         S = self.S = RegFile("s", 0, 102)
         V = self.V = RegFile("v", 0, 256)
@@ -113,6 +113,9 @@ class Gen:
         self.vM = [V.alloc(f"m {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vNEGM = [V.alloc(f"-m {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vMT = [V.alloc(f"m+THR {n}", 1) for n in ("qb0", "qb1", "solo")]
+        if lazy_max:
+            self.vMTR = [V.alloc(f"(m+THR-0.5)/scale {n}: the trigger threshold in raw-score units", 1) for n in ("qb0", "qb1")]
+            self.vRSC = V.alloc("1 / scale_log2", 1)
         self.vL = [V.alloc(f"l {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vALPHA = [V.alloc(f"pending alpha {n}", 1) for n in ("qb0", "qb1", "solo")]
         self.vT = [V.alloc(f"softmax temps {n}", 6) for n in ("qb0", "qb1", "solo")]
@@ -209,19 +212,24 @@ class Gen:
         f(I("v_max3_f32", t[4], x[12], x[13], x[14]))
         f(I("v_max3_f32", t[0], t[0], t[1], t[2])); f(I("v_max3_f32", t[3], t[3], t[4], x[15]))
         f(I("v_max_f32", t[0], t[0], t[3]))
-        f(I("v_mov_b32", t[1], t[0]))
-        f(I("v_permlane32_swap_b32", t[1], t[0], ndef=2))
-        f(I("v_max_f32", t[0], t[0], t[1]))
-        f(I("v_mul_f32", t[0], sc, t[0]))
+        lazy = self.lazy_max and not init
+        full = [I("v_mov_b32", t[1], t[0]), I("v_permlane32_swap_b32", t[1], t[0], ndef=2), I("v_max_f32", t[0], t[0], t[1]), I("v_mul_f32", t[0], sc, t[0])]
+        if not lazy:
+            for ins in full: f(ins)
         if init:
             f(I("v_mov_b32", m, t[0]), I("v_xor_b32", negm, 0x80000000, t[0]), I("v_add_f32", mt, THR_BITS, t[0]))
+            if self.lazy_max: f(I("v_add_f32", t[1], -0.5, mt), I("v_mul_f32", self.vMTR[qb], self.vRSC, t[1]))
         else:
             st = self.new_site()
-            f(I("v_cmp_gt_f32", VCC, t[0], mt), I("s_cbranch_vccnz", f"L_slow_{st}", ndef=0, xuse=[VCC]), Label(f"L_slowret_{st}"))
+            # lazy_max (as attn_fwd_d128.py): the trigger tests the lane's PARTIAL raw maximum against (m + THR - 0.5) / scale; the slow path repeats
+            # the exact per-lane test on the row's full, scaled maximum — results are those of the exact form
+            f(I("v_cmp_gt_f32", VCC, t[0], self.vMTR[qb] if lazy else mt), I("s_cbranch_vccnz", f"L_slow_{st}", ndef=0, xuse=[VCC]), Label(f"L_slowret_{st}"))
             a = t[2]
-            self.ool += [Label(f"L_slow_{st}"), I("v_cndmask_b32", t[1], m, t[0], VCC), I("v_sub_f32", a, m, t[1]), I("v_exp_f32", a, a),
+            self.ool += [Label(f"L_slow_{st}")] + ((full + [I("v_cmp_gt_f32", VCC, t[0], mt)]) if lazy else []) + [
+                         I("v_cndmask_b32", t[1], m, t[0], VCC), I("v_sub_f32", a, m, t[1]), I("v_exp_f32", a, a),
                          I("v_mov_b32", m, t[1]), I("v_xor_b32", negm, 0x80000000, t[1]), I("v_add_f32", mt, THR_BITS, t[1]),
-                         I("v_mul_f32", l, l, a), I("v_mul_f32", self.vALPHA[qb], self.vALPHA[qb], a),
+                         I("v_mul_f32", l, l, a), I("v_mul_f32", self.vALPHA[qb], self.vALPHA[qb], a)] + (
+                         [I("v_add_f32", t[1], -0.5, mt), I("v_mul_f32", self.vMTR[qb], self.vRSC, t[1])] if lazy else []) + [
                          I("s_bitset1_b32", self.s_pend, qb, rw=True), I("s_branch", f"L_slowret_{st}", ndef=0)]
         consumers = []
         if self.dot_sum:
@@ -581,6 +589,7 @@ class Gen:
         for r, base, nbytes in ((self.s_rq, self.s_qkv, self.s_qbytes), (self.s_ro, self.s_out, self.s_obytes)):
             add(I("s_mov_b32", r[0], base[0])); add(I("s_and_b32", r[1], base[1], 0xffff)); add(I("s_mov_b32", r[2], nbytes)); add(I("s_mov_b32", r[3], 0x00020000))
         add(I("v_mov_b32", self.vNINF, NEG_INF)); add(I("s_mov_b32", self.s_ones, 0x3C003C00))
+        if self.lazy_max: add(I("v_rcp_f32", self.vRSC, self.s_scale))
         # K fragment addresses (attention.hip tile_addr<64>): row l31, chunk (2 ks + hi) ^ swz64(l31), swz64(r) = (((r >> 1) & 1) << 2) | ((r >> 2) & 3)
         add(I("v_bfe_u32", X[0], self.vL31, 1, 1)); add(I("v_bfe_u32", X[1], self.vL31, 2, 2)); add(I("v_lshl_or_b32", X[0], X[0], 2, X[1]))
         for ks in range(4):
@@ -715,8 +724,8 @@ class Gen:
         return P
 
 
-def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False, dot_sum=False):
-    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split, dot_sum=dot_sum)
+def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False, dot_sum=False, lazy_max=False):
+    g = Gen(abl=abl, prof=prof, dma_steps=dma_steps, solo_split=solo_split, dot_sum=dot_sum, lazy_max=lazy_max)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     hdr = ("// GENERATED by csrc/asm/attn_clip_d64.py — do not edit.  Register map:\n" + g.S.listing() + "\n" + g.V.listing() + "\n" + g.A.listing()
@@ -731,7 +740,7 @@ def generate(abl=(), prof=False, name=KNAME, dma_steps=5, solo_split=False, dot_
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
                 ("dma1", dict(prof=True, dma_steps=1)), ("dma2", dict(prof=True, dma_steps=2)), ("dma5", dict(prof=True, dma_steps=3)),
-                ("dma9", dict(prof=True, dma_steps=9)), ("split", dict(prof=True, solo_split=True)), ("dotsum", dict(prof=True, dot_sum=True))]
+                ("dma9", dict(prof=True, dma_steps=9)), ("split", dict(prof=True, solo_split=True)), ("dotsum", dict(prof=True, dot_sum=True)), ("lazymax", dict(prof=True, lazy_max=True))]
 
 
 def unique_labels(text, suffix):

@@ -57,7 +57,7 @@ KERNARG_BYTES = 80
 
 
 class Gen:
-    def __init__(self, debug_serial=False, abl=(), prof=False, k_rows=True, dot_sum=False):
+    def __init__(self, debug_serial=False, abl=(), prof=False, k_rows=True, dot_sum=False, lazy_max=False):
         """abl: timing-only ablations (WRONG RESULTS): 'nosm' no softmax stream, 'nodma' no LDS-DMA in the loop, 'nolds' no
         fragment reloads, 'nomfma' no MFMAs.  prof: s_memtime cycle sums per workgroup phase through the extra kernel argument."""
         self.debug_serial = debug_serial
@@ -69,6 +69,7 @@ class Gen:
         # 234-235 mJ for the granule image at S = 867, 201 vs 206 us at S = 2048: the row image is the default (dev variant `kgran` = the granule
         # image).  A first A/B in 20-launch timing loops (profiles/r05h) had ranked them the other way round: such loops do not settle the chip.
         self.k_rows = k_rows
+        self.lazy_max = lazy_max    # slow-path trigger on the lane's PARTIAL step maximum in raw-score units: no half-wave exchange, no scaling on the fast path
         self.dot_sum = dot_sum      # row sum as v_dot2_f32_bf16 over the ROUNDED probability pairs (8 per block instead of 16 v_add_f32 on the fp32 values)
         self.report = []
         self.site = 0
@@ -140,6 +141,9 @@ class Gen:
         self.vM = [V.alloc(f"m qb{q}", 1) for q in range(2)]
         self.vNEGM = [V.alloc(f"-m qb{q}", 1) for q in range(2)]
         self.vMT = [V.alloc(f"m+THR qb{q}", 1) for q in range(2)]
+        if lazy_max:
+            self.vMTR = [V.alloc(f"(m+THR-0.5)/scale qb{q}: the trigger threshold in raw-score units", 1) for q in range(2)]
+            self.s_rsc = V.alloc("1 / scale_log2 (a VGPR: the SGPR file is full)", 1)
         self.vL = [V.alloc(f"l qb{q}", 1) for q in range(2)]
         self.vALPHA = [V.alloc(f"pending alpha qb{q}", 1) for q in range(2)]
         self.vT = [V.alloc(f"softmax temps qb{q}", 6) for q in range(2)]
@@ -257,19 +261,29 @@ class Gen:
         f(I("v_max3_f32", t[4], x[12], x[13], x[14]))
         f(I("v_max3_f32", t[0], t[0], t[1], t[2])); f(I("v_max3_f32", t[3], t[3], t[4], x[15]))
         f(I("v_max_f32", t[0], t[0], t[3]))
-        f(I("v_mov_b32", t[1], t[0]))
-        # (the hazard pass pads VALU -> permlane; with two qb chains interleaved the other chain's instructions sit in between)
-        f(I("v_permlane32_swap_b32", t[1], t[0], ndef=2))
-        f(I("v_max_f32", t[0], t[0], t[1]))
-        f(I("v_mul_f32", t[0], sc, t[0]))                                   # the step's maximum, log2 domain
+        lazy = self.lazy_max and not init
+        full = [I("v_mov_b32", t[1], t[0]),
+                # (the hazard pass pads VALU -> permlane; with two qb chains interleaved the other chain's instructions sit in between)
+                I("v_permlane32_swap_b32", t[1], t[0], ndef=2),
+                I("v_max_f32", t[0], t[0], t[1]),
+                I("v_mul_f32", t[0], sc, t[0])]                                 # the step's maximum, log2 domain
+        if not lazy:
+            for ins in full: f(ins)
         if init:
             f(I("v_mov_b32", m, t[0]), I("v_xor_b32", negm, 0x80000000, t[0]), I("v_add_f32", mt, THR_BITS, t[0]))
+            if self.lazy_max: f(I("v_add_f32", t[1], -0.5, mt), I("v_mul_f32", self.vMTR[qb], self.s_rsc, t[1]))
         else:
             st = self.new_site()
-            f(I("v_cmp_gt_f32", VCC, t[0], mt), I("s_cbranch_vccnz", f"L_slow_{st}", ndef=0, xuse=[VCC]), Label(f"L_slowret_{st}"))
+            if lazy:
+                # trigger: the lane's PARTIAL maximum (its half of the row's keys), raw, against (m + THR - 0.5) / scale — fires whenever the exact
+                # test below could (0.5 in the log2 domain covers the rounding of the two forms by orders of magnitude); a spurious trigger changes
+                # nothing: the slow path repeats the exact per-lane test on the row's full maximum
+                f(I("v_cmp_gt_f32", VCC, t[0], self.vMTR[qb]), I("s_cbranch_vccnz", f"L_slow_{st}", ndef=0, xuse=[VCC]), Label(f"L_slowret_{st}"))
+            else:
+                f(I("v_cmp_gt_f32", VCC, t[0], mt), I("s_cbranch_vccnz", f"L_slow_{st}", ndef=0, xuse=[VCC]), Label(f"L_slowret_{st}"))
             # slow path: lanes whose step maximum exceeds m + THR take it as the new m; l is rescaled now, O at the next step boundary
             a = t[2]
-            self.ool += [Label(f"L_slow_{st}"),
+            self.ool += [Label(f"L_slow_{st}")] + ((full + [I("v_cmp_gt_f32", VCC, t[0], mt)]) if lazy else []) + [
                          I("v_cndmask_b32", t[1], m, t[0], VCC),                    # m_new = vcc ? ms : m
                          I("v_sub_f32", a, m, t[1]),
                          I("v_exp_f32", a, a),
@@ -277,7 +291,7 @@ class Gen:
                          I("v_xor_b32", negm, 0x80000000, t[1]),
                          I("v_add_f32", mt, THR_BITS, t[1]),
                          I("v_mul_f32", l, l, a),
-                         I("v_mul_f32", self.vALPHA[qb], self.vALPHA[qb], a),
+                         I("v_mul_f32", self.vALPHA[qb], self.vALPHA[qb], a)] + ([I("v_add_f32", t[1], -0.5, mt), I("v_mul_f32", self.vMTR[qb], self.s_rsc, t[1])] if lazy else []) + [
                          I("s_bitset1_b32", self.s_pend, qb, rw=True),
                          I("s_branch", f"L_slowret_{st}", ndef=0)]
         # p = exp2(s * scale - m); row sum; pack to bf16
@@ -545,6 +559,8 @@ class Gen:
         add(s_nop(0))
         add(I("v_readfirstlane_b32", self.s_w, X[0]))
         add(s_waitcnt(lgkm=0))
+        if self.lazy_max:                          # 1 / scale_log2 (the arguments have landed)
+            add(I("v_rcp_f32", self.s_rsc, self.s_scale))
         if self.prof:
             add(I("s_memtime", self.s_tm)); add(s_waitcnt(lgkm=0)); add(I("s_mov_b32", self.s_t0, self.s_tm[0]))
         add(I("s_lshl_b32", self.s_ld2, self.s_ld, 1)); add(I("s_lshl_b32", self.s_outrow, self.s_H, 8))
@@ -832,8 +848,8 @@ class Gen:
         return fix_hazards(out, f"epilogue{qb}", self.report)
 
 
-def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=True, dot_sum=False):
-    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof, k_rows=k_rows, dot_sum=dot_sum)
+def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=True, dot_sum=False, lazy_max=False):
+    g = Gen(debug_serial=debug_serial, abl=abl, prof=prof, k_rows=k_rows, dot_sum=dot_sum, lazy_max=lazy_max)
     prog = g.build()
     items = fix_hazards(prog.items, "whole", g.report)
     body = render(items)
@@ -849,7 +865,7 @@ def generate(debug_serial=False, abl=(), prof=False, name=KNAME, k_rows=True, do
 # development variants (make DEV=1): cycle sums and timing-only ablations (hvlm_attn_fwd_asm_dev)
 DEV_VARIANTS = [("prof", dict(prof=True)), ("nosm", dict(prof=True, abl=("nosm",))), ("nodma", dict(prof=True, abl=("nodma",))),
                 ("nolds", dict(prof=True, abl=("nolds",))), ("nomfma", dict(prof=True, abl=("nomfma",))),
-                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("kgran", dict(prof=True, k_rows=False)), ("dotsum", dict(prof=True, dot_sum=True)), ("kgrandot", dict(prof=True, dot_sum=True, k_rows=False))]
+                ("mfmaonly", dict(prof=True, abl=("nosm", "nodma", "nolds"))), ("kgran", dict(prof=True, k_rows=False)), ("dotsum", dict(prof=True, dot_sum=True)), ("kgrandot", dict(prof=True, dot_sum=True, k_rows=False)), ("lazymax", dict(prof=True, lazy_max=True))]
 
 
 def unique_labels(text, suffix):

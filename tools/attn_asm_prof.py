@@ -11,7 +11,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot", "lazymax"]
 PHASES = ["item start wait", "prologue + step 0", "main loop", "flush + epilogue", "item switch"]
 
 def timeit(fn, n=20):

@@ -10,8 +10,8 @@ import bench
 lib = _lib.load()
 assert lib.hvlm_is_dev_build(), "development library needed (HVLM_LIB)"
 ec = bench.EnergyCounter(0)
-FWD = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot"]
-CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum"]
+FWD = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot", "lazymax"]
+CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "lazymax"]
 st = torch.cuda.current_stream().cuda_stream
 
 def measure(label, fn, seconds=1.5):
@@ -35,10 +35,19 @@ for rep in range(2):
         lse = torch.empty(B, H, S, device="cuda", dtype=torch.float32)
         ws = torch.zeros(1024, device="cuda", dtype=torch.uint8)
         print(f"== decoder forward B={B} S={S} H={H} (pass {rep})")
+        if rep == 0:
+            for spike in (False, True):
+                qq = qkv.clone()
+                if spike: qq.view(B, S, 3, H, 128)[:, S // 2::97, 1] *= 6.0           # late large keys: the deferred-maximum slow path
+                o2, l2 = torch.empty_like(out), torch.empty_like(lse)
+                lib.hvlm_attn_fwd_asm_dev(qq.data_ptr(), out.data_ptr(), lse.data_ptr(), ws.data_ptr(), None, B, S, H, qq.stride(0), 128 ** -0.5, FWD.index("production"), st)
+                lib.hvlm_attn_fwd_asm_dev(qq.data_ptr(), o2.data_ptr(), l2.data_ptr(), ws.data_ptr(), None, B, S, H, qq.stride(0), 128 ** -0.5, FWD.index("lazymax"), st)
+                torch.cuda.synchronize()
+                print(f"   lazymax == production bit for bit (spike={int(spike)}): O {torch.equal(out, o2)}, lse {torch.equal(lse, l2)}", flush=True)
         _lib.configure("attn_fwd_asm", 0)
         measure("c++ kernel", lambda: ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5))
         _lib.configure("attn_fwd_asm", 1)
-        for name in ("production", "kgran", "dotsum", "kgrandot"):
+        for name in ("production", "lazymax", "kgran", "dotsum"):
             v = FWD.index(name)
             measure("asm " + name, lambda: lib.hvlm_attn_fwd_asm_dev(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), ws.data_ptr(), None, B, S, H, qkv.stride(0), 128 ** -0.5, v, st))
         del qkv, out, lse
@@ -46,10 +55,19 @@ for rep in range(2):
     qkv = torch.randn(B * 257, 3 * H * 64, device="cuda").to(torch.float16)
     out = torch.empty(B * 257, H * 64, device="cuda", dtype=torch.float16)
     print(f"== CLIP attention 1600 x 16 (pass {rep})")
+    if rep == 0:
+        for spike in (False, True):
+            qq = qkv.clone()
+            if spike: qq.view(B, 257, 3, H, 64)[:, 70::61, 1] *= 5.0
+            o2 = torch.empty_like(out)
+            lib.hvlm_attn_clip_asm_dev(qq.data_ptr(), out.data_ptr(), None, B, H, qq.stride(0), 64 ** -0.5, CLIP.index("production"), st)
+            lib.hvlm_attn_clip_asm_dev(qq.data_ptr(), o2.data_ptr(), None, B, H, qq.stride(0), 64 ** -0.5, CLIP.index("lazymax"), st)
+            torch.cuda.synchronize()
+            print(f"   lazymax == production bit for bit (spike={int(spike)}): O {torch.equal(out, o2)}  finite {bool(torch.isfinite(o2.float()).all())}", flush=True)
     _lib.configure("attn_clip_asm", 0)
     measure("c++ resident kernel", lambda: ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5))
     _lib.configure("attn_clip_asm", 1)
-    for name in ("production", "dotsum", "split"):
+    for name in ("production", "lazymax", "dotsum", "split"):
         v = CLIP.index(name)
         measure("asm " + name, lambda: lib.hvlm_attn_clip_asm_dev(qkv.data_ptr(), out.data_ptr(), None, B, H, qkv.stride(0), 64 ** -0.5, v, st))
     del qkv, out
