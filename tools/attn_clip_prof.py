@@ -10,7 +10,7 @@ import torch
 import numpy as np
 from hvlm import ops, _lib
 lib = _lib.load()
-VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "lazymax"]
+VARIANTS = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "eagermax"]
 def timeit(fn, n=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()

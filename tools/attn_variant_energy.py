@@ -11,7 +11,7 @@ lib = _lib.load()
 assert lib.hvlm_is_dev_build(), "development library needed (HVLM_LIB)"
 ec = bench.EnergyCounter(0)
 FWD = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "mfmaonly", "kgran", "dotsum", "kgrandot", "lazymax"]
-CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "lazymax"]
+CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "eagermax"]
 st = torch.cuda.current_stream().cuda_stream
 
 def measure(label, fn, seconds=1.5):
@@ -61,13 +61,13 @@ for rep in range(2):
             if spike: qq.view(B, 257, 3, H, 64)[:, 70::61, 1] *= 5.0
             o2 = torch.empty_like(out)
             lib.hvlm_attn_clip_asm_dev(qq.data_ptr(), out.data_ptr(), None, B, H, qq.stride(0), 64 ** -0.5, CLIP.index("production"), st)
-            lib.hvlm_attn_clip_asm_dev(qq.data_ptr(), o2.data_ptr(), None, B, H, qq.stride(0), 64 ** -0.5, CLIP.index("lazymax"), st)
+            lib.hvlm_attn_clip_asm_dev(qq.data_ptr(), o2.data_ptr(), None, B, H, qq.stride(0), 64 ** -0.5, CLIP.index("eagermax"), st)
             torch.cuda.synchronize()
-            print(f"   lazymax == production bit for bit (spike={int(spike)}): O {torch.equal(out, o2)}  finite {bool(torch.isfinite(o2.float()).all())}", flush=True)
+            print(f"   eagermax == production bit for bit (spike={int(spike)}): O {torch.equal(out, o2)}  finite {bool(torch.isfinite(o2.float()).all())}", flush=True)
     _lib.configure("attn_clip_asm", 0)
     measure("c++ resident kernel", lambda: ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5))
     _lib.configure("attn_clip_asm", 1)
-    for name in ("production", "lazymax", "dotsum", "split"):
+    for name in ("production", "eagermax", "dotsum", "split"):
         v = CLIP.index(name)
         measure("asm " + name, lambda: lib.hvlm_attn_clip_asm_dev(qkv.data_ptr(), out.data_ptr(), None, B, H, qkv.stride(0), 64 ** -0.5, v, st))
     del qkv, out

@@ -8,7 +8,7 @@ from hvlm import _lib
 import bench
 lib = _lib.load(); assert lib.hvlm_is_dev_build()
 ec = bench.EnergyCounter(0)
-CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "lazymax"]
+CLIP = ["production", "prof", "nosm", "nodma", "nolds", "nomfma", "dma1", "dma2", "dma5", "dma9", "split", "dotsum", "eagermax"]
 st = torch.cuda.current_stream().cuda_stream
 B, H = 1600, 16
 qkv = torch.randn(B * 257, 3 * H * 64, device="cuda").to(torch.float16)
