@@ -83,6 +83,14 @@ def test_g_13b_L40_S2048_forward_backward_vs_oracle():
     torch.cuda.synchronize()
     hip.update(_hip_grads(m, cfg, bt))
     del out
+    # the INFERENCE-mode forward on the same weights and batch (no saved activations, the evaluation path: what round 4's test_d ran with its own two oracle
+    # passes — 114 s of the suite for the same references)
+    m.training = False
+    with torch.no_grad():
+        out = _hip_pass(m, bt, output_hidden_states=True)
+    inf = {"loss": float(out.loss), "hidden": out.hidden_states[-1].float().cpu(), "logits_slice": out.logits.float().cpu()[:, ::7, ::251].clone()}
+    m.training = True
+    del out
     ref = _oracle_pass(m, cfg, clip_np, bt, torch.float32, torch.float32, backward=True)
     env = _oracle_pass(m, cfg, clip_np, bt, BF, torch.float16, backward=True)
     keys = ("hidden", "logits_slice") + GRAD_KEYS
@@ -90,13 +98,19 @@ def test_g_13b_L40_S2048_forward_backward_vs_oracle():
          "loss_rel": abs(hip["loss"] - ref["loss"]) / abs(ref["loss"]), "loss_rel_bf16_eager": abs(env["loss"] - ref["loss"]) / abs(ref["loss"]),
          "hip_vs_fp32_oracle": {k: rel(hip[k], ref[k]) for k in keys},
          "bf16_eager_oracle_vs_fp32_oracle": {k: rel(env[k], ref[k]) for k in keys},
-         "oracle_wall_s": {"fp32": ref["wall_s"], "bf16_eager": env["wall_s"]}}
+         "oracle_wall_s": {"fp32": ref["wall_s"], "bf16_eager": env["wall_s"]},
+         "inference_forward": {"loss_rel": abs(inf["loss"] - ref["loss"]) / abs(ref["loss"]),
+                               "hidden": rel(inf["hidden"], ref["hidden"]), "logits_slice": rel(inf["logits_slice"], ref["logits_slice"])}}
     REPORT["g_13b_L40_S2048_fwd_bwd"] = r
     print(json.dumps(r, indent=1))
     _write()
     del m, ref, env
     gc.collect(); torch.cuda.empty_cache()
     _envelope_asserts(r, keys, cap=1.0e-1)          # (L = 40, S = 2048: the bf16-eager oracle itself is 5.8e-2 from fp32 on the hidden state)
+    fi = r["inference_forward"]                     # (the assertions of round 4's test_d, on the same references)
+    assert fi["loss_rel"] <= max(1.25 * r["loss_rel_bf16_eager"], 2e-3), fi
+    for k in ("hidden", "logits_slice"):
+        assert fi[k] <= 1.25 * r["bf16_eager_oracle_vs_fp32_oracle"][k] + 1e-3 and fi[k] < 8e-2, (k, fi, r["bf16_eager_oracle_vs_fp32_oracle"][k])
 
 
 def test_h_7b_L32_ragged_batch_padded_and_packed_vs_oracle():
