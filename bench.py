@@ -428,6 +428,91 @@ def cpu_baseline(cfg, T, budget_s=60.0):
             "wall_s": time.perf_counter() - t_start}
 
 
+def eval_cpu_baseline(cfg, T, n_new=12):
+    """BASELINE config 1 (`handsonvlm.evaluation.evaluate` on CPU eager, Vicuna-7B, batch 1: handsonvlm/evaluation/evaluate.py:18-26
+    -> handsonvlm_inference.py:99-109): the CPU oracle (oracle/ref_cpu.py, kind "port"), FORWARD only, on this host's cores, on a bounded
+    sample scaled to one evaluation sample (CLIP on all frames + a T-token prompt + `n_new` generated tokens), two recipes:
+      reference   — what the reference's generate() does with use_cache=False: every generated token re-runs the CLIP tower on the
+                    100 frames and the full-sequence decoder + lm_head:  n_new x (CLIP + L layers at S rows + lm_head at S rows);
+      kv_cached   — the same port with a KV cache (this build's recipe): CLIP + prefill once, then n_new - 1 one-row steps
+                    (L layers + lm_head on 1 row; the cached K / V reads are not counted — flatters the CPU).
+    Timed pieces (1 warm-up + median of 3 each, fp32 and bf16): one decoder layer forward at S rows, the same layer on 1 row, lm_head
+    at S rows and at 1 row, one CLIP layer on 10 frames.  Splice / pooling / CVAE head / sampling are not counted."""
+    from oracle import ref_cpu as R
+    t_start = time.perf_counter()
+    D, F, H, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+    v = cfg.vision
+    S = T + cfg.num_frames + v.num_patches - 1
+    phys = _physical_cores()
+    cands = sorted({c for c in (phys, max(1, phys // 2), 64, 32) if 1 <= c <= (os.cpu_count() or 1)})
+    g = torch.Generator().manual_seed(1)
+    pa, pb = torch.randn(S, D, generator=g), torch.randn(F, D, generator=g)
+    best, probe = None, {}
+    for c in cands:
+        torch.set_num_threads(c)
+        (pa @ pb.t()).sum()
+        t0 = time.perf_counter(); (pa @ pb.t()).sum(); probe[c] = time.perf_counter() - t0
+        if best is None or probe[c] < probe[best]:
+            best = c
+    torch.set_num_threads(best)
+
+    def med3(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    d, m = v.hidden_size, v.intermediate_size
+    n_clip_layers = v.num_hidden_layers + 1 + cfg.mm_vision_select_layer
+    out = {}
+    with torch.no_grad():
+        for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            p, pre = {}, "l."
+            for n, shp in {"self_attn.q_proj": (D, D), "self_attn.k_proj": (D, D), "self_attn.v_proj": (D, D),
+                           "self_attn.o_proj": (D, D), "mlp.gate_proj": (F, D), "mlp.up_proj": (F, D), "mlp.down_proj": (D, F)}.items():
+                p[pre + n + ".weight"] = (torch.randn(*shp, generator=g) * 0.02).to(dt)
+            p[pre + "input_layernorm.weight"] = torch.ones(D, dtype=dt)
+            p[pre + "post_attention_layernorm.weight"] = torch.ones(D, dtype=dt)
+            x = torch.randn(1, S, D, generator=g).to(dt)
+            cos, sin = R.rope_tables(D // H, S)
+            cos, sin = cos.to(dt), sin.to(dt)
+            wl = (torch.randn(cfg.vocab_size, D, generator=g) * 0.02).to(dt)
+            cp, cpre = {}, "c."
+            for n, shp in {"self_attn.q_proj": (d, d), "self_attn.k_proj": (d, d), "self_attn.v_proj": (d, d),
+                           "self_attn.out_proj": (d, d), "mlp.fc1": (m, d), "mlp.fc2": (d, m)}.items():
+                cp[cpre + n + ".weight"] = (torch.randn(*shp, generator=g) * 0.02).to(dt)
+                cp[cpre + n + ".bias"] = torch.zeros(shp[0], dtype=dt)
+            for n in ("layer_norm1", "layer_norm2"):
+                cp[cpre + n + ".weight"] = torch.ones(d, dtype=dt); cp[cpre + n + ".bias"] = torch.zeros(d, dtype=dt)
+            xc = torch.randn(10, v.num_patches + 1, d, generator=g).to(dt)
+            t_layer = med3(lambda: R.llama_layer(x, p, pre, H, cos, sin, 1e-6))
+            t_layer1 = med3(lambda: R.llama_layer(x[:, :1], p, pre, H, cos[:1], sin[:1], 1e-6))
+            t_head = med3(lambda: x[0] @ wl.t())
+            t_head1 = med3(lambda: x[0, :1] @ wl.t())
+            t_clip10 = med3(lambda: R.clip_layer(xc, cp, cpre, v.num_attention_heads))
+            t_clip = n_clip_layers * (cfg.num_frames / 10.0) * t_clip10
+            t_prefill = L * t_layer + t_head
+            ref = n_new * (t_clip + t_prefill)
+            kvc = t_clip + t_prefill + (n_new - 1) * (L * t_layer1 + t_head1)
+            out[name] = {"reference_recipe_samples_per_s": 1.0 / ref, "kv_cached_samples_per_s": 1.0 / kvc,
+                         "reference_recipe_s_per_sample": ref, "kv_cached_s_per_sample": kvc,
+                         "layer_fwd_S_rows_s": t_layer, "layer_fwd_1_row_s": t_layer1, "lm_head_S_rows_s": t_head,
+                         "lm_head_1_row_s": t_head1, "clip_layer_10_frames_s": t_clip10}
+            del p, wl, cp
+    f32 = out["fp32"]
+    return {"value": f32["reference_recipe_samples_per_s"], "unit": "samples/s", "cores": best, "kind": "port",
+            "recipe": "reference (use_cache=False: CLIP + full-sequence forward per generated token)",
+            "kv_cached": {"value": f32["kv_cached_samples_per_s"], "unit": "samples/s"},
+            "sample": (f"oracle/ref_cpu.py eager fp32 forward, torch {best} threads (fastest of {cands}; host has {os.cpu_count()} hardware threads, "
+                       f"{phys} physical cores), 1 warm-up + median of 3 per piece: 1 decoder layer at D={D},S={S},B=1 ({f32['layer_fwd_S_rows_s']:.3f}s) x{L} "
+                       f"+ lm_head at S rows ({f32['lm_head_S_rows_s']:.3f}s) + 1 CLIP layer on 10 frames of {v.num_patches + 1} tokens "
+                       f"({f32['clip_layer_10_frames_s']:.3f}s) x{n_clip_layers} layers x{cfg.num_frames // 10}, all x{n_new} generated tokens "
+                       f"(reference recipe); kv_cached: that once + {n_new - 1} x (1-row layer {f32['layer_fwd_1_row_s'] * 1e3:.1f} ms x{L} + 1-row lm_head); "
+                       "splice / pooling / CVAE head / sampling not counted"),
+            "fp32": f32, "bf16": out["bf16"], "new_tokens": n_new, "seq_len": S, "wall_s": time.perf_counter() - t_start}
+
+
 def eval_roofline(model, cfg, T, device):
     """The two bounds of the batch-1 inference path (BASELINE config 2), event-timed on the decoder stack alone:
     prefill = the S-row forward of all layers against the bf16 MFMA peak (algorithmic FLOPs, causal attention at half);
@@ -612,6 +697,11 @@ def eval_only_main(args, real_stdout):
     cfg = make_config(args)
     model = HandsOnVLMForCausalLM(cfg, device=device, training=False).init_random(seed=0)
     ev = eval_leg(model, cfg, args.text_len, device, batched=False)
+    if not args.no_cpu_baseline:
+        try:                                    # (after the GPU legs of this process, never beside them)
+            ev["cpu_baseline"] = eval_cpu_baseline(cfg, args.text_len, n_new=ev["new_tokens"])
+        except Exception as ex:  # noqa
+            ev["cpu_baseline"] = {"error": str(ex)[:200]}
     S = args.text_len + cfg.num_frames + (cfg.vision.image_size // cfg.vision.patch_size) ** 2 - 1
     res = {"metric": "eval samples/sec HandsOnVLM-7B (batch 1, KV cache)", "value": ev["samples_per_s"], "unit": "samples/s", "n_gpus": 1,
            "steps": 3, "warmup": 1, "ms_per_step": ev["ms_per_sample"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -657,6 +747,8 @@ def other_configs(args):
             c = json.loads(lines[-1])
             keep = {k: c[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "peak_mem_gib",
                                       "model_tflops_per_gpu", "mfma_roofline_frac_whole_step", "loss", "roofline", "h2d") if k in c}
+            if isinstance(c.get("eval"), dict) and "cpu_baseline" in c["eval"]:
+                keep["cpu_baseline"] = c["eval"]["cpu_baseline"]
             keep["workload"] = c["config"]["workload"]
             keep["seq_len"] = c["config"]["seq_len"]
             keep["global_batch"] = c["config"]["global_batch"]
@@ -958,7 +1050,7 @@ def main():
         waits = feed.collect_wait_ms()
         h2d = {"steps": n_h2d, "ms_per_step": 1e3 * th / n_h2d, "samples_per_s": B * n_h2d / th,
                "h2d_ms_exposed": float(np.mean(waits[2:])) if len(waits) > 2 else None,
-               "bytes_per_step": int(feed.bytes_last), "tiling_detected": bool(cfg.dedup_frames),
+               "bytes_per_step": int(feed.bytes_last), "tiling_detected": bool(feed.tiled_last),
                "gpu_ms_per_step": float(np.mean([m[i].elapsed_time(m[i + 1]) for i in range(2, len(m) - 1)])),
                "note": "the trainer's input path: a CPU batch per step (pageable, as a DataLoader hands it over) -> pinned staging -> "
                        "copy stream, batch i + 1 uploaded while step i computes; h2d_ms_exposed = compute-stream time spent waiting for "
@@ -1129,6 +1221,11 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(cfg, T)
             except Exception as ex:  # noqa
                 res["cpu_baseline"] = {"error": str(ex)[:200]}
+            if isinstance(res.get("eval"), dict) and "error" not in res["eval"]:
+                try:                            # BASELINE config 1: the CPU-eager evaluation beside `eval.samples_per_s`
+                    res["eval"]["cpu_baseline"] = eval_cpu_baseline(cfg, T, n_new=res["eval"]["new_tokens"])
+                except Exception as ex:  # noqa
+                    res["eval"]["cpu_baseline"] = {"error": str(ex)[:200]}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if torch.distributed.is_initialized():

@@ -37,6 +37,8 @@ int attn_fwd_d128_causal_asm(const bf16_t* qkv, bf16_t* out, float* lse, void* w
                              const int32_t* cu, hipStream_t st, int variant = 0, void* prof = nullptr);
 int attn_fwd_clip_s257_asm(const bf16_t* qkv, bf16_t* out, int B, int H, int ld, float scale_log2, hipStream_t st, int variant = 0,
                            void* prof = nullptr);
+bool attn_fwd_d128_causal_asm_ok(const void* ws, int B, int S_max, int H);   // preconditions of the two assembly kernels: a call
+bool attn_fwd_clip_s257_asm_ok(int B, int H, int ld);                        // that does not meet them runs on the C++ kernel below
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1799,7 +1801,9 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
       const int nitems = B * H;
       if constexpr (F16) {
         // CLIP ViT-L/14 at 224 px, the tower's own dtype: the hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_clip_d64.py)
-        if (S == 257 && !lse && config().attn_clip_asm) return attn_fwd_clip_s257_asm(qkv, out, B, H, ld, scale * LOG2E, st);
+        // (calls beyond its 32-bit byte offsets, or a module that did not load, fall through to the C++ kernel)
+        if (S == 257 && !lse && config().attn_clip_asm && attn_fwd_clip_s257_asm_ok(B, H, ld))
+          return attn_fwd_clip_s257_asm(qkv, out, B, H, ld, scale * LOG2E, st);
       }
       if (S == 257) {                          // CLIP ViT-L/14 at 224 px: the unrolled, LDS-latency-pipelined schedule
         rc = set_lds(attn_fwd_resident_kernel<DH, F16, 257>, lds, "attn_fwd_resident");
@@ -1815,8 +1819,11 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   }
   if constexpr (DH == 128 && CAUSAL && !F16) {
     // the decoder's forward: hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_fwd_d128.py, attention_asm.hip)
-    // (its work-queue counters live in `ws`: a caller that sized / aligned the workspace for an older library gets the C++ kernel)
-    if (config().attn_fwd_asm && ws && !((uintptr_t)ws & 63)) return attn_fwd_d128_causal_asm(qkv, out, lse, ws, B, S, H, ld, scale * LOG2E, cu, st);
+    // Its eight work-queue counters live in `ws` (hvlm.h: >= hvlm_attn_fwd_ws_bytes() = 512 bytes, 64-byte aligned — the size is
+    // the caller's contract, only the alignment can be checked here).  A null / misaligned workspace, a module that did not
+    // load, or >= 2^24 work items run on the C++ kernel below, which needs none of it.
+    if (config().attn_fwd_asm && attn_fwd_d128_causal_asm_ok(ws, B, S, H))
+      return attn_fwd_d128_causal_asm(qkv, out, lse, ws, B, S, H, ld, scale * LOG2E, cu, st);
   }
   constexpr int LDS = 2 * 2 * 64 * DH * 2;   // (no V^T pre-pass: `ws` is unused, kept in the signature for ABI stability)
   // (96-row workgroups — whichever of 128 / 96 wastes fewer query rows, S = 257 -> 96 — measured slower in situ, 649 vs 593 us

@@ -110,6 +110,7 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::atomic<hvlm_handle*> g_handles[kMaxDevices];      // the one table of mutable library state: device -> its handle
 }  // namespace
+int attn_asm_preload(int dev);    // attention_asm.hip
 void* pp_sched_ws() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
@@ -133,6 +134,9 @@ extern "C" int hvlm_create(int device, void* sched_ws, size_t sched_ws_bytes, vo
       return HVLM_ERR_LAUNCH;
     }
   }
+  // the embedded assembly code objects are loaded here, not at their first launch (which may sit inside a hipGraph capture);
+  // a load failure is not an error of create: attention.hip then dispatches the C++ kernels
+  (void)hvlm::attn_asm_preload(device);
   hvlm_handle* h = new hvlm_handle{device, sched_ws};
   hvlm_handle* expected = nullptr;
   if (!hvlm::g_handles[device].compare_exchange_strong(expected, h, std::memory_order_acq_rel)) {

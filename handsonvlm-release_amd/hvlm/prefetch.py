@@ -55,6 +55,7 @@ class DevicePrefetcher:
         self._consumed = [None] * depth        # event on the compute stream: the step that used device set k has been enqueued
         self.h2d_wait_ms = []                  # per delivered batch: compute-stream time spent waiting for the upload
         self.bytes_last = 0
+        self.tiled_last = False                # whether the last staged batch was recognised as a period-tiled clip
         self._wait_events = []
 
     # -- staging ----------------------------------------------------------------------------------------------------
@@ -63,9 +64,21 @@ class DevicePrefetcher:
         for s in shape: n *= int(s)
         b = store[k]
         if b is None or b.numel() < n or b.dtype != dtype:
-            b = (torch.empty(n, dtype=dtype, pin_memory=True) if pinned else torch.empty(n, dtype=dtype, device=self.device))
+            if pinned:
+                b = torch.empty(n, dtype=dtype, pin_memory=True)
+            else:
+                b = self._dev_alloc(n, dtype)
             store[k] = b
         return b[:n].view(*shape)
+
+    def _dev_alloc(self, n, dtype):
+        """Device staging memory comes from the COPY stream's pool.  The caching allocator hands a freed block back to the stream
+        it was allocated on without waiting for that stream's queued kernels; a block taken from the compute stream's pool
+        could still be read or written by the in-flight step when the copy stream's DMA first touches it.  A block of the
+        copy stream's pool was last used by the copy stream (or by a compute-stream reader the allocator already waits for
+        through `record_stream`), so its first touch needs no further ordering."""
+        with torch.cuda.stream(self.copy_stream):
+            return torch.empty(n, dtype=dtype, device=self.device)
 
     def _stage(self, batch: Dict, k: int) -> Dict:
         img = batch["image"]
@@ -89,7 +102,7 @@ class DevicePrefetcher:
                 idx = (torch.arange(B, dtype=torch.int32).view(B, 1) * self.period
                        + (torch.arange(T, dtype=torch.int32) % self.period).view(1, T)).reshape(-1)
                 ih = idx.pin_memory()                           # 4 * B * T bytes
-                idev = torch.empty(B * T, dtype=torch.int32, device=self.device)
+                idev = torch.empty(B * T, dtype=torch.int32, device=self.device)   # (copy stream current: its pool)
                 idev.copy_(ih, non_blocking=True)
                 self._idx_host[k] = ih                          # (kept alive until this slot is staged again)
             ev = torch.cuda.Event()
@@ -97,6 +110,7 @@ class DevicePrefetcher:
         self._copied[k] = ev
         dev.record_stream(cur)
         self.bytes_last = host.numel() * host.element_size()
+        self.tiled_last = bool(tiled)
         if tiled:
             idev.record_stream(cur)
             out["image"] = None

@@ -241,12 +241,14 @@ int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int3
  *   qkv: bf16 [B*S, ld]  q at col 0, k at col H*dh, v at col 2*H*dh (per head dh contiguous)
  *   out: bf16 [B*S, H*dh]; lse: f32 [B, H, S] (log-sum-exp of scaled scores; NULL to skip)
  *   dh in {64, 128}.
- *   ws: caller-provided scratch of hvlm_attn_{fwd,bwd}_ws_bytes() bytes (16-byte aligned): the backward keeps
- *       delta = rowsum(dO*O) there, followed by the eight per-XCD entry counters of the persistent dK/dV kernel (zeroed by
- *       the call itself with a stream-ordered memset: no initialisation is asked of the caller); the forward keeps the eight
- *       work-queue counters of its persistent dh = 128 causal kernel there (64-byte aligned, zeroed by the call itself) (the
- *       transposed operands V^T, K^T, Q^T, dO^T are gathered inside the kernels with LDS transpose reads — the parameter
- *       stays for ABI stability).
+ *   ws: caller-provided scratch.  HARD CONTRACT (ABI version >= 2): at least hvlm_attn_{fwd,bwd}_ws_bytes() bytes — the
+ *       forward's is 512 — and 64-byte aligned.  The backward keeps delta = rowsum(dO*O) there, followed by the eight per-XCD
+ *       entry counters of the persistent dK/dV kernel; the forward keeps the eight work-queue counters of its persistent
+ *       dh = 128 causal kernel there and WRITES all 512 bytes (both zeroed by the call itself with a stream-ordered memset: no
+ *       initialisation is asked of the caller).  The library can only check the alignment: a forward workspace that is NULL or
+ *       not 64-byte aligned selects the non-persistent kernel (which needs no workspace) instead of failing; a workspace that
+ *       is aligned but SHORTER than hvlm_attn_fwd_ws_bytes() is overrun.  (The transposed operands V^T, K^T, Q^T, dO^T are
+ *       gathered inside the kernels with LDS transpose reads.)
  * bwd: dqkv (same layout as qkv, fully written for rows < S) from dout [B*S, H*dh].
  * ------------------------------------------------------------------------------------------ */
 size_t hvlm_attn_fwd_ws_bytes(int B, int S, int H, int dh);

@@ -268,7 +268,8 @@ def test_b_7b_labelled_rows_packed_recompute_equal_default(seven_b):
         # (packed / recompute: 0.0 exactly, asserted below.  Labelled rows: lm_head and the last layer's GEMMs run with M = n_v instead
         #  of M = B S, i.e. on a different tile schedule / split — a few logits land on the neighbouring bf16 value, and the mean CE over
         #  the ~500 labelled rows moves by a few 1e-6 relative: 8.5e-7 measured in round 4, 2.2e-6 in round 5 on a different loss value.)
-        assert rr["loss_rel_vs_default"] <= 1e-5, (name, rr)
+        #  Bound: 4e-6 — just under 2 x the larger measurement, so a real regression of the labelled-rows path still trips it.
+        assert rr["loss_rel_vs_default"] <= 4e-6, (name, rr)
         for k in GRAD_KEYS:
             assert rr[k] <= (max(2e-3, 0.6 * floor[k]) if floor else 3e-2), (name, k, rr[k], floor and floor[k])
     for k in GRAD_KEYS:                                                       # packed rows at B = 1 only drop the 5 pad rows

@@ -42,10 +42,17 @@ def _mem_available_gb():
     return 0.0
 
 
-def _need_host_gb(gb):
+SKIPPED = {}       # test name -> reason: written into the report and checked by test_zz_no_silent_fulldepth_skip
+
+
+def _need_host_gb(gb, name):
     have = _mem_available_gb()
     if have < gb:
-        pytest.skip(f"the fp32 oracle of this test needs ~{gb} GB of host memory, {have:.0f} GB available")
+        why = f"the fp32 oracle of this test needs ~{gb} GB of host memory, {have:.0f} GB available"
+        SKIPPED[name] = why
+        REPORT.setdefault("skipped", {})[name] = why
+        _write()
+        pytest.skip(why)
 
 
 # g_embed_hand is ONE 4096-element row = the sum of the 4 B hand-token rows' gradients: its distance from fp32 is decided by which handful
@@ -64,13 +71,14 @@ def _envelope_asserts(r, keys, cap=8e-2):
 
 
 def _write():
+    REPORT.setdefault("skipped", {})
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/fulldepth_r5_report.json", "w") as f:
         json.dump(REPORT, f, indent=1)
 
 
 def test_g_13b_L40_S2048_forward_backward_vs_oracle():
-    _need_host_gb(230)
+    _need_host_gb(230, "test_g_13b_L40_S2048_forward_backward_vs_oracle")
     gc.collect(); torch.cuda.empty_cache()
     m, cfg, clip_np = _build("13b", training=True)
     bt = _batch(1, 1693, seed=50, pad_tail=(0,))
@@ -114,7 +122,7 @@ def test_g_13b_L40_S2048_forward_backward_vs_oracle():
 
 
 def test_h_7b_L32_ragged_batch_padded_and_packed_vs_oracle():
-    _need_host_gb(150)
+    _need_host_gb(150, "test_h_7b_L32_ragged_batch_padded_and_packed_vs_oracle")
     gc.collect(); torch.cuda.empty_cache()
     m, cfg, clip_np = _build("7b", training=True)
     pads = (0, 37, 5, 120)
@@ -199,7 +207,7 @@ def _build_336(training):
 
 
 def test_i_7b_336px_S1187_forward_and_kv_decode_vs_oracle(monkeypatch):
-    _need_host_gb(90)
+    _need_host_gb(90, "test_i_7b_L32_336px_prefill_and_cached_decode_vs_oracle")
     gc.collect(); torch.cuda.empty_cache()
     from hvlm import ops
     monkeypatch.setenv("HVLM_DECODE_GRAPH", "0")
@@ -261,3 +269,11 @@ def test_i_7b_336px_S1187_forward_and_kv_decode_vs_oracle(monkeypatch):
     assert rep["final_hidden_rel"]["hip"] <= 1.25 * rep["final_hidden_rel"]["bf16_eager"] + 1e-3 and rep["final_hidden_rel"]["hip"] < 6e-2
     for h, e in zip(rep["decode_hip_vs_fp32_oracle"], rep["decode_bf16_eager_vs_fp32_oracle"]):
         assert h <= 1.5 * e + 1e-3 and h < 8e-2, (h, e)
+
+
+def test_zz_no_silent_fulldepth_skip():
+    """A full-depth case that skipped for lack of host memory must not leave the suite green unnoticed: the reason is in
+    gpurun_out/fulldepth_r5_report.json ("skipped") and this test FAILS unless HVLM_ALLOW_FULLDEPTH_SKIP=1 says the box is known to be small."""
+    _write()
+    if SKIPPED and os.environ.get("HVLM_ALLOW_FULLDEPTH_SKIP") != "1":
+        pytest.fail("full-depth parity cases skipped (set HVLM_ALLOW_FULLDEPTH_SKIP=1 to accept): " + json.dumps(SKIPPED))

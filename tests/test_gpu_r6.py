@@ -1,0 +1,167 @@
+"""Round-6 GPU tests.
+
+  * the assembly attention kernels at the PRODUCTION queue sizes (VERDICT r5 "What's weak": the suite stopped at 24 work items; the
+    persistent queue with more items than CUs and the cross-item prefetch were only reached through the full-depth tests);
+  * the prefetcher fed WITHOUT a per-step synchronisation, through a staging-buffer regrow (the device staging
+    buffer must not come from the compute stream's pool);
+  * the assembly kernels' preconditions: a call they cannot take runs on the C++ kernel instead of failing.
+
+Reference arithmetic: llava/train/llama_flash_attn_monkey_patch.py:81-94 (causal flash attention, padded and varlen), transformers
+CLIPAttention (non-causal, dh = 64)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _ref_attn_sample(x, H, dh):
+    """x: [S, 3, H, dh] fp32 of ONE sample -> (O [S, H*dh], lse [H, S]); per-sample so that B = 16 / S = 2048 fits."""
+    S = x.shape[0]
+    q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)
+    s = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    s = s.masked_fill(~torch.ones(S, S, device=x.device, dtype=torch.bool).tril(), float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(0, 1).reshape(S, H * dh), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,S,H", [(16, 867, 32), (4, 2048, 40)])
+def test_attn_fwd_asm_production_queue_vs_oracle_and_cpp(B, S, H):
+    """BASELINE config 3's and config 4's attention calls: 2048 resp. 1280 work items on 256 persistent workgroups (8 resp. 5 items
+    per workgroup through the per-XCD queue, every switch with the cross-item prefetch)."""
+    from hvlm import _lib, ops
+    g = torch.Generator(device="cuda").manual_seed(S + H)
+    qkv = (torch.randn(B * S, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+    try:
+        _lib.configure("attn_fwd_asm", 0); o0, l0 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+        _lib.configure("attn_fwd_asm", 1); o1, l1 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+    finally:
+        _lib.configure("attn_fwd_asm", 1)
+    assert torch.isfinite(o1.float()).all()
+    e0 = e1 = el = 0.0
+    for b in range(B):
+        orf, lrf = _ref_attn_sample(qkv[b * S:(b + 1) * S].float().view(S, 3, H, 128), H, 128)
+        e0 = max(e0, (o0[b * S:(b + 1) * S].float() - orf).abs().max().item())
+        e1 = max(e1, (o1[b * S:(b + 1) * S].float() - orf).abs().max().item())
+        el = max(el, (l1[b] - lrf).abs().max().item())
+    assert e1 <= max(1.5 * e0, 4e-3), (e1, e0)          # tolerance: 4e-3 abs on O(1) bf16 outputs = the C++ kernel's bar (test_gpu_r5)
+    assert el <= 2e-3
+
+
+def test_attn_fwd_asm_production_varlen_vs_oracle():
+    """The ragged bench batch's lengths [867, 862, 830, 747] x H = 32, packed rows (cu_seqlens): every sample against its own fp32
+    reference, and packed == padded bit for bit."""
+    from hvlm import _lib, ops
+    lens, H = [867, 862, 830, 747], 32
+    Sm = max(lens)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    full = (torch.randn(len(lens) * Sm, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+    rows = torch.cat([torch.arange(b * Sm, b * Sm + n, device="cuda") for b, n in enumerate(lens)])
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    _lib.configure("attn_fwd_asm", 1)
+    op, lp = ops.attn_fwd(full[rows].contiguous(), len(lens), Sm, H, 128, True, 128 ** -0.5, cu_seqlens=cu)
+    of, lf = ops.attn_fwd(full, len(lens), Sm, H, 128, True, 128 ** -0.5)
+    assert torch.equal(op, of[rows])
+    off = 0
+    for b, n in enumerate(lens):
+        orf, lrf = _ref_attn_sample(full[b * Sm:b * Sm + n].float().view(n, 3, H, 128), H, 128)
+        assert (op[off:off + n].float() - orf).abs().max().item() <= 4e-3
+        assert (lp[b, :, :n] - lrf).abs().max().item() <= 2e-3
+        assert torch.equal(lp[b, :, :n], lf[b, :, :n])
+        off += n
+
+
+def test_clip_attn_asm_production_queue_vs_oracle_and_cpp():
+    """One tower pass of the SFT step: 1600 frames x 16 heads = 25600 items on 256 persistent workgroups."""
+    from hvlm import _lib, ops
+    F16 = torch.float16
+    B, H = 1600, 16
+    g = torch.Generator(device="cuda").manual_seed(1600)
+    qkv = torch.randn(B * 257, 3 * H * 64, device="cuda", generator=g).to(F16)
+    try:
+        _lib.configure("attn_clip_asm", 0); o0 = ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5)
+        _lib.configure("attn_clip_asm", 1); o1 = ops.attn_fwd_f16(qkv, B, 257, H, 64, 64 ** -0.5)
+    finally:
+        _lib.configure("attn_clip_asm", 1)
+    assert torch.isfinite(o1.float()).all()
+    e0 = e1 = 0.0
+    for c in range(0, B, 100):                                              # fp32 reference in chunks of 100 frames (0.4 GB of scores)
+        x = qkv[c * 257:(c + 100) * 257].float().view(100, 257, 3, H, 64)
+        q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+        ref = (torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1) @ v).transpose(1, 2).reshape(100 * 257, H * 64)
+        e0 = max(e0, (o0[c * 257:(c + 100) * 257].float() - ref).abs().max().item())
+        e1 = max(e1, (o1[c * 257:(c + 100) * 257].float() - ref).abs().max().item())
+    assert e1 <= max(2.0 * e0, 2e-3), (e1, e0)                              # tolerance: 2e-3 abs (one fp16 rounding of P and of O), as test_gpu_r5
+
+
+def test_attn_asm_preconditions_fall_back_to_cpp():
+    """A forward workspace that is not 64-byte aligned cannot hold the assembly kernel's queue counters: the call must run (on the C++
+    kernel, bit-identical to `attn_fwd_asm = 0`), not fail.  Same for a CLIP call past the assembly kernel's 32-bit byte offsets."""
+    from hvlm import _lib, ops
+    lib = _lib.load()
+    B, S, H = 2, 300, 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = (torch.randn(B * S, 3 * H * 128, device="cuda", generator=g) * 0.7).to(BF)
+    try:
+        _lib.configure("attn_fwd_asm", 0); o0, l0 = ops.attn_fwd(qkv, B, S, H, 128, True, 128 ** -0.5)
+    finally:
+        _lib.configure("attn_fwd_asm", 1)
+    raw = torch.empty(2048, dtype=torch.uint8, device="cuda")
+    ws = raw[(16 - raw.data_ptr() % 64) % 64:]                               # 16-byte aligned (the old header's contract), not 64
+    assert ws.data_ptr() % 64 == 16
+    o = torch.empty_like(o0); lse = torch.empty_like(l0)
+    rc = lib.hvlm_attn_fwd(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(o.data_ptr()), ctypes.c_void_p(lse.data_ptr()),
+                           ctypes.c_void_p(ws.data_ptr()), B, S, H, 128, qkv.stride(0), 1, 128 ** -0.5, ops._stream())
+    assert rc == 0, lib.hvlm_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(o, o0) and torch.equal(lse, l0)
+    # CLIP: ld so large that rows * ld * 2 >= 2^32 (2 frames of a 4 M-column row stride; only the first 3 * H * 64 columns are read)
+    Bc, Hc = 2, 1
+    ld = (1 << 32) // (Bc * 257 * 2) + 64
+    ld -= ld % 8
+    big = torch.zeros(Bc * 257, ld, dtype=torch.float16, device="cuda")
+    big[:, :3 * Hc * 64] = torch.randn(Bc * 257, 3 * Hc * 64, device="cuda", generator=g).to(torch.float16)
+    o1 = ops.attn_fwd_f16(big, Bc, 257, Hc, 64, 64 ** -0.5)                 # asm enabled, preconditions not met -> C++ kernel
+    try:
+        _lib.configure("attn_clip_asm", 0); o2 = ops.attn_fwd_f16(big, Bc, 257, Hc, 64, 64 ** -0.5)
+    finally:
+        _lib.configure("attn_clip_asm", 1)
+    assert torch.equal(o1, o2)
+
+
+def test_prefetch_without_per_step_sync_and_regrow():
+    """The trainer's feed with NO synchronisation between steps (train.py enqueues step i, then stages batch i + 1), through a staging
+    regrow (distinct-frame batches, then an untiled one ten times the size): losses and gradients equal the synchronous feed's bit
+    for bit.  With device staging taken from the compute stream's pool the regrown buffer could be a block the in-flight step
+    still uses; it now comes from the copy stream's pool (hvlm/prefetch.py::_dev_alloc)."""
+    from hvlm.prefetch import DevicePrefetcher
+    from test_gpu_r5 import _batch, tiny
+    m, cfg = tiny(training=True)
+    m.config.dedup_frames = True
+    batches = [_batch(2, 40 + 3 * i, seed=20 + i, tiled=(i not in (2, 4))) for i in range(6)]
+
+    def run(feed, sync):
+        out = []
+        for bt in feed:
+            torch.manual_seed(7); torch.cuda.manual_seed_all(7)
+            o = m(**bt)
+            m.backward()
+            if sync:
+                torch.cuda.synchronize()
+            out.append((o.loss.detach().clone(), m.proj_w_g.clone(), m.stack.layers[0].flat_g.clone(), m.embed_g.clone()))
+        torch.cuda.synchronize()
+        return out
+
+    ref = run([dict(b) for b in batches], True)
+    for _ in range(2):                                                       # twice: the second pass starts from a warm allocator
+        torch.cuda.empty_cache() if _ == 0 else None
+        feed = DevicePrefetcher([dict(b) for b in batches], m.device, dedup_period=10)
+        got = run(feed, False)
+        assert len(got) == len(ref)
+        for (l0, a0, b0, c0), (l1, a1, b1, c1) in zip(ref, got):
+            assert float(l0) == float(l1)
+            assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(c0, c1)
+    assert feed.tiled_last is True and feed.bytes_last == 2 * 10 * 3 * 224 * 224 * 2
