@@ -21,6 +21,34 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
                                                    const int32_t* __restrict__ yrow, long ystride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+  constexpr int UNR = 4;                         // ROWS*UNR 16-byte loads per lane and block of UNR*512 columns
+  const int l = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n0 = wave * ROWS;
+  const bf16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (size_t)min(max(n0, 0) + r, N - 1) * ldw;
+  // The weight rows do not depend on x: the first block of every wave's stream (ROWS * UNR x 16 B per lane) is requested BEFORE the
+  // prologue stages x (two passes over x and a block reduction for PRE = 1, 43 exponentials per thread for PRE = 2 at F = 11008), so the
+  // HBM latency of the first block overlaps the prologue instead of following it (round 6: the step is a chain of 5 - 35 us kernels,
+  // each of which used to open with 1.5 - 2 us of HBM silence).
+  u32x4 wv0[UNR][ROWS], wv1[UNR][ROWS];
+  const bool has0 = (UNR - 1) * 512 + l * 8 < K;                  // the first full block exists for this lane
+  const bool has1 = has0 && (2 * UNR - 1) * 512 + l * 8 < K;      // ... and the second (K = 4096: the whole row is then in flight)
+  if (has0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv0[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + l * 8 + u * 512));
+  }
+  if (has1) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv1[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + l * 8 + (UNR + u) * 512));
+  }
   if (yrow) y += (long)(*yrow) * ystride;      // graph-replayed decode: the output row (KV-cache position) lives on the device
   if constexpr (PRE == 0) {
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8)
@@ -59,25 +87,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
     }
   }
   __syncthreads();
-  const int l = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n0 = wave * ROWS;
   if (n0 >= N) return;
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  constexpr int UNR = 4;                         // ROWS*UNR 16-byte loads in flight per lane
-  const bf16_t* wrow[ROWS];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
-  int k = l * 8;
-  for (; k + (UNR - 1) * 512 < K; k += UNR * 512) {
-    u32x4 wv[UNR][ROWS];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
+  auto fma_block = [&](const u32x4 (&wv)[UNR][ROWS], int k) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k + u * 512);
@@ -87,6 +101,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
         for (int e = 0; e < 4; ++e)
           acc[r] += bf_lo(wv[u][r][e]) * bf_lo(xv[e]) + bf_hi(wv[u][r][e]) * bf_hi(xv[e]);
     }
+  };
+  auto load_block = [&](u32x4 (&wv)[UNR][ROWS], int k) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
+  };
+  // two register sets, both requested before the prologue; from then on block b + 2 is requested into the set block b has just left
+  // (same per-row accumulation order as a one-set loop: results are bit-identical to the round-3 kernel)
+  int k = l * 8;
+  bool h0 = has0, h1 = has1;
+  while (h0) {
+    fma_block(wv0, k);
+    k += UNR * 512;
+    const int ka = k + UNR * 512;                                  // block b + 2 (if block b + 1 exists)
+    h0 = h1 && ka + (UNR - 1) * 512 < K;
+    if (h0) load_block(wv0, ka);
+    if (!h1) break;
+    fma_block(wv1, k);
+    k += UNR * 512;
+    const int kb = k + UNR * 512;
+    h1 = h0 && kb + (UNR - 1) * 512 < K;
+    if (h1) load_block(wv1, kb);
   }
   for (; k < K; k += 512) {
     const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k);
@@ -330,6 +368,199 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16_t* 
   if (t == 0) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// sum over a group of 8 or 16 adjacent lanes (aligned to the group); every lane of the group gets the total
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LPR == 8 || LPR == 16, "lane groups of 8 or 16");
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));            // quad_perm [2,3,0,1]
+  x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));           // row_half_mirror: lane i <-> 7 - i
+  if constexpr (LPR == 16) {
+    x = __float_as_int(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));         // row_mirror: lane i <-> 15 - i
+  }
+  return v;
+}
+
+// Round 6: the split kernel above walks its keys one row per THREAD (16 dependent 16-byte loads per key, 108 of 256 threads busy at
+// S = 867 / 8 splits) and then the values four bytes per lane — a chain of three HBM round trips that took 16.5 us per layer for 14 MB
+// (profiles/r06g_decode_kernel_stats_before.txt), a sixth of the decode step.  This kernel reads a row with DH / 8 ADJACENT lanes x
+// 16 B (one wave instruction = 64 * 8 / DH whole rows, as attn_decode_batched_kernel) and requests the K rows AND the V rows of its
+// split before anything else — values do not depend on scores — so ONE round trip covers the whole split (<= 128 keys: U loads of K
+// and U of V per lane).  No block-wide softmax: every lane group keeps (max, sum, acc[DH]) of its own U rows (all lanes of a group hold
+// the group's scores after the DPP sum), and the groups are merged flash-decoding style through LDS — one barrier instead of five.
+// Same contract as attn_decode_partial_kernel (RoPE of the new token fused when cos_tab != null, combine of the splits by the head's
+// last workgroup when cnt != null, position on the device when pos_dev != null); fused and unfused forms share every instruction that
+// touches the data, so they stay bit-identical to each other (tests/test_gpu_model.py).
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                                const bf16_t* __restrict__ vc, float* __restrict__ part_out,
+                                                                int S, int ld, float scale, int NS,
+                                                                const int32_t* __restrict__ pos_dev,
+                                                                const bf16_t* __restrict__ cos_tab,
+                                                                const bf16_t* __restrict__ sin_tab, int* __restrict__ cnt,
+                                                                bf16_t* __restrict__ out) {
+  constexpr int LPR = DH / 8;            // lanes per row (16 B each)
+  constexpr int RPI = 64 / LPR;          // rows per wave instruction
+  constexpr int NG = 4 * RPI;            // lane groups per workgroup
+  constexpr int U = 128 / NG;            // rows per lane group: the split holds at most 128 keys
+  constexpr int HALF = DH / 2;
+  __shared__ __attribute__((aligned(16))) float qs[DH];
+  __shared__ __attribute__((aligned(16))) bf16_t knew[DH];
+  __shared__ __attribute__((aligned(16))) float gp[NG][DH + 4];      // per lane group: acc[DH], max, sum
+  __shared__ int is_last;
+  const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int c = l % LPR, g = w * RPI + l / LPR;
+  if (pos_dev) {                         // graph-replayed decode: q is the cache base, the position is on the device
+    const int p = *pos_dev;
+    S = p + 1;
+    q += (size_t)p * ld;
+  }
+  const int s_begin = (int)((long)S * j / NS), s_end = (int)((long)S * (j + 1) / NS);
+  const int n = s_end - s_begin;         // <= 128 (launcher)
+  const bool rope = cos_tab != nullptr;
+  const bool has_new = rope && j == NS - 1;          // this split holds the new token's key, still un-rotated in the cache
+  // 1. every K and V row of the split, in flight at once
+  u32x4 kv[U], vv[U];
+  const bf16_t* kb = kc + (size_t)s_begin * ld + h * DH + c * 8;
+  const bf16_t* vb = vc + (size_t)s_begin * ld + h * DH + c * 8;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = g + u * NG;
+    kv[u] = u32x4{0u, 0u, 0u, 0u};
+    if (row < n) kv[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)row * ld);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = g + u * NG;
+    vv[u] = u32x4{0u, 0u, 0u, 0u};
+    if (row < n) vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)row * ld);
+  }
+  // 2. q (rotated here when the RoPE is fused) -> LDS as scaled floats; the new key rotated, written back and parked in LDS
+  const bf16_t* ct = rope ? cos_tab + (size_t)(S - 1) * HALF : nullptr;
+  const bf16_t* st = rope ? sin_tab + (size_t)(S - 1) * HALF : nullptr;
+  if (t < DH) {
+    if (rope) {
+      const int cc_ = t < HALF ? t : t - HALF;
+      const float x1 = bf2f(q[h * DH + cc_]), x2 = bf2f(q[h * DH + cc_ + HALF]);
+      const float cc = bf2f(ct[cc_]), ss = bf2f(st[cc_]);
+      const float r = t < HALF ? bf2f(f2bf(x1 * cc)) + bf2f(f2bf(-x2 * ss)) : bf2f(f2bf(x2 * cc)) + bf2f(f2bf(x1 * ss));
+      qs[t] = bf2f(f2bf(r)) * scale;
+    } else {
+      qs[t] = bf2f(q[h * DH + t]) * scale;
+    }
+  }
+  if (has_new && t >= 64 && t < 64 + HALF / 8) {     // (wave 1: wave 0's lanes are busy with q)
+    const int c8 = 8 * (t - 64);
+    bf16_t* kp = const_cast<bf16_t*>(kc) + (size_t)(S - 1) * ld + h * DH;
+    const u32x4 x1 = *reinterpret_cast<const u32x4*>(kp + c8), x2 = *reinterpret_cast<const u32x4*>(kp + c8 + HALF);
+    const u32x4 cv = *reinterpret_cast<const u32x4*>(ct + c8), sv = *reinterpret_cast<const u32x4*>(st + c8);
+    u32x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a[2] = {bf_lo(x1[e]), bf_hi(x1[e])}, b[2] = {bf_lo(x2[e]), bf_hi(x2[e])};
+      const float cc[2] = {bf_lo(cv[e]), bf_hi(cv[e])}, ss[2] = {bf_lo(sv[e]), bf_hi(sv[e])};
+      float r1[2], r2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        r1[k] = bf2f(f2bf(a[k] * cc[k])) + bf2f(f2bf(-b[k] * ss[k]));
+        r2[k] = bf2f(f2bf(b[k] * cc[k])) + bf2f(f2bf(a[k] * ss[k]));
+      }
+      o1[e] = pack_bf2(r1[0], r1[1]);
+      o2[e] = pack_bf2(r2[0], r2[1]);
+    }
+    *reinterpret_cast<u32x4*>(kp + c8) = o1;
+    *reinterpret_cast<u32x4*>(kp + c8 + HALF) = o2;
+    *reinterpret_cast<u32x4*>(knew + c8) = o1;
+    *reinterpret_cast<u32x4*>(knew + c8 + HALF) = o2;
+  }
+  __syncthreads();
+  float qf[8];
+  {
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + c * 8), q1 = *reinterpret_cast<const f32x4*>(qs + c * 8 + 4);
+    qf[0] = q0[0]; qf[1] = q0[1]; qf[2] = q0[2]; qf[3] = q0[3]; qf[4] = q1[0]; qf[5] = q1[1]; qf[6] = q1[2]; qf[7] = q1[3];
+  }
+  // 3. scores of the group's rows (every lane of the group ends up with them), the group's own softmax, P V from registers
+  float sc[U];
+  float mg = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int row = g + u * NG;
+    u32x4 kk = kv[u];
+    if (has_new && row == n - 1) kk = *reinterpret_cast<const u32x4*>(knew + c * 8);     // the rotated new key (the load above saw it raw)
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot += bf_lo(kk[e]) * qf[2 * e] + bf_hi(kk[e]) * qf[2 * e + 1];
+    dot = group_sum<LPR>(dot);
+    sc[u] = row < n ? dot : -INFINITY;
+    mg = fmaxf(mg, sc[u]);
+  }
+  float lg = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float p = (g + u * NG < n) ? __expf(sc[u] - mg) : 0.f;
+    lg += p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += p * bf_lo(vv[u][e]); acc[2 * e + 1] += p * bf_hi(vv[u][e]); }
+  }
+  {
+    float* pp = &gp[g][c * 8];
+    *reinterpret_cast<f32x4*>(pp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(pp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    if (c == 0) { gp[g][DH] = mg; gp[g][DH + 1] = lg; }
+  }
+  __syncthreads();
+  // 4. merge the lane groups: (max, sum, unnormalised o[DH]) of the split
+  float* po = part_out + ((size_t)h * NS + j) * (DH + 2);
+  auto st_f = [](float* ptr, float v) {      // agent-scope relaxed atomic store = write-through, L1-bypassing (see attn_decode_partial_kernel)
+    __hip_atomic_store(reinterpret_cast<int*>(ptr), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (t < DH) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) m = fmaxf(m, gp[i][DH]);
+    float lsum = 0.f, o = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const float mi = gp[i][DH];
+      const float wi = (mi == -INFINITY) ? 0.f : __expf(mi - m);
+      lsum += gp[i][DH + 1] * wi;
+      o += gp[i][t] * wi;
+    }
+    st_f(po + 2 + t, o);
+    if (t == 0) { st_f(po, m); st_f(po + 1, lsum); }
+  }
+  if (cnt == nullptr) return;
+  // fused combine: the last of the head's NS workgroups merges the partials (ticket counter, zero at rest)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's partial stores have reached the coherence point
+  __syncthreads();
+  if (t == 0) is_last = (__hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1);
+  __syncthreads();
+  if (!is_last) return;
+  if (t < DH) {
+    auto ld_f = [](const float* ptr) {
+      return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    const float* p = part_out + (size_t)h * NS * (DH + 2);
+    float m = -INFINITY;
+    for (int jj = 0; jj < NS; ++jj) m = fmaxf(m, ld_f(p + jj * (DH + 2)));
+    float lsum = 0.f, o = 0.f;
+    for (int jj = 0; jj < NS; ++jj) {
+      const float mj = ld_f(p + jj * (DH + 2));
+      const float wj = (mj == -INFINITY) ? 0.f : __expf(mj - m);
+      lsum += ld_f(p + jj * (DH + 2) + 1) * wj;
+      o += ld_f(p + jj * (DH + 2) + 2 + t) * wj;
+    }
+    out[h * DH + t] = f2bf(o / lsum);
+  }
+  if (t == 0) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int DH>
 __global__ __launch_bounds__(DH) void attn_decode_combine_kernel(const float* __restrict__ part, bf16_t* __restrict__ out, int NS) {
   const int h = blockIdx.x, t = threadIdx.x;
@@ -412,23 +643,6 @@ static int gemv_pre(const void* W, const void* x, void* y, const void* residual,
 // 64 * 8 / DH whole rows (1 KB, every 128-B line touched once), eight such loads are in flight per wave, and the
 // per-row dot product is closed with DPP adds inside the lane group.  (The first version read K with one lane per row -
 // 64 rows x 16 B per instruction, 24 KB apart - and V four bytes per lane: 3.9 TB/s; profiles/r02v_attn_decode.txt.)
-// sum over a group of 8 or 16 adjacent lanes (aligned to the group); every lane of the group gets the total
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-  static_assert(LPR == 8 || LPR == 16, "lane groups of 8 or 16");
-  int x = __float_as_int(v);
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
-  x = __float_as_int(v);
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));            // quad_perm [2,3,0,1]
-  x = __float_as_int(v);
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));           // row_half_mirror: lane i <-> 7 - i
-  if constexpr (LPR == 16) {
-    x = __float_as_int(v);
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));         // row_mirror: lane i <-> 15 - i
-  }
-  return v;
-}
-
 template <int DH>
 __global__ __launch_bounds__(256) void attn_decode_batched_kernel(const bf16_t* __restrict__ q, int ldq,
                                                                   const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
@@ -591,7 +805,15 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   const bool dev = pos < 0;
   const int S = dev ? max_S : pos + 1;
   HVLM_REQUIRE(S > 0, "decode_step: bad position / max_S");
-  const int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);      // key splits: H * NS workgroups
+  // key splits (H * NS workgroups).  Round 6: splits of <= 64 keys (at most 1024 / H of them: the partials' slots in the workspace) for the
+  // lane-group kernel attn_decode_split_kernel, which holds a split of <= 128 keys in registers; longer splits (S > 128 * NS) and
+  // hvlm_configure("decode_attn_v1", 1) run the round-3 kernel with its 1 / 4 / 8 splits
+  int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);
+  bool v2 = !config().decode_attn_v1;
+  if (v2) {
+    const int ns2 = std::min(std::max(1, cdiv(S, 64)), std::max(1, std::min(32, 1024 / H)));
+    if (cdiv(S, ns2) <= 128) NS = ns2; else v2 = false;
+  }
   const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1 + 4) * 4 + (size_t)dh * 2;   // + the new key row
   HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
   const int32_t* pd = dev ? pos_dev : nullptr;
@@ -615,16 +837,23 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
     const bf16_t* fc = fused ? (const bf16_t*)cos_tab : nullptr;
     const bf16_t* fs = fused ? (const bf16_t*)sin_tab : nullptr;
     int* fcnt = fused ? cnt : nullptr;
-    if (dh == 128) {
+    if (v2) {
+      if (dh == 128)
+        hipLaunchKernelGGL((attn_decode_split_kernel<128>), dim3(H, NS), dim3(256), 0, as_stream(stream), (const bf16_t*)row,
+                           (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
+      else
+        hipLaunchKernelGGL((attn_decode_split_kernel<64>), dim3(H, NS), dim3(256), 0, as_stream(stream), (const bf16_t*)row,
+                           (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
+    } else if (dh == 128) {
       hipLaunchKernelGGL((attn_decode_partial_kernel<128>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
                          (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
-      if (!fused)
-        hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
     } else {
       hipLaunchKernelGGL((attn_decode_partial_kernel<64>), dim3(H, NS), dim3(256), lds_attn, as_stream(stream), (const bf16_t*)row,
                          (const bf16_t*)(kv + D), (const bf16_t*)(kv + 2 * D), apart, S, cache_ld, scale, NS, pd, fc, fs, fcnt, ao);
-      if (!fused)
-        hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
+    }
+    if (!fused) {
+      if (dh == 128) hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3(H), dim3(128), 0, as_stream(stream), (const float*)apart, ao, NS);
+      else hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3(H), dim3(64), 0, as_stream(stream), (const float*)apart, ao, NS);
     }
     if ((rc = check_launch("attn_decode_split"))) return rc;
     if ((rc = gemv_pre(w_o[l], ao, h, x, D, D, D, 0, nullptr, 0.f, stream))) return rc;

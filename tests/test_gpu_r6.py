@@ -68,7 +68,10 @@ def test_attn_fwd_asm_production_varlen_vs_oracle():
     off = 0
     for b, n in enumerate(lens):
         orf, lrf = _ref_attn_sample(full[b * Sm:b * Sm + n].float().view(n, 3, H, 128), H, 128)
-        assert (op[off:off + n].float() - orf).abs().max().item() <= 4e-3
+        # tolerance: 4e-3 abs + 2^-8 relative, elementwise — a sample's first rows attend to a handful of keys, so |O| reaches 2 - 3 there
+        # and ONE bf16 rounding of such an output is already 2^-9 relative (3.9e-3 .. 7.8e-3 abs); the P rounding adds as much again
+        err = (op[off:off + n].float() - orf).abs() - 2.0 ** -8 * orf.abs()
+        assert err.max().item() <= 4e-3, err.max().item()
         assert (lp[b, :, :n] - lrf).abs().max().item() <= 2e-3
         assert torch.equal(lp[b, :, :n], lf[b, :, :n])
         off += n
@@ -165,3 +168,31 @@ def test_prefetch_without_per_step_sync_and_regrow():
             assert float(l0) == float(l1)
             assert torch.equal(a0, a1) and torch.equal(b0, b1) and torch.equal(c0, c1)
     assert feed.tiled_last is True and feed.bytes_last == 2 * 10 * 3 * 224 * 224 * 2
+
+
+@pytest.mark.parametrize("S0,n", [(62, 4), (1022, 3), (4092, 3), (4200, 2)])
+def test_decode_step_lane_group_attention_split_boundaries_vs_oracle(monkeypatch, S0, n):
+    """The decode step's lane-group attention (csrc/decode.hip attn_decode_split_kernel, round 6): splits of <= 64 keys around the
+    changes of the split count (1 -> 2 splits at 65 keys, 16 -> 17 at 1025, the 32-split cap at 4096 keys with 128-key splits) and the
+    fall-back to the round-3 kernel beyond it (S > 4096), 1 layer of 7B width against the fp32 oracle inside the bf16-eager envelope;
+    and both kernels against each other at S = 867 (handsonvlm/model/language_model/handsonvlm.py:543-647 decodes at batch 1)."""
+    from test_gpu_decode_r3 import _check, _decode_run, _stack
+    st, cfg = _stack(4096, 11008, 32, 1, max_pos=4400)
+    xfull, rows, got = _decode_run(st, cfg, S0, n, 23 + S0, monkeypatch, False)
+    _check(st, cfg, xfull, rows, got, f"lane-group decode attention from S0={S0}")
+
+
+def test_decode_step_attention_v1_v2_agree(monkeypatch):
+    from hvlm import _lib
+    from test_gpu_decode_r3 import _decode_run, _stack
+    st, cfg = _stack(4096, 11008, 32, 2)
+    res = {}
+    for v1 in (0, 1):
+        _lib.configure("decode_attn_v1", v1)
+        try:
+            _, rows, got = _decode_run(st, cfg, 867, 6, 31, monkeypatch, False)
+        finally:
+            _lib.configure("decode_attn_v1", 0)
+        res[v1] = got
+    d = (res[0] - res[1]).norm() / res[1].norm()
+    assert torch.isfinite(res[0]).all() and d < 5e-3, float(d)          # two bf16 roundings of the attention output per layer apart
