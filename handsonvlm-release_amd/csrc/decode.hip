@@ -14,41 +14,17 @@ namespace {
 // PRE selects what x' is (computed by every workgroup while it stages the 8-22 KB vector: cheaper than a kernel launch):
 //   0: x' = x;   1: x' = RMSNorm(x) * nw  (same arithmetic as rmsnorm_fwd_kernel: bf16(x*rstd) then * w, bf16);
 //   2: x' = SwiGLU(x) with x = [gate(K) | up(K)]  (same arithmetic as swiglu_fwd_kernel).
+// (Round 6, measured and not kept — profiles/r06h_decode_kernel_stats_regression.txt: requesting the first two weight blocks of every wave BEFORE
+//  the prologue stages x, two register sets: 164 VGPRs instead of ~50, three waves per SIMD instead of eight, and x — which returns behind the
+//  weights, loads complete in order — arrives last: q|k|v + gate|up 28.2 vs 26.2 us, o_proj 8.9 vs 8.1 us, the step 3.31 vs 3.18 ms per token.
+//  The kernel's speed comes from MANY short waves whose prologues overlap each other's streams, not from one deep pipeline per wave.)
 template <int ROWS, int PRE>
 __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
                                                    bf16_t* __restrict__ y, const bf16_t* __restrict__ res, int N,
                                                    int K, int ldw, const bf16_t* __restrict__ nw, float eps,
-                                                   const int32_t* __restrict__ yrow, long ystride) {
+                                                   const int32_t* __restrict__ yrow, long ystride, int pair_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
-  constexpr int UNR = 4;                         // ROWS*UNR 16-byte loads per lane and block of UNR*512 columns
-  const int l = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n0 = wave * ROWS;
-  const bf16_t* wrow[ROWS];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (size_t)min(max(n0, 0) + r, N - 1) * ldw;
-  // The weight rows do not depend on x: the first block of every wave's stream (ROWS * UNR x 16 B per lane) is requested BEFORE the
-  // prologue stages x (two passes over x and a block reduction for PRE = 1, 43 exponentials per thread for PRE = 2 at F = 11008), so the
-  // HBM latency of the first block overlaps the prologue instead of following it (round 6: the step is a chain of 5 - 35 us kernels,
-  // each of which used to open with 1.5 - 2 us of HBM silence).
-  u32x4 wv0[UNR][ROWS], wv1[UNR][ROWS];
-  const bool has0 = (UNR - 1) * 512 + l * 8 < K;                  // the first full block exists for this lane
-  const bool has1 = has0 && (2 * UNR - 1) * 512 + l * 8 < K;      // ... and the second (K = 4096: the whole row is then in flight)
-  if (has0) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        wv0[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + l * 8 + u * 512));
-  }
-  if (has1) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        wv1[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + l * 8 + (UNR + u) * 512));
-  }
   if (yrow) y += (long)(*yrow) * ystride;      // graph-replayed decode: the output row (KV-cache position) lives on the device
   if constexpr (PRE == 0) {
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8)
@@ -87,11 +63,29 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
     }
   }
   __syncthreads();
+  const int l = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // pair_off != 0 (ROWS == 2; the decode step's gate|up projection, round 6): the wave's two rows are gate row n and up row n + pair_off of the
+  // fused [gate; up] weight, N counts PAIRS and y[n] = SwiGLU(bf16(gate . x), bf16(up . x)) — the arithmetic of PRE == 2 below (and of
+  // swiglu_fwd_kernel) on the same bf16-rounded pair, so the down projection's input is bit-identical; the 2 F-element gate|up vector is never
+  // written, and the down GEMV no longer evaluates F exponentials in EVERY workgroup's prologue (43 per thread at F = 11008)
+  const int n0 = pair_off ? wave : wave * ROWS;
   if (n0 >= N) return;
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  auto fma_block = [&](const u32x4 (&wv)[UNR][ROWS], int k) {
+  constexpr int UNR = 4;                         // ROWS*UNR 16-byte loads in flight per lane
+  const bf16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (pair_off ? (size_t)(n0 + r * pair_off) : (size_t)min(n0 + r, N - 1)) * ldw;
+  int k = l * 8;
+  for (; k + (UNR - 1) * 512 < K; k += UNR * 512) {
+    u32x4 wv[UNR][ROWS];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k + u * 512);
@@ -101,30 +95,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
         for (int e = 0; e < 4; ++e)
           acc[r] += bf_lo(wv[u][r][e]) * bf_lo(xv[e]) + bf_hi(wv[u][r][e]) * bf_hi(xv[e]);
     }
-  };
-  auto load_block = [&](u32x4 (&wv)[UNR][ROWS], int k) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
-  };
-  // two register sets, both requested before the prologue; from then on block b + 2 is requested into the set block b has just left
-  // (same per-row accumulation order as a one-set loop: results are bit-identical to the round-3 kernel)
-  int k = l * 8;
-  bool h0 = has0, h1 = has1;
-  while (h0) {
-    fma_block(wv0, k);
-    k += UNR * 512;
-    const int ka = k + UNR * 512;                                  // block b + 2 (if block b + 1 exists)
-    h0 = h1 && ka + (UNR - 1) * 512 < K;
-    if (h0) load_block(wv0, ka);
-    if (!h1) break;
-    fma_block(wv1, k);
-    k += UNR * 512;
-    const int kb = k + UNR * 512;
-    h1 = h0 && kb + (UNR - 1) * 512 < K;
-    if (h1) load_block(wv1, kb);
   }
   for (; k < K; k += 512) {
     const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k);
@@ -138,6 +108,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
   if (l == 0) {
+    if constexpr (ROWS == 2) {
+      if (pair_off) {
+        const float g0 = bf2f(f2bf(acc[0])), u0 = bf2f(f2bf(acc[1]));
+        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0)))));
+        y[n0] = f2bf(s0 * u0);
+        return;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
@@ -410,7 +388,11 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   constexpr int HALF = DH / 2;
   __shared__ __attribute__((aligned(16))) float qs[DH];
   __shared__ __attribute__((aligned(16))) bf16_t knew[DH];
-  __shared__ __attribute__((aligned(16))) float gp[NG][DH + 4];      // per lane group: acc[DH], max, sum
+  // one buffer, two uses: per lane group (acc[DH], max, sum) at stride DH + 4, then — in the head's last workgroup — the NS partials
+  constexpr int GS = DH + 4, MAXNS = 32;
+  constexpr int BUFN = NG * GS > MAXNS * (DH + 2) ? NG * GS : MAXNS * (DH + 2);
+  __shared__ __attribute__((aligned(16))) float buf[BUFN];
+  auto gp = [&](int i) -> float* { return buf + i * GS; };
   __shared__ int is_last;
   const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63;
   const int c = l % LPR, g = w * RPI + l / LPR;
@@ -419,26 +401,21 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
     S = p + 1;
     q += (size_t)p * ld;
   }
-  const int s_begin = (int)((long)S * j / NS), s_end = (int)((long)S * (j + 1) / NS);
+  // (32-bit arithmetic throughout: S * NS and rows * ld are bounded by the launcher; 64-bit division and multiplication are emulated
+  //  by long instruction sequences in front of the first load)
+  const int s_begin = (int)((unsigned)(S * j) / (unsigned)NS), s_end = (int)((unsigned)(S * (j + 1)) / (unsigned)NS);
   const int n = s_end - s_begin;         // <= 128 (launcher)
   const bool rope = cos_tab != nullptr;
   const bool has_new = rope && j == NS - 1;          // this split holds the new token's key, still un-rotated in the cache
-  // 1. every K and V row of the split, in flight at once
+  // 1. every K and V row of the split, in flight at once: unconditional loads (rows past the split re-read its last row — a branch per
+  // load made the compiler wait for each one before issuing the next)
   u32x4 kv[U], vv[U];
-  const bf16_t* kb = kc + (size_t)s_begin * ld + h * DH + c * 8;
-  const bf16_t* vb = vc + (size_t)s_begin * ld + h * DH + c * 8;
+  const bf16_t* kb = kc + (long)(s_begin * ld) + h * DH + c * 8;
+  const bf16_t* vb = vc + (long)(s_begin * ld) + h * DH + c * 8;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int row = g + u * NG;
-    kv[u] = u32x4{0u, 0u, 0u, 0u};
-    if (row < n) kv[u] = *reinterpret_cast<const u32x4*>(kb + (size_t)row * ld);
-  }
+  for (int u = 0; u < U; ++u) kv[u] = *reinterpret_cast<const u32x4*>(kb + (long)(max(min(g + u * NG, n - 1), 0) * ld));
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int row = g + u * NG;
-    vv[u] = u32x4{0u, 0u, 0u, 0u};
-    if (row < n) vv[u] = *reinterpret_cast<const u32x4*>(vb + (size_t)row * ld);
-  }
+  for (int u = 0; u < U; ++u) vv[u] = *reinterpret_cast<const u32x4*>(vb + (long)(max(min(g + u * NG, n - 1), 0) * ld));
   // 2. q (rotated here when the RoPE is fused) -> LDS as scaled floats; the new key rotated, written back and parked in LDS
   const bf16_t* ct = rope ? cos_tab + (size_t)(S - 1) * HALF : nullptr;
   const bf16_t* st = rope ? sin_tab + (size_t)(S - 1) * HALF : nullptr;
@@ -509,10 +486,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
     for (int e = 0; e < 4; ++e) { acc[2 * e] += p * bf_lo(vv[u][e]); acc[2 * e + 1] += p * bf_hi(vv[u][e]); }
   }
   {
-    float* pp = &gp[g][c * 8];
+    float* pp = gp(g) + c * 8;
     *reinterpret_cast<f32x4*>(pp) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     *reinterpret_cast<f32x4*>(pp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-    if (c == 0) { gp[g][DH] = mg; gp[g][DH + 1] = lg; }
+    if (c == 0) { gp(g)[DH] = mg; gp(g)[DH + 1] = lg; }
   }
   __syncthreads();
   // 4. merge the lane groups: (max, sum, unnormalised o[DH]) of the split
@@ -523,14 +500,14 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   if (t < DH) {
     float m = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NG; ++i) m = fmaxf(m, gp[i][DH]);
+    for (int i = 0; i < NG; ++i) m = fmaxf(m, gp(i)[DH]);
     float lsum = 0.f, o = 0.f;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      const float mi = gp[i][DH];
+      const float mi = gp(i)[DH];
       const float wi = (mi == -INFINITY) ? 0.f : __expf(mi - m);
-      lsum += gp[i][DH + 1] * wi;
-      o += gp[i][t] * wi;
+      lsum += gp(i)[DH + 1] * wi;
+      o += gp(i)[t] * wi;
     }
     st_f(po + 2 + t, o);
     if (t == 0) { st_f(po, m); st_f(po + 1, lsum); }
@@ -542,19 +519,31 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   if (t == 0) is_last = (__hip_atomic_fetch_add(&cnt[h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NS - 1);
   __syncthreads();
   if (!is_last) return;
-  if (t < DH) {
+  // every float of the head's NS partials in flight at once (the round-3 kernel walked them split by split: 3 NS dependent L2 round trips,
+  // most of its 16.5 us), through LDS; then one thread per output channel merges them
+  {
     auto ld_f = [](const float* ptr) {
       return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
     const float* p = part_out + (size_t)h * NS * (DH + 2);
+    const int total = NS * (DH + 2);
+    constexpr int PER = (MAXNS * (DH + 2) + 255) / 256;
+    float tmp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = t + 256 * k; tmp[k] = i < total ? ld_f(p + i) : 0.f; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const int i = t + 256 * k; if (i < total) buf[i] = tmp[k]; }
+  }
+  __syncthreads();
+  if (t < DH) {
     float m = -INFINITY;
-    for (int jj = 0; jj < NS; ++jj) m = fmaxf(m, ld_f(p + jj * (DH + 2)));
+    for (int jj = 0; jj < NS; ++jj) m = fmaxf(m, buf[jj * (DH + 2)]);
     float lsum = 0.f, o = 0.f;
     for (int jj = 0; jj < NS; ++jj) {
-      const float mj = ld_f(p + jj * (DH + 2));
+      const float mj = buf[jj * (DH + 2)];
       const float wj = (mj == -INFINITY) ? 0.f : __expf(mj - m);
-      lsum += ld_f(p + jj * (DH + 2) + 1) * wj;
-      o += ld_f(p + jj * (DH + 2) + 2 + t) * wj;
+      lsum += buf[jj * (DH + 2) + 1] * wj;
+      o += buf[jj * (DH + 2) + 2 + t] * wj;
     }
     out[h * DH + t] = f2bf(o / lsum);
   }
@@ -620,19 +609,19 @@ using namespace hvlm;
 // GEMV with a fused prologue on x (pre: 0 none, 1 RMSNorm with weights `nw`, 2 SwiGLU of x = [gate | up]); internal to the
 // native decode step (hvlm_gemv_bf16 is pre = 0).
 static int gemv_pre(const void* W, const void* x, void* y, const void* residual, int N, int K, int ldw, int pre,
-                    const void* nw, float eps, void* stream, const int32_t* yrow = nullptr, long ystride = 0) {
+                    const void* nw, float eps, void* stream, const int32_t* yrow = nullptr, long ystride = 0, int pair_off = 0) {
   constexpr int ROWS = 2;
-  const int waves = cdiv(N, ROWS);
+  const int waves = pair_off ? N : cdiv(N, ROWS);          // (pair mode: N = number of (gate, up) pairs, one per wave)
   dim3 grid(cdiv(waves, 4)), block(256);
   if (pre == 1)
     hipLaunchKernelGGL((gemv_kernel<ROWS, 1>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps, yrow, ystride);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps, yrow, ystride, pair_off);
   else if (pre == 2)
     hipLaunchKernelGGL((gemv_kernel<ROWS, 2>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride, pair_off);
   else
     hipLaunchKernelGGL((gemv_kernel<ROWS, 0>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
-                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride);
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nullptr, 0.f, yrow, ystride, pair_off);
   return check_launch("gemv");
 }
 
@@ -812,7 +801,7 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   bool v2 = !config().decode_attn_v1;
   if (v2) {
     const int ns2 = std::min(std::max(1, cdiv(S, 64)), std::max(1, std::min(32, 1024 / H)));
-    if (cdiv(S, ns2) <= 128) NS = ns2; else v2 = false;
+    if (cdiv(S, ns2) <= 128 && (size_t)S * (size_t)cache_ld < (1ull << 31)) NS = ns2; else v2 = false;   // (its 32-bit row offsets)
   }
   const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1 + 4) * 4 + (size_t)dh * 2;   // + the new key row
   HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
@@ -857,9 +846,15 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
     }
     if ((rc = check_launch("attn_decode_split"))) return rc;
     if ((rc = gemv_pre(w_o[l], ao, h, x, D, D, D, 0, nullptr, 0.f, stream))) return rc;
-    if ((rc = gemv_pre(w_gu[l], h, gu, nullptr, 2 * F, D, D, 1, ln2[l], eps, stream))) return rc;
     bf16_t* xo = (l & 1) ? xb : xa;
-    if ((rc = gemv_pre(w_down[l], gu, xo, h, D, F, F, 2, nullptr, 0.f, stream))) return rc;
+    if (!config().decode_unfused) {
+      // gate|up as (gate row, up row) pairs with the SwiGLU in the GEMV's epilogue: `gu` holds the F-element activation
+      if ((rc = gemv_pre(w_gu[l], h, gu, nullptr, F, D, D, 1, ln2[l], eps, stream, nullptr, 0, F))) return rc;
+      if ((rc = gemv_pre(w_down[l], gu, xo, h, D, F, F, 0, nullptr, 0.f, stream))) return rc;
+    } else {
+      if ((rc = gemv_pre(w_gu[l], h, gu, nullptr, 2 * F, D, D, 1, ln2[l], eps, stream))) return rc;
+      if ((rc = gemv_pre(w_down[l], gu, xo, h, D, F, F, 2, nullptr, 0.f, stream))) return rc;
+    }
     x = xo;
   }
   if ((rc = hvlm_rmsnorm_fwd(x, norm_w, hidden_out, nullptr, 1, D, eps, stream))) return rc;

@@ -1050,7 +1050,7 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
 #define HVLM_PHASE_SYNC_K()               \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
-    if constexpr (!FIRSTK) HVLM_VMCNT(8); \
+    if constexpr (!FIRSTK) { if (DBG && (p.dbg & 16)) HVLM_VMCNT(12); else HVLM_VMCNT(8); } \
     __builtin_amdgcn_s_barrier();         \
   } while (0)
 
@@ -1119,6 +1119,14 @@ __device__ __forceinline__ void gemm_pp_body(const GemmArgs& p) {
           stage_a(cb, 0, c2);
           stage_b(cb, 0, c2);
           stage_b(cb, 1, c2);
+          // dbg 16 (round 6: what 1.5 x the operand bytes per flop cost — the L2 -> LDS stream of a 256 x 128 re-tiling): the B
+          // half-tiles are staged TWICE (same slots, same bytes: 12 instead of 8 LDS-DMA pieces per K-tile and wave, the extra ones L2 hits like the
+          // extra bytes of a smaller tile would be); the counted wait of both syncs becomes vmcnt(12) so that every piece keeps its four segments
+          // to land.  dbg 32 selects this kernel with nothing changed (the baseline of the A/B: the 32x32x16 form of the production schedule)
+          if (DBG && (p.dbg & 16)) {
+            stage_b(cb, 0, c2);
+            stage_b(cb, 1, c2);
+          }
         }
         HVLM_PHASE_SYNC_K();
         if constexpr (TN) {
