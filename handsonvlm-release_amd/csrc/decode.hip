@@ -601,7 +601,6 @@ __global__ __launch_bounds__(256) void rope_decode_kernel(bf16_t* __restrict__ k
 
 __global__ void pos_advance_kernel(int32_t* pos_dev) { pos_dev[0] += 1; }
 
-}  // namespace
 }  // namespace hvlm
 
 using namespace hvlm;
@@ -800,7 +799,10 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   int NS = S >= 512 ? 8 : (S >= 128 ? 4 : 1);
   bool v2 = !config().decode_attn_v1;
   if (v2) {
-    const int ns2 = std::min(std::max(1, cdiv(S, 64)), std::max(1, std::min(32, 1024 / H)));
+    // splits: 64-key splits, but no more workgroups than CUs when 128-key splits allow it (H = 32, S = 867: 8 splits = 256 workgroups, 2.87
+    // against 2.92 ms per token with 14), and never more than the workspace's 1024 / H partial slots
+    const int cap = config().decode_attn_ns > 0 ? config().decode_attn_ns : std::max(1, std::min(32, 1024 / H));
+    const int ns2 = std::min(std::max(cdiv(S, 128), std::min(cdiv(S, 64), std::max(1, 256 / H))), cap);
     if (cdiv(S, ns2) <= 128 && (size_t)S * (size_t)cache_ld < (1ull << 31)) NS = ns2; else v2 = false;   // (its 32-bit row offsets)
   }
   const size_t lds_attn = (size_t)(dh + 8 + (256 / (dh / 2)) * dh + (S + NS - 1) / NS + 1 + 4) * 4 + (size_t)dh * 2;   // + the new key row
@@ -813,6 +815,10 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
     bf16_t* kv = reinterpret_cast<bf16_t*>(kv_cache[l]);
     bf16_t* row = dev ? kv : kv + (size_t)pos * cache_ld;
     if ((rc = gemv_pre(w_qkv[l], x, row, nullptr, 3 * D, D, D, 1, ln1[l], eps, stream, pd, cache_ld))) return rc;
+    // (Round 6, measured and removed — profiles/r06j_decode_experiments.txt: touching o_proj's and the head of gate|up's weights from a side
+    //  stream beside the attention, so that the GEMVs find them in the 256 MB memory-side cache: 3.18 / 3.28 / 3.43 ms per token at 32 / 64 /
+    //  128 MB against 2.92 without — the touch kernel (8.3 us per launch) competes with the attention for the same queues, and a GEMV whose
+    //  weights sit in the memory-side cache is no faster than one that streams them from HBM.)
     // RoPE of the new q / k row and the combine of the key splits are fused into the attention kernel (HVLM_DECODE_UNFUSED=1
     // keeps them as separate launches: A/B and the parity test)
     if (!fused) {

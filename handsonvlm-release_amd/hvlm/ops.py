@@ -148,6 +148,34 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
                 if hook is not None:
                     hook(M, N, K, False, 2)             # two launches of the GEMM kernel inside this interval
                 return out
+    # Few row panels (the batch-1 prefill: M = 867 -> 4 panels) and a tile count just above one round of the chip (gate|up: 4 x 86 = 344
+    # tiles on 256 CUs = two rounds for 1.34 rounds of work): the leftmost column panels that make up exactly ONE round run as one launch and
+    # the remaining columns as a split-K launch whose K-slices fill the chip — 1 + 1/s tile-times instead of 2 (round 6; the row-panel
+    # form above needs K >= 8192 and many row panels).  Deterministic (fixed slab order), every output column computed once.
+    tm = (M + 255) // 256
+    if (_GEMM_TAIL and tm <= 8 and _GEMM_CUS < tiles < 2 * _GEMM_CUS and out.dtype == BF16 and N % 256 == 0 and K >= 2048):
+        body_cols = _GEMM_CUS // tm                       # column panels of the body: tm * body_cols <= one round
+        T = (tn - body_cols) * tm
+        splits = 0
+        for cand in (2, 3, 4):
+            if T * cand <= _GEMM_CUS and K % (64 * cand) == 0 and K // cand >= 1024:
+                splits = cand
+        if splits and 0 < body_cols < tn:
+            nb = body_cols * 256
+            b_b, b_t = b[:nb], b[nb:]
+            bias_b = None if bias is None else bias[:nb]
+            bias_t = None if bias is None else bias[nb:]
+            res_b = None if residual is None else residual[:, :nb]
+            res_t = None if residual is None else residual[:, nb:]
+            o_b, o_t = out[:, :nb], out[:, nb:]
+            check(lib.hvlm_gemm_bf16_nt(_p(a), _p(b_b), _p(o_b), M, nb, K, a.stride(0), b.stride(0), out.stride(0), _p(bias_b),
+                                        _p(res_b), ldr, act, 0, _stream()), "gemm_bf16_nt(body columns)")
+            ws = torch.empty((lib.hvlm_gemm_splitk_ws_bytes(M, N - nb, splits),), dtype=torch.uint8, device=a.device)
+            check(lib.hvlm_gemm_bf16_nt_splitk(_p(a), _p(b_t), _p(o_t), M, N - nb, K, a.stride(0), b.stride(0), out.stride(0),
+                                               _p(bias_t), _p(res_t), ldr, act, _p(ws), splits, _stream()), "gemm_splitk(tail columns)")
+            if hook is not None:
+                hook(M, N, K, False, 2)
+            return out
     check(lib.hvlm_gemm_bf16_nt(_p(a), _p(b), _p(out), M, N, K, a.stride(0), b.stride(0),
                                 out.stride(0), _p(bias), _p(residual), ldr, act,
                                 1 if out.dtype == torch.float32 else 0, _stream()), "gemm_bf16_nt")

@@ -196,3 +196,32 @@ def test_decode_step_attention_v1_v2_agree(monkeypatch):
         res[v1] = got
     d = (res[0] - res[1]).norm() / res[1].norm()
     assert torch.isfinite(res[0]).all() and d < 5e-3, float(d)          # two bf16 roundings of the attention output per layer apart
+
+
+@pytest.mark.parametrize("M,N,K,res", [(867, 22016, 4096, False), (600, 22016, 4096, True), (867, 5632, 4096, True)])
+def test_gemm_column_tail_split_vs_fp32_and_one_launch(monkeypatch, M, N, K, res):
+    """ops.gemm_nt's column-panel tail split for few row panels (the batch-1 prefill's gate|up projection: 344 tiles on 256 CUs): body
+    columns as one launch + the rest as split-K.  Against the fp32 product (tolerance: 2^-8 relative to the row-wise operand norms — one
+    bf16 rounding of the output) and within one bf16 ulp of the one-launch kernel (HVLM_GEMM_TAIL=0), elementwise."""
+    from hvlm import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(BF)
+    b = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(BF)
+    r = (torch.randn(M, N, device="cuda", generator=g)).to(BF) if res else None
+    calls = []
+    prev = ops._gemm_hook
+    ops.set_gemm_hook(lambda *args: calls.append(args))
+    try:
+        got = ops.gemm_nt(a, b, residual=r)
+    finally:
+        ops.set_gemm_hook(prev)
+    monkeypatch.setattr(ops, "_GEMM_TAIL", False)
+    one = ops.gemm_nt(a, b, residual=r)
+    ref = a.float() @ b.float().t() + (r.float() if res else 0.0)
+    tiles = ((M + 255) // 256) * (N // 256)
+    if 256 < tiles < 512:
+        assert any(len(c) == 5 and c[4] == 2 for c in calls), calls            # the two-launch path was taken
+    err = (got.float() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2e-2).all(), float(err.max())
+    ulp = 2.0 ** (torch.floor(torch.log2(one.float().abs().clamp_min(1e-30))) - 7)
+    assert ((got.float() - one.float()).abs() <= ulp + 1e-6).all()
