@@ -601,6 +601,7 @@ __global__ __launch_bounds__(256) void rope_decode_kernel(bf16_t* __restrict__ k
 
 __global__ void pos_advance_kernel(int32_t* pos_dev) { pos_dev[0] += 1; }
 
+}  // namespace
 }  // namespace hvlm
 
 using namespace hvlm;
