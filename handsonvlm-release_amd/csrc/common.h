@@ -139,6 +139,7 @@ struct Config {
   int gemm_group_m = 4;       // row panels per group of the XCD-aware tile order
   int gemm_static = 0;        // 1: static tile assignment even when there are >= 3 tiles per workgroup
   int attn_no_resident = 0;   // 1: CLIP attention on the streaming kernel instead of the resident-K/V kernel
+  int decode_engine = 0;      // 1: the batch-1 decode step as ONE persistent launch (decode_stack_kernel) instead of 5 launches per layer
   int decode_attn_ns = 0;     // EXPERIMENT: cap on the key splits of the lane-group decode attention (0 = min(32, 1024 / H))
   int decode_attn_v1 = 0;     // 1: the round-3 decode attention (one key per thread) instead of the lane-group kernel of round 6 (A/B)
   int decode_unfused = 0;     // 1: RoPE and the split combine of the native decode step as separate launches

@@ -31,16 +31,18 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
       *reinterpret_cast<u32x4*>(xs + i) = *reinterpret_cast<const u32x4*>(x + i);
   } else if constexpr (PRE == 1) {
     __shared__ float red[4];
+    // (round 6: x crosses the L2 once — the first pass parks the raw chunk in xs, where the second pass of the SAME thread finds it)
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
+      *reinterpret_cast<u32x4*>(xs + i) = v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float a = bf_lo(v[e]), b = bf_hi(v[e]); ss += a * a + b * b; }
     }
     ss = block_sum<4>(ss, red);
     const float rstd = rsqrtf(ss / (float)K + eps);
     for (int i = threadIdx.x * 8; i < K; i += 256 * 8) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + i);
       const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + i);
       u32x4 o;
 #pragma unroll
@@ -373,14 +375,23 @@ __device__ __forceinline__ float group_sum(float v) {
 // Same contract as attn_decode_partial_kernel (RoPE of the new token fused when cos_tab != null, combine of the splits by the head's
 // last workgroup when cnt != null, position on the device when pos_dev != null); fused and unfused forms share every instruction that
 // touches the data, so they stay bit-identical to each other (tests/test_gpu_model.py).
-template <int DH>
-__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                                const bf16_t* __restrict__ vc, float* __restrict__ part_out,
-                                                                int S, int ld, float scale, int NS,
-                                                                const int32_t* __restrict__ pos_dev,
-                                                                const bf16_t* __restrict__ cos_tab,
-                                                                const bf16_t* __restrict__ sin_tab, int* __restrict__ cnt,
-                                                                bf16_t* __restrict__ out) {
+// ENG = the body runs inside decode_stack_kernel (one launch for the whole stack): the workgroup has more than 256 threads (the others pass
+// the barriers and do nothing: `act`), and everything another workgroup wrote EARLIER IN THE SAME LAUNCH — the new token's q | k | v row —
+// is read with agent-scope (L1-bypassing, sc1) loads, the output written with agent-scope stores: no kernel boundary makes them coherent.
+__device__ __forceinline__ u32x4 load16_agent(const void* ptr) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+__device__ __forceinline__ bf16_t load2_agent(const bf16_t* ptr) {
+  return __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DH, bool ENG>
+__device__ __forceinline__ void attn_decode_split_body(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                       const bf16_t* __restrict__ vc, float* __restrict__ part_out,
+                                                       int S, int ld, float scale, int NS,
+                                                       const bf16_t* __restrict__ cos_tab, const bf16_t* __restrict__ sin_tab,
+                                                       int* __restrict__ cnt, bf16_t* __restrict__ out, const int h, const int j) {
   constexpr int LPR = DH / 8;            // lanes per row (16 B each)
   constexpr int RPI = 64 / LPR;          // rows per wave instruction
   constexpr int NG = 4 * RPI;            // lane groups per workgroup
@@ -394,13 +405,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   __shared__ __attribute__((aligned(16))) float buf[BUFN];
   auto gp = [&](int i) -> float* { return buf + i * GS; };
   __shared__ int is_last;
-  const int h = blockIdx.x, j = blockIdx.y, t = threadIdx.x, w = t >> 6, l = t & 63;
-  const int c = l % LPR, g = w * RPI + l / LPR;
-  if (pos_dev) {                         // graph-replayed decode: q is the cache base, the position is on the device
-    const int p = *pos_dev;
-    S = p + 1;
-    q += (size_t)p * ld;
-  }
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const bool act = !ENG || t < 256;     // (uniform per wave)
+  const int c = l % LPR, g = (w & 3) * RPI + l / LPR;
   // (32-bit arithmetic throughout: S * NS and rows * ld are bounded by the launcher; 64-bit division and multiplication are emulated
   //  by long instruction sequences in front of the first load)
   const int s_begin = (int)((unsigned)(S * j) / (unsigned)NS), s_end = (int)((unsigned)(S * (j + 1)) / (unsigned)NS);
@@ -410,19 +417,22 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   // 1. every K and V row of the split, in flight at once: unconditional loads (rows past the split re-read its last row — a branch per
   // load made the compiler wait for each one before issuing the next)
   u32x4 kv[U], vv[U];
+  if (act) {
   const bf16_t* kb = kc + (long)(s_begin * ld) + h * DH + c * 8;
   const bf16_t* vb = vc + (long)(s_begin * ld) + h * DH + c * 8;
 #pragma unroll
   for (int u = 0; u < U; ++u) kv[u] = *reinterpret_cast<const u32x4*>(kb + (long)(max(min(g + u * NG, n - 1), 0) * ld));
 #pragma unroll
   for (int u = 0; u < U; ++u) vv[u] = *reinterpret_cast<const u32x4*>(vb + (long)(max(min(g + u * NG, n - 1), 0) * ld));
+  }
   // 2. q (rotated here when the RoPE is fused) -> LDS as scaled floats; the new key rotated, written back and parked in LDS
   const bf16_t* ct = rope ? cos_tab + (size_t)(S - 1) * HALF : nullptr;
   const bf16_t* st = rope ? sin_tab + (size_t)(S - 1) * HALF : nullptr;
   if (t < DH) {
     if (rope) {
       const int cc_ = t < HALF ? t : t - HALF;
-      const float x1 = bf2f(q[h * DH + cc_]), x2 = bf2f(q[h * DH + cc_ + HALF]);
+      const float x1 = bf2f(ENG ? load2_agent(q + h * DH + cc_) : q[h * DH + cc_]);
+      const float x2 = bf2f(ENG ? load2_agent(q + h * DH + cc_ + HALF) : q[h * DH + cc_ + HALF]);
       const float cc = bf2f(ct[cc_]), ss = bf2f(st[cc_]);
       const float r = t < HALF ? bf2f(f2bf(x1 * cc)) + bf2f(f2bf(-x2 * ss)) : bf2f(f2bf(x2 * cc)) + bf2f(f2bf(x1 * ss));
       qs[t] = bf2f(f2bf(r)) * scale;
@@ -433,7 +443,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   if (has_new && t >= 64 && t < 64 + HALF / 8) {     // (wave 1: wave 0's lanes are busy with q)
     const int c8 = 8 * (t - 64);
     bf16_t* kp = const_cast<bf16_t*>(kc) + (size_t)(S - 1) * ld + h * DH;
-    const u32x4 x1 = *reinterpret_cast<const u32x4*>(kp + c8), x2 = *reinterpret_cast<const u32x4*>(kp + c8 + HALF);
+    const u32x4 x1 = ENG ? load16_agent(kp + c8) : *reinterpret_cast<const u32x4*>(kp + c8);
+    const u32x4 x2 = ENG ? load16_agent(kp + c8 + HALF) : *reinterpret_cast<const u32x4*>(kp + c8 + HALF);
     const u32x4 cv = *reinterpret_cast<const u32x4*>(ct + c8), sv = *reinterpret_cast<const u32x4*>(st + c8);
     u32x4 o1, o2;
 #pragma unroll
@@ -454,12 +465,18 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
     *reinterpret_cast<u32x4*>(knew + c8) = o1;
     *reinterpret_cast<u32x4*>(knew + c8 + HALF) = o2;
   }
+  if constexpr (ENG) {                    // the new token's value row: written by other workgroups earlier in this launch
+    if (act && j == NS - 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (g + u * NG == n - 1) vv[u] = load16_agent(vc + (long)((S - 1) * ld) + h * DH + c * 8);
+    }
+  }
   __syncthreads();
   float qf[8];
-  {
+  if (act) {
     const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + c * 8), q1 = *reinterpret_cast<const f32x4*>(qs + c * 8 + 4);
     qf[0] = q0[0]; qf[1] = q0[1]; qf[2] = q0[2]; qf[3] = q0[3]; qf[4] = q1[0]; qf[5] = q1[1]; qf[6] = q1[2]; qf[7] = q1[3];
-  }
   // 3. scores of the group's rows (every lane of the group ends up with them), the group's own softmax, P V from registers
   float sc[U];
   float mg = -INFINITY;
@@ -491,6 +508,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
     *reinterpret_cast<f32x4*>(pp + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
     if (c == 0) { gp(g)[DH] = mg; gp(g)[DH + 1] = lg; }
   }
+  }   // act
   __syncthreads();
   // 4. merge the lane groups: (max, sum, unnormalised o[DH]) of the split
   float* po = part_out + ((size_t)h * NS + j) * (DH + 2);
@@ -521,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
   if (!is_last) return;
   // every float of the head's NS partials in flight at once (the round-3 kernel walked them split by split: 3 NS dependent L2 round trips,
   // most of its 16.5 us), through LDS; then one thread per output channel merges them
-  {
+  if (act) {
     auto ld_f = [](const float* ptr) {
       return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
@@ -545,9 +563,26 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __
       lsum += buf[jj * (DH + 2) + 1] * wj;
       o += buf[jj * (DH + 2) + 2 + t] * wj;
     }
-    out[h * DH + t] = f2bf(o / lsum);
+    if constexpr (ENG) __hip_atomic_store(out + h * DH + t, f2bf(o / lsum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out[h * DH + t] = f2bf(o / lsum);
   }
   if (t == 0) __hip_atomic_store(&cnt[h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                                const bf16_t* __restrict__ vc, float* __restrict__ part_out,
+                                                                int S, int ld, float scale, int NS,
+                                                                const int32_t* __restrict__ pos_dev,
+                                                                const bf16_t* __restrict__ cos_tab,
+                                                                const bf16_t* __restrict__ sin_tab, int* __restrict__ cnt,
+                                                                bf16_t* __restrict__ out) {
+  if (pos_dev) {                         // graph-replayed decode: q is the cache base, the position is on the device
+    const int p = *pos_dev;
+    S = p + 1;
+    q += (size_t)p * ld;
+  }
+  attn_decode_split_body<DH, false>(q, kc, vc, part_out, S, ld, scale, NS, cos_tab, sin_tab, cnt, out, (int)blockIdx.x, (int)blockIdx.y);
 }
 
 template <int DH>
@@ -597,6 +632,254 @@ __global__ __launch_bounds__(256) void rope_decode_kernel(bf16_t* __restrict__ k
   }
   *reinterpret_cast<u32x4*>(base) = o1;
   *reinterpret_cast<u32x4*>(base + half) = o2;
+}
+
+
+// =====================================================================================================================================
+// decode_stack_kernel (round 6): ONE persistent launch for the whole decoder stack of a batch-1 decode step — the same five phases per
+// layer as the launch sequence of decode_step_impl (q|k|v GEMV with the RMSNorm in its prologue, split attention with the RoPE and the
+// combine fused, o_proj GEMV + residual, gate|up GEMV as (gate, up) pairs with the SwiGLU in its epilogue, down GEMV + residual), separated
+// by grid barriers instead of kernel boundaries.  What the single launch buys is NOT the boundary (a grid barrier costs more than a kernel
+// boundary on this chip: MI355X_MICROARCH.md "Persistent kernels"): it is that a wave knows its rows of the NEXT phase's weight matrix and
+// requests them before it arrives at the barrier, so the HBM stream does not stop while a phase drains, the barrier resolves, x is staged
+// and normalised — 2.5 us per kernel in the launch sequence, four GEMVs and an 11 us attention per layer.
+//   * one workgroup of ENG_NT threads per CU, rows of every phase split evenly over all waves (contiguous per workgroup);
+//   * every per-row sum is accumulated in the order of gemv_kernel (16-byte chunks of the row ascending, the same expression, wave_sum), the
+//     RMSNorm / SwiGLU arithmetic is gemv_kernel's, the attention IS attn_decode_split_body: the step's results are bit-identical to the
+//     launch sequence's (tests/test_gpu_r6.py);
+//   * hand-offs between phases: producers store with agent-scope (write-through) stores from ONE wave per workgroup, which waits for
+//     them (vmcnt(0)) and then arrives at the barrier; consumers read with agent-scope (L1-bypassing) loads after the barrier
+//     (MI355X_MICROARCH.md: "sc1 stores AND sc1 loads" — the per-XCD L2s are not coherent with each other);
+//   * the barrier is one monotonic counter (zeroed by the launcher), polled by one lane per workgroup with s_sleep; every spin is BOUNDED:
+//     on a timeout the workgroup raises *err and stops waiting (wrong results, reported by the host function) instead of hanging the GPU.
+constexpr int ENG_NT = 512, ENG_W = ENG_NT / 64, ENG_MAXL = 48, ENG_UNR = 8;
+struct EngineArgs {
+  const bf16_t* wqkv[ENG_MAXL]; const bf16_t* wo[ENG_MAXL]; const bf16_t* wgu[ENG_MAXL]; const bf16_t* wdown[ENG_MAXL];
+  const bf16_t* ln1[ENG_MAXL]; const bf16_t* ln2[ENG_MAXL]; bf16_t* kv[ENG_MAXL];
+  const bf16_t* cos_tab; const bf16_t* sin_tab; const int32_t* pos_dev; const bf16_t* x_in;
+  bf16_t* ao; bf16_t* h; bf16_t* xa; bf16_t* xb; bf16_t* act; float* apart; int* cnt; unsigned* bar; int* err;
+  int L, D, F, H, pos, cache_ld, ns_cap;
+  float eps, scale;
+};
+static_assert(sizeof(EngineArgs) <= 4096, "kernarg segment");
+
+struct EngPF { u32x4 v[ENG_UNR]; };      // one block (ENG_UNR 16-byte chunks per lane) of a wave's weight stream, in flight
+
+// rows [r0, r1) of wave gw when `n` rows are split evenly over `tw` waves (contiguous, workgroup-major)
+__device__ __forceinline__ void eng_rows(int n, int tw, int gw, int& r0, int& r1) {
+  r0 = (int)((long)n * gw / tw);
+  r1 = (int)((long)n * (gw + 1) / tw);
+}
+// weight row of stream index rr: plain rows, or (pair mode) gate row rr >> 1 for even rr, up row (rr >> 1) + F for odd rr
+template <bool PAIR>
+__device__ __forceinline__ const bf16_t* eng_wrow(const bf16_t* W, int rr, int ldw, int pair_off) {
+  if constexpr (PAIR) return W + (size_t)((rr >> 1) + (rr & 1) * pair_off) * ldw;
+  else return W + (size_t)rr * ldw;
+}
+// request block `bi` of the wave's stream (rows rr0.., nblk blocks of ENG_UNR chunks per row); chunks past the row's end re-read its
+// last chunk (masked at use) — unconditional loads, see attn_decode_split_body
+template <bool PAIR>
+__device__ __forceinline__ void eng_load(EngPF& b, const bf16_t* W, int rr0, int bi, int nblk, int K, int ldw, int pair_off, int l) {
+  const int row = rr0 + bi / nblk, c0 = (bi % nblk) * ENG_UNR;
+  const bf16_t* wp = eng_wrow<PAIR>(W, row, ldw, pair_off);
+#pragma unroll
+  for (int u = 0; u < ENG_UNR; ++u) {
+    const int k = min((c0 + u) * 512 + l * 8, K - 8);
+    b.v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + k));
+  }
+}
+
+__device__ __forceinline__ void eng_fail(const EngineArgs& a) { __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// grid barrier number `k` (1-based).  Called by every thread; `stores_by_wave0`: wave 0 has just issued this workgroup's agent-scope
+// stores and waits for them before it arrives.
+__device__ __forceinline__ void eng_barrier(const EngineArgs& a, unsigned k) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned target = k * gridDim.x;
+    __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    // (once any workgroup has given up, nobody waits any more: the launch ends within one time-out, with wrong results and *err = 1)
+    while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if ((++spins & 1023) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      if (spins > (1 << 20)) { eng_fail(a); break; }               // (~1 s: never hang the GPU)
+    }
+  }
+  __syncthreads();
+}
+
+// One GEMV phase.  PRE: 0 = x as is, 1 = RMSNorm(x) * nw.  PAIR: (gate, up) pairs + SwiGLU (n = pairs), else y[n] = W x (+ res[n]).
+// `pf` holds block 0 of this wave's stream (requested before the barrier); on return `pf` holds block 0 of the NEXT phase's stream
+// (Wn, nn rows / pairs, Kn, pair mode PAIRN) unless Wn is null.  xs: LDS, K bf16; ybuf: LDS, rows of this workgroup.
+template <int PRE, bool PAIR, bool PAIRN>
+__device__ __forceinline__ void eng_gemv(const EngineArgs& a, EngPF& pf, const bf16_t* W, int n, int K, const bf16_t* x, const bf16_t* nw,
+                                         const bf16_t* res, bf16_t* y, const bf16_t* Wn, int nn, int Kn, bf16_t* xs, bf16_t* ybuf,
+                                         float* red) {
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int tw = (int)gridDim.x * ENG_W, gw = (int)blockIdx.x * ENG_W + w;
+  const int nstream = PAIR ? 2 * n : n;                           // rows of the weight stream
+  int r0, r1, g0, g1;
+  eng_rows(n, tw, gw, r0, r1);                                    // this wave's outputs
+  eng_rows(n, (int)gridDim.x, (int)blockIdx.x, g0, g1);           // this workgroup's outputs (contiguous; r0 >= g0)
+  {
+    int q0, q1; eng_rows(n, tw, (int)blockIdx.x * ENG_W, q0, q1); g0 = q0;          // (exactly the first wave's first row)
+    eng_rows(n, tw, (int)blockIdx.x * ENG_W + ENG_W - 1, q0, q1); g1 = q1;
+  }
+  (void)nstream;
+  // residual values of this wave's rows (agent-scope: written earlier in this launch), one per lane
+  float resv = 0.f;
+  if (res && r0 + l < r1) resv = bf2f(load2_agent(res + r0 + l));
+  // ---- stage x (agent-scope loads) -> xs, with gemv_kernel's prologue arithmetic
+  const int nch = K / 8;
+  for (int i = t; i < nch; i += ENG_NT) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(x + (size_t)i * 8) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+    *reinterpret_cast<u32x4*>(xs + (size_t)i * 8) = v;
+  }
+  if constexpr (PRE == 1) {
+    __syncthreads();
+    float ss = 0.f;
+    if (t < 256) {                                                 // gemv_kernel's 256 threads, its order, its expression
+      for (int i = t * 8; i < K; i += 256 * 8) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(xs + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float p = bf_lo(v[e]), q = bf_hi(v[e]); ss += p * p + q * q; }
+      }
+      ss = wave_sum(ss);
+      if (l == 0) red[w] = ss;
+    }
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tot += red[i];
+    const float rstd = rsqrtf(tot / (float)K + a.eps);
+    for (int i = t; i < nch; i += ENG_NT) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xs + (size_t)i * 8);
+      const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + (size_t)i * 8);
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf2(bf2f(f2bf(bf_lo(v[e]) * rstd)) * bf_lo(wv[e]), bf2f(f2bf(bf_hi(v[e]) * rstd)) * bf_hi(wv[e]));
+      *reinterpret_cast<u32x4*>(xs + (size_t)i * 8) = o;
+    }
+  }
+  __syncthreads();
+  // ---- the wave's stream: blocks of ENG_UNR chunks, block b + 1 requested before block b is multiplied
+  const int nchunk = (K + 511) / 512, nblk = (nchunk + ENG_UNR - 1) / ENG_UNR;
+  const int rr0 = PAIR ? 2 * r0 : r0, rr1 = PAIR ? 2 * r1 : r1;
+  const int TB = (rr1 - rr0) * nblk;
+  const int pair_off = PAIR ? a.F : 0;
+  float acc = 0.f, gate = 0.f;
+  EngPF nx;
+  auto fma_blk = [&](const EngPF& b, int bi) {
+    const int c0 = (bi % nblk) * ENG_UNR;
+#pragma unroll
+    for (int u = 0; u < ENG_UNR; ++u) {
+      const int k = (c0 + u) * 512 + l * 8;
+      if (k < K) {                                                  // (uniform for K % 4096 == 0; the tail block of F = 11008 masks lanes)
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(xs + k);
+        const u32x4 wv = b.v[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += bf_lo(wv[e]) * bf_lo(xv[e]) + bf_hi(wv[e]) * bf_hi(xv[e]);
+      }
+    }
+    if (bi % nblk == nblk - 1) {                                   // row complete
+      const int rr = rr0 + bi / nblk;
+      const float v = wave_sum(acc);
+      acc = 0.f;
+      if constexpr (PAIR) {
+        if ((rr & 1) == 0) gate = v;
+        else if (l == 0) {
+          const float gq = bf2f(f2bf(gate)), uq = bf2f(f2bf(v));
+          const float sg = bf2f(f2bf(gq * (1.f / (1.f + __expf(-gq)))));
+          ybuf[(rr >> 1) - g0] = f2bf(sg * uq);
+        }
+      } else {
+        const float rv = __shfl(resv, rr - r0, 64);
+        if (l == 0) ybuf[rr - g0] = f2bf(v + (res ? rv : 0.f));
+      }
+    }
+  };
+  for (int bi = 0; bi < TB; bi += 2) {
+    if (bi + 1 < TB) eng_load<PAIR>(nx, W, rr0, bi + 1, nblk, K, K, pair_off, l);
+    fma_blk(pf, bi);
+    if (bi + 1 >= TB) break;
+    if (bi + 2 < TB) eng_load<PAIR>(pf, W, rr0, bi + 2, nblk, K, K, pair_off, l);
+    fma_blk(nx, bi + 1);
+  }
+  // ---- next phase's first block (waves 1..: now; wave 0: behind its stores), results out through wave 0, barrier by the caller
+  int nr0 = 0, nr1 = 0;
+  if (Wn) eng_rows(nn, tw, gw, nr0, nr1);
+  const int nnblk = Wn ? (((Kn + 511) / 512) + ENG_UNR - 1) / ENG_UNR : 1;
+  const bool have_next = Wn && nr1 > nr0;
+  if (w != 0 && have_next) eng_load<PAIRN>(pf, Wn, PAIRN ? 2 * nr0 : nr0, 0, nnblk, Kn, Kn, PAIRN ? a.F : 0, l);
+  __syncthreads();
+  if (w == 0) {
+    for (int i = l; i < g1 - g0; i += 64) __hip_atomic_store(y + g0 + i, ybuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (have_next) eng_load<PAIRN>(pf, Wn, PAIRN ? 2 * nr0 : nr0, 0, nnblk, Kn, Kn, PAIRN ? a.F : 0, l);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(ENG_NT) void decode_stack_kernel(const EngineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                          // [max(D, F)] bf16
+  bf16_t* ybuf = xs + (a.F > a.D ? a.F : a.D);                           // [rows of this workgroup] (<= 3 D / grid + 1)
+  __shared__ float red[4];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int tw = (int)gridDim.x * ENG_W, gw = (int)blockIdx.x * ENG_W + w;
+  const int D = a.D, F = a.F, H = a.H;
+  int pos = a.pos;
+  if (a.pos_dev) pos = *a.pos_dev;                                       // graph-replayed step: the position lives on the device
+  const int S = pos + 1;
+  // the launch sequence's split count (decode_step_impl), from the same S
+  int NS;
+  {
+    const int c128 = (S + 127) / 128, c64 = (S + 63) / 64, per_cu = 256 / H > 1 ? 256 / H : 1;
+    const int want = c64 < per_cu ? c64 : per_cu;
+    NS = c128 > want ? c128 : want;
+    if (NS > a.ns_cap) NS = a.ns_cap;
+  }
+  unsigned bk = 0;
+  EngPF pf;
+  {   // block 0 of layer 0's q|k|v stream
+    int r0, r1; eng_rows(3 * D, tw, gw, r0, r1);
+    const int nblk = (((D + 511) / 512) + ENG_UNR - 1) / ENG_UNR;
+    if (r1 > r0) eng_load<false>(pf, a.wqkv[0], r0, 0, nblk, D, D, 0, l);
+  }
+  const bf16_t* x = a.x_in;
+  for (int layer = 0; layer < a.L; ++layer) {
+    bf16_t* kvl = a.kv[layer];
+    bf16_t* row = kvl + (size_t)pos * a.cache_ld;
+    // 1. q|k|v -> cache row `pos` (raw: the RoPE is the attention's)
+    eng_gemv<1, false, false>(a, pf, a.wqkv[layer], 3 * D, D, x, a.ln1[layer], nullptr, row, a.wo[layer], D, D, xs, ybuf, red);
+    eng_barrier(a, ++bk);
+    // 2. attention: item (head, split) = workgroup index (H * NS <= grid: checked by the launcher)
+    {
+      const int item = (int)blockIdx.x;
+      if (item < H * NS)
+        attn_decode_split_body<DH, true>(row, kvl + D, kvl + 2 * D, a.apart, S, a.cache_ld, a.scale, NS, a.cos_tab, a.sin_tab, a.cnt, a.ao,
+                                         item / NS, item % NS);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the head's last workgroup: its agent-scope stores of `ao`)
+    }
+    eng_barrier(a, ++bk);
+    // 3. o_proj + residual -> h
+    eng_gemv<0, false, true>(a, pf, a.wo[layer], D, D, a.ao, nullptr, x, a.h, a.wgu[layer], F, D, xs, ybuf, red);
+    eng_barrier(a, ++bk);
+    // 4. gate|up pairs + SwiGLU -> act
+    eng_gemv<1, true, false>(a, pf, a.wgu[layer], F, D, a.h, a.ln2[layer], nullptr, a.act, a.wdown[layer], D, F, xs, ybuf, red);
+    eng_barrier(a, ++bk);
+    // 5. down + residual -> the next layer's x
+    bf16_t* xo = (layer & 1) ? a.xb : a.xa;
+    const bool last = layer + 1 == a.L;
+    eng_gemv<0, false, false>(a, pf, a.wdown[layer], D, F, a.act, nullptr, a.h, xo, last ? nullptr : a.wqkv[layer + 1], 3 * D, D, xs, ybuf, red);
+    eng_barrier(a, ++bk);
+    x = xo;
+  }
+  if (a.pos_dev && blockIdx.x == 0 && t == 0) const_cast<int32_t*>(a.pos_dev)[0] = pos + 1;
 }
 
 __global__ void pos_advance_kernel(int32_t* pos_dev) { pos_dev[0] += 1; }
@@ -810,6 +1093,38 @@ static int decode_step_impl(const void* const* w_qkv, const void* const* w_o, co
   HVLM_REQUIRE(lds_attn <= 64 * 1024, "decode_step: S=%d too long for the LDS score buffer", S);
   const int32_t* pd = dev ? pos_dev : nullptr;
   int rc;
+  // ---- the persistent form (decode_stack_kernel): hvlm_configure("decode_engine", 1) --------------------------------------------------
+  if (config().decode_engine && fused && v2) {
+    static int cus[64];
+    int devi = 0;
+    if (hipGetDevice(&devi) == hipSuccess && devi >= 0 && devi < 64) {
+      if (!cus[devi]) { hipDeviceProp_t prop; cus[devi] = hipGetDeviceProperties(&prop, devi) == hipSuccess ? prop.multiProcessorCount : 256; }
+      const int G = cus[devi];
+      const int rows_wg = std::max(3 * D, F) / G + 2;
+      const size_t lds = ((size_t)std::max(D, F) + 128) * 2;
+      if (L <= ENG_MAXL && H * NS <= G && D % 8 == 0 && F % 8 == 0 && D >= 8 && rows_wg <= 128 && lds <= 48 * 1024) {
+        EngineArgs a;
+        for (int l = 0; l < L; ++l) {
+          a.wqkv[l] = (const bf16_t*)w_qkv[l]; a.wo[l] = (const bf16_t*)w_o[l]; a.wgu[l] = (const bf16_t*)w_gu[l];
+          a.wdown[l] = (const bf16_t*)w_down[l]; a.ln1[l] = (const bf16_t*)ln1[l]; a.ln2[l] = (const bf16_t*)ln2[l];
+          a.kv[l] = (bf16_t*)kv_cache[l];
+        }
+        a.cos_tab = (const bf16_t*)cos_tab; a.sin_tab = (const bf16_t*)sin_tab; a.pos_dev = pd; a.x_in = x;
+        a.ao = ao; a.h = h; a.xa = xa; a.xb = xb; a.act = gu; a.apart = apart; a.cnt = cnt;
+        a.bar = reinterpret_cast<unsigned*>(cnt + 128); a.err = reinterpret_cast<int*>(cnt + 128 + 16);
+        a.L = L; a.D = D; a.F = F; a.H = H; a.pos = dev ? 0 : pos; a.cache_ld = cache_ld;
+        a.ns_cap = config().decode_attn_ns > 0 ? config().decode_attn_ns : std::max(1, std::min(32, 1024 / H));
+        a.eps = eps; a.scale = scale;
+        if (hipMemsetAsync(a.bar, 0, 4, as_stream(stream)) != hipSuccess) { set_error("decode_engine: hipMemsetAsync failed"); return HVLM_ERR_LAUNCH; }
+        if (dh == 128) hipLaunchKernelGGL((decode_stack_kernel<128>), dim3(G), dim3(ENG_NT), lds, as_stream(stream), a);
+        else hipLaunchKernelGGL((decode_stack_kernel<64>), dim3(G), dim3(ENG_NT), lds, as_stream(stream), a);
+        if ((rc = check_launch("decode_stack"))) return rc;
+        const bf16_t* xl = (L & 1) ? xa : xb;                       // layer L - 1 wrote (L - 1) & 1 ? xb : xa
+        if (L == 0) xl = x;
+        return hvlm_rmsnorm_fwd(xl, norm_w, hidden_out, nullptr, 1, D, eps, stream);
+      }
+    }
+  }
   // 5 launches per layer: the two RMSNorms and the SwiGLU ride in the prologue of the GEMV that consumes them; attention is
   // split over the keys (flash-decoding) with the new token's RoPE and the combine of the splits fused in
   for (int l = 0; l < L; ++l) {

@@ -225,3 +225,53 @@ def test_gemm_column_tail_split_vs_fp32_and_one_launch(monkeypatch, M, N, K, res
     assert (err <= 2.0 ** -8 * ref.abs() + 2e-2).all(), float(err.max())
     ulp = 2.0 ** (torch.floor(torch.log2(one.float().abs().clamp_min(1e-30))) - 7)
     assert ((got.float() - one.float()).abs() <= ulp + 1e-6).all()
+
+
+def _engine_err(st, cache):
+    """the persistent decode kernel's timeout flag (decode.hip: EngineArgs::err, in the step's workspace behind the combine tickets)"""
+    ws = st._decode_tables(cache)[8]
+    D, F = st.D, st.F
+    off = (4 * D + 2 * F + 64) * 2 + 128 * 8 * 130 * 4 + 128 * 4 + 64
+    return int(ws[off:off + 4].view(torch.int32).item())
+
+
+@pytest.mark.parametrize("D,F,H,L,S0", [(4096, 11008, 32, 2, 867), (4096, 11008, 32, 1, 0), (4096, 11008, 32, 1, 126), (5120, 13824, 40, 1, 600),
+                                        (256, 512, 2, 3, 40)])
+def test_decode_engine_bit_identical_to_launch_sequence(monkeypatch, D, F, H, L, S0):
+    """decode_stack_kernel (one persistent launch for the whole stack, grid barriers between the phases, the next phase's weight rows
+    requested before each barrier) against the launch sequence of hvlm_llama_decode_step (5 launches per layer): hidden states of 6 steps
+    and the K | V rows they leave in the cache are bit-identical — same per-row summation order, same RMSNorm / SwiGLU / RoPE arithmetic,
+    the same attention body; and no barrier timed out.  (handsonvlm/model/language_model/handsonvlm.py:543-647: batch-1 decoding.)"""
+    from hvlm import _lib
+    from test_gpu_decode_r3 import _stack
+    st, cfg = _stack(D, F, H, L)
+    n = 6
+    g = torch.Generator(device="cuda").manual_seed(5 + S0)
+    xfull = torch.randn(S0 + n, D, device="cuda", generator=g).to(BF)
+    monkeypatch.setenv("HVLM_DECODE_GRAPH", "0")
+    res = {}
+    for eng in (0, 1, 0, 1):
+        _lib.configure("decode_engine", eng)
+        try:
+            st._kv_cache = None; st._dec_tables = None
+            cache = st.new_cache(S0 + n + 1)
+            for c in cache:
+                c.copy_(torch.full(c.shape, float("nan"), device="cuda", dtype=BF))
+            if S0 > 0:
+                st.forward(xfull[:S0].contiguous(), 1, S0, save=False, cache=cache)
+            hs = [st.decode_step(xfull[S0 + i:S0 + i + 1].contiguous(), S0 + i, cache).view(-1).clone() for i in range(n)]
+            torch.cuda.synchronize()
+            rows = [c[S0:S0 + n, D:].clone() for c in cache]
+            if eng:
+                assert _engine_err(st, cache) == 0, "a grid barrier of the persistent decode kernel timed out"
+        finally:
+            _lib.configure("decode_engine", 0)
+        if eng in res:
+            for a, b in zip(res[eng][0], hs):
+                assert torch.equal(a, b)                                  # run-to-run identical
+        res[eng] = (hs, rows)
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.isfinite(b.float()).all(), i
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
