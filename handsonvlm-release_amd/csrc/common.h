@@ -139,6 +139,8 @@ struct Config {
   int gemm_group_m = 4;       // row panels per group of the XCD-aware tile order
   int gemm_static = 0;        // 1: static tile assignment even when there are >= 3 tiles per workgroup
   int attn_no_resident = 0;   // 1: CLIP attention on the streaming kernel instead of the resident-K/V kernel
+  int gemv_early = 1;         // 1 (default, round 6): the decode GEMVs request x, then their first weight block, and run the prologue's
+                              // arithmetic while the block is in flight (gemv_early_kernel: 2.87 -> 2.75 ms per token); 0: gemv_kernel
   int decode_engine = 0;      // 1: the batch-1 decode step as ONE persistent launch (decode_stack_kernel) instead of 5 launches per layer
   int decode_attn_ns = 0;     // EXPERIMENT: cap on the key splits of the lane-group decode attention (0 = min(32, 1024 / H))
   int decode_attn_v1 = 0;     // 1: the round-3 decode attention (one key per thread) instead of the lane-group kernel of round 6 (A/B)

@@ -126,6 +126,143 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W,
   }
 }
 
+// gemv_kernel with the first weight block requested BEHIND the loads of x and AHEAD of the prologue's arithmetic (round 6, second attempt —
+// the first one, weights before x with two register sets, lost: see the note above gemv_kernel): x's chunks (<= XC per thread: K <= 2048 XC)
+// are requested first, so they return first — loads complete in order —, the wave's first UNR x ROWS weight chunks right behind them, and the
+// RMSNorm / SwiGLU arithmetic runs while those are in flight.  One register set, the loop and every sum exactly as gemv_kernel: bit-identical.
+template <int ROWS, int PRE, int XC>
+__global__ __launch_bounds__(256) void gemv_early_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ x,
+                                                         bf16_t* __restrict__ y, const bf16_t* __restrict__ res, int N,
+                                                         int K, int ldw, const bf16_t* __restrict__ nw, float eps,
+                                                         const int32_t* __restrict__ yrow, long ystride, int pair_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+  constexpr int UNR = 4;
+  const int t = threadIdx.x, l = t & 63;
+  const int wave = blockIdx.x * 4 + (t >> 6);
+  const int n0 = pair_off ? wave : wave * ROWS;
+  // 1. x (and, PRE = 2, the up half) — chunk j of thread t is element (t + 256 j) * 8; chunks past K re-read the last one
+  u32x4 xv[XC], uv[PRE == 2 ? XC : 1];
+  const int last = K / 8 - 1;
+#pragma unroll
+  for (int j = 0; j < XC; ++j) {
+    const int c = min(t + 256 * j, last);
+    xv[j] = *reinterpret_cast<const u32x4*>(x + (size_t)c * 8);
+    if constexpr (PRE == 2) uv[j] = *reinterpret_cast<const u32x4*>(x + K + (size_t)c * 8);
+  }
+  // 2. the first weight block
+  const bf16_t* wrow[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = W + (pair_off ? (size_t)(min(n0, N - 1) + r * pair_off) : (size_t)min(n0 + r, N - 1)) * ldw;
+  u32x4 wv[UNR][ROWS];
+  const bool has0 = (UNR - 1) * 512 + l * 8 < K;
+  if (has0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + l * 8 + u * 512));
+  }
+  if (yrow) y += (long)(*yrow) * ystride;
+  // 3. the prologue's arithmetic (gemv_kernel's, on the chunks in registers)
+  if constexpr (PRE == 0) {
+#pragma unroll
+    for (int j = 0; j < XC; ++j) { const int c = t + 256 * j; if (c <= last) *reinterpret_cast<u32x4*>(xs + (size_t)c * 8) = xv[j]; }
+  } else if constexpr (PRE == 1) {
+    __shared__ float red[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < XC; ++j) {
+      if (t + 256 * j <= last) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = bf_lo(xv[j][e]), b = bf_hi(xv[j][e]); ss += a * a + b * b; }
+      }
+    }
+    ss = block_sum<4>(ss, red);
+    const float rstd = rsqrtf(ss / (float)K + eps);
+#pragma unroll
+    for (int j = 0; j < XC; ++j) {
+      const int c = t + 256 * j;
+      if (c <= last) {
+        const u32x4 nv = *reinterpret_cast<const u32x4*>(nw + (size_t)c * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf2(bf2f(f2bf(bf_lo(xv[j][e]) * rstd)) * bf_lo(nv[e]), bf2f(f2bf(bf_hi(xv[j][e]) * rstd)) * bf_hi(nv[e]));
+        *reinterpret_cast<u32x4*>(xs + (size_t)c * 8) = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XC; ++j) {
+      const int c = t + 256 * j;
+      if (c <= last) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g0 = bf_lo(xv[j][e]), g1 = bf_hi(xv[j][e]);
+          const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
+          o[e] = pack_bf2(s0 * bf_lo(uv[j][e]), s1 * bf_hi(uv[j][e]));
+        }
+        *reinterpret_cast<u32x4*>(xs + (size_t)c * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+  if (n0 >= N) return;
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  int k = l * 8;
+  bool have = has0;
+  while (have) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const u32x4 xq = *reinterpret_cast<const u32x4*>(xs + k + u * 512);
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[r] += bf_lo(wv[u][r][e]) * bf_lo(xq[e]) + bf_hi(wv[u][r][e]) * bf_hi(xq[e]);
+    }
+    k += UNR * 512;
+    have = k + (UNR - 1) * 512 < K;
+    if (have) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+          wv[u][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k + u * 512));
+    }
+  }
+  for (; k < K; k += 512) {
+    const u32x4 xq = *reinterpret_cast<const u32x4*>(xs + k);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const u32x4 wq = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow[r] + k));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r] += bf_lo(wq[e]) * bf_lo(xq[e]) + bf_hi(wq[e]) * bf_hi(xq[e]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = wave_sum(acc[r]);
+  if (l == 0) {
+    if constexpr (ROWS == 2) {
+      if (pair_off) {
+        const float g0 = bf2f(f2bf(acc[0])), u0 = bf2f(f2bf(acc[1]));
+        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0)))));
+        y[n0] = f2bf(s0 * u0);
+        return;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n < N) y[n] = f2bf(acc[r] + (res ? bf2f(res[n]) : 0.f));
+    }
+  }
+}
+
 // One workgroup (256 threads) per head.  q [H*dh] (one token), K/V cache [S, ld] token-major.
 // Phase 1: one key per thread (16-byte loads of its K row, q broadcast from LDS) -> scores in LDS;
 // phase 2: block softmax; phase 3: channel pairs x key groups stream V with coalesced 4-byte loads.
@@ -896,6 +1033,17 @@ static int gemv_pre(const void* W, const void* x, void* y, const void* residual,
   constexpr int ROWS = 2;
   const int waves = pair_off ? N : cdiv(N, ROWS);          // (pair mode: N = number of (gate, up) pairs, one per wave)
   dim3 grid(cdiv(waves, 4)), block(256);
+  if (config().gemv_early && pre != 2 && K % 8 == 0 && K <= 2048 * 8) {
+    // (x in <= 8 chunks per thread; K <= 4096: 2 — the q|k|v, o_proj and gate|up projections of the 7B model —, else 8)
+#define HVLM_GEMV_EARLY(ROWS_, PRE_, XC_, GRID_)                                                                                          \
+    hipLaunchKernelGGL((gemv_early_kernel<ROWS_, PRE_, XC_>), GRID_, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x, \
+                       (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps, yrow, ystride, pair_off)
+    if (pre == 1) { if (K <= 4096) HVLM_GEMV_EARLY(2, 1, 2, grid); else HVLM_GEMV_EARLY(2, 1, 8, grid); }
+    // (one row per wave for the narrow projections — twice the workgroups for o_proj / down — measured: 2.745 vs 2.751 ms per token, not kept)
+    else { if (K <= 4096) HVLM_GEMV_EARLY(2, 0, 2, grid); else HVLM_GEMV_EARLY(2, 0, 8, grid); }
+#undef HVLM_GEMV_EARLY
+    return check_launch("gemv_early");
+  }
   if (pre == 1)
     hipLaunchKernelGGL((gemv_kernel<ROWS, 1>), grid, block, K * 2, as_stream(stream), (const bf16_t*)W, (const bf16_t*)x,
                        (bf16_t*)y, (const bf16_t*)residual, N, K, ldw, (const bf16_t*)nw, eps, yrow, ystride, pair_off);

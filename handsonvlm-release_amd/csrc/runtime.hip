@@ -35,7 +35,7 @@ const Key kKeys[] = {
     {"gemm_tail_half", &Config::gemm_tail_half, true, 0}, {"gemm_epi_swap", &Config::gemm_epi_swap, true, 0},
     {"attn_no_resident", &Config::attn_no_resident, false, 0}, {"attn_fwd_pipe", &Config::attn_fwd_pipe, true, 0},
     {"decode_unfused", &Config::decode_unfused, false, 0}, {"decode_attn_v1", &Config::decode_attn_v1, false, 0},
-    {"decode_attn_ns", &Config::decode_attn_ns, false, 0}, {"decode_engine", &Config::decode_engine, false, 0}, {"skinny_per", &Config::skinny_per, false, 0},
+    {"decode_attn_ns", &Config::decode_attn_ns, false, 0}, {"decode_engine", &Config::decode_engine, false, 0}, {"gemv_early", &Config::gemv_early, false, 1}, {"skinny_per", &Config::skinny_per, false, 0},
     {"attn_delta_separate", &Config::attn_delta_separate, false, 0},
     {"attn_fwd_asm", &Config::attn_fwd_asm, false, 1},     {"attn_clip_asm", &Config::attn_clip_asm, false, 1},
     {"gemm_dbg", &Config::gemm_dbg, true, 0},              {"gemm_seg4", &Config::gemm_seg4, true, 1},

@@ -84,7 +84,10 @@ size_t hvlm_gemm_sched_ws_bytes(void);
  * environment.  Production switches: "gemm_group_m" (row panels per group of the XCD-aware tile order, default 4),
  * "gemm_static" (1: static tile assignment), "attn_no_resident" (1: CLIP attention on the streaming kernel),
  * "decode_unfused" (1: RoPE / split combine of the native decode step as separate launches), "decode_attn_v1" (1: the decode step's
- * attention on the one-key-per-thread kernel of round 3 instead of the lane-group kernel), "skinny_per" (forced K-slice of
+ * attention on the one-key-per-thread kernel of round 3 instead of the lane-group kernel), "decode_attn_ns" (cap on its key splits, 0 =
+ * automatic), "gemv_early" (default 1: the decode GEMVs request x, then their first weight block, and run the RMSNorm prologue while the block
+ * is in flight; 0: the round-3 kernel), "decode_engine" (1: the whole batch-1 decode step as ONE persistent launch with grid barriers —
+ * bit-identical results, measured slower than the 5-launches-per-layer sequence, default 0), "skinny_per" (forced K-slice of
  * the weight-streaming GEMM), "attn_delta_separate" (1: rowsum(O * dO) of the attention backward by its own pass).  Switches that select a superseded kernel variant or the K-loop ablation kernel ("gemm_dbg",
  * "gemm_seg4", "gemm_m16", "gemm_tn_seg4", "gemm_fp8_m16", "gemm_epi_swap", "gemm_tail_half", "attn_dkv_fused", "attn_fwd_pipe") exist in development builds only
  * (`make DEV=1`; hvlm_is_dev_build() == 1): a production build returns HVLM_ERR_UNSUPPORTED for any non-default value, and

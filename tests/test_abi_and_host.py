@@ -232,6 +232,8 @@ def test_configure_switches_without_a_device(lib):
     with lib.configured(gemm_group_m=8, decode_unfused=1):
         assert lib.config_get("gemm_group_m") == 8 and lib.config_get("decode_unfused") == 1
     assert lib.config_get("gemm_group_m") == 4 and lib.config_get("decode_unfused") == 0
+    # round 6's decode switches and their defaults: early-issue GEMV on, persistent single-launch form off, lane-group attention on
+    assert (lib.config_get("gemv_early"), lib.config_get("decode_engine"), lib.config_get("decode_attn_v1"), lib.config_get("decode_attn_ns")) == (1, 0, 0, 0)
     assert l.hvlm_configure(b"no_such_switch", 1) == -1 and b"unknown switch" in l.hvlm_last_error()
     assert l.hvlm_configure(b"gemm_group_m", 0) == -1
     if l.hvlm_is_dev_build() == 0:
