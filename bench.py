@@ -258,10 +258,10 @@ def pmc_mfma_busy(kernel_substr="gemm_pp4m_kernel", label_prefix="gemm bf16"):
             continue
         w = [r.get("avg_us_unprofiled_pass") or 1.0 for r in rows]
         v = sum(r["mfma_busy_frac"] * wi for r, wi in zip(rows, w)) / sum(w)
-        return v, (f"SQ_VALU_MFMA_BUSY_CYCLES over the launch's SIMD cycles, {len(rows)} decoder GEMM shapes in isolation, duration-weighted "
-                   f"(profiles/{os.path.basename(path)}); cycle-based: under the power cap the clock is ~1.8 GHz, so this is higher than "
-                   "achieved / peak, which is priced at 2.4 GHz")
-    return None, "no profiles/r*_mfma_pmc.json"
+        return v, (f"NOT measured by this run: read from the committed counter table profiles/{os.path.basename(path)} — SQ_VALU_MFMA_BUSY_CYCLES over the "
+                   f"launch's SIMD cycles, {len(rows)} decoder GEMM shapes in isolation, duration-weighted; cycle-based: under the power cap the clock is "
+                   "~1.8 GHz, so this is higher than achieved / peak, which is priced at 2.4 GHz"), f"profiles/{os.path.basename(path)}"
+    return None, "no profiles/r*_mfma_pmc.json", None
 
 
 def fp8_pmc_traffic(shapes):
@@ -579,12 +579,12 @@ def eval_leg(model, cfg, T, device, batched=True):
     out = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 3
+    n = 5
     for _ in range(n):
         out = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    res = {"samples_per_s": 1.0 / dt, "ms_per_sample": dt * 1e3, "new_tokens": len(forced), "hands_decoded": int(out.pred_hands.shape[2]),
+    res = {"samples_per_s": 1.0 / dt, "samples_timed": n, "ms_per_sample": dt * 1e3, "new_tokens": len(forced), "hands_decoded": int(out.pred_hands.shape[2]),
            "batch": 1, "kv_cache": True, "note": "reference recipe re-runs CLIP + full prefill per token (use_cache=False)"}
     try:
         res["roofline"] = eval_roofline(model, cfg, T, device)
@@ -722,17 +722,17 @@ def other_configs(args):
         "config2_7b_inference_336px_b1": ["--eval-only", "--image-size", "336"],
         # (three warm-ups: at 13B the caching allocator still settles in the third step — 669-755 ms against 654-655 steady,
         #  profiles/r05r_13b_attn_asm_ab.txt; with two, the 3-step mean of rounds 3-4 carried that step)
-        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "4", "--warmup", "3", "--no-eval",
+        "config4_13b_sft_S2048_b4": ["--model", "13b", "--batch", "4", "--text-len", "1693", "--steps", "6", "--warmup", "3", "--no-eval",
                                      "--no-cpu-baseline", "--no-h2d"],
         # the headline workload with EXACT frame de-duplication: the reference's EK100 dataset always hands the model 10 distinct
         # frames tiled to 100 (handsonvlm/dataset/epic_dataset.py:90-95: image.unsqueeze(0).repeat(10, ...).reshape(100, ...)) and
         # runs the CLIP tower on all 100; hvlm matches frames by hash, verifies them bit for bit and encodes each distinct frame
         # once (what hvlm/train.py does) — identical features, a tenth of the tower's work.  Reported here, NOT as the headline.
-        "variant_7b_sft_exact_frame_dedup": ["--dedup", "--steps", "3", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events"],
+        "variant_7b_sft_exact_frame_dedup": ["--dedup", "--steps", "5", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events"],
         # the headline workload with lm_head, the cross-entropy and the last decoder layer's o_proj / MLP on the LABELLED rows only
         # (same loss and gradients; the headline runs them on all rows, the reference's shapes): what the switch is worth on THIS
         # box.  Its gain depends on the label density of the batch (here the synthetic 40 % prompt mask), so it is a variant.
-        "variant_7b_sft_labelled_rows": ["--labelled-rows", "--steps", "3", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events", "--no-h2d"],
+        "variant_7b_sft_labelled_rows": ["--labelled-rows", "--steps", "5", "--warmup", "2", "--no-eval", "--no-cpu-baseline", "--no-gemm-events", "--no-h2d"],
     }
     out = {}
     for name, flags in runs.items():
@@ -1177,12 +1177,13 @@ def main():
         if args.layers is not None:
             res["INVALID_debug_layers"] = args.layers
         traffic, traffic_note = pmc_traffic(ev, args)
-        busy, busy_note = pmc_mfma_busy()
+        busy, busy_note, busy_src = pmc_mfma_busy()
         if gs is not None:
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_pp4m_kernel (v_mfma_f32_16x16x32; the CLIP tower runs its fp16 twin gemm_pp4m_f16_kernel)", "achieved": gs["tflops"],
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gs["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_note": traffic_note,
-                               "mfma_busy_frac": busy, "mfma_busy_note": busy_note,
+                               "mfma_busy_frac": busy, "mfma_busy_source": {"kind": "committed_table", "file": busy_src, "measured_by_this_run": False},
+                               "mfma_busy_note": busy_note,
                                "launches": gs["launches"], "gemm_calls": gs["calls"], "avg_launch_us": gs["avg_us"],
                                "avg_launch_gflop": gs["total_flops"] / gs["launches"] / 1e9,
                                "gemm_share_of_step_time": gs["total_ms"] / (dt * 1e3)}

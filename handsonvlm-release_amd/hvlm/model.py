@@ -714,6 +714,7 @@ class HandsOnVLMForCausalLM:
         n_gen = 160 if max_length is None else max(1, max_length - input_ids.shape[1])
         cache = self.stack.new_cache(min(cfg.max_position_embeddings, input_ids.shape[1] + vis.shape[1] + n_gen)) if use_kv else None
         cur_len = 0
+        tok = -1
         while True:
             fh = torch.stack(pred_hands, dim=2) if pred_hands else None
             if not use_kv:
@@ -723,7 +724,7 @@ class HandsOnVLMForCausalLM:
             elif n_new == 0:
                 logits_last, cur_len = self._prefill(input_ids, vis, fh, cache)
             else:
-                tok_in = int(input_ids[0, -1])
+                tok_in = tok                                     # (the token drawn in the previous iteration: no second device read-back)
                 hand_in = pred_hands[-1] if tok_in == HAND_TOKEN_ID and pred_hands else None
                 if cur_len + 1 > cache[0].shape[0]:
                     raise RuntimeError(f"sequence exceeds the KV cache ({cache[0].shape[0]} rows = min(max_position_embeddings, "
