@@ -513,6 +513,23 @@ def eval_cpu_baseline(cfg, T, n_new=12):
             "fp32": f32, "bf16": out["bf16"], "new_tokens": n_new, "seq_len": S, "wall_s": time.perf_counter() - t_start}
 
 
+def _decode_traffic(bytes_per_token):
+    """eval.roofline.decode.traffic: fetched bytes per token of the batch-1 decode step from the newest committed PMC table
+    (tools/decode_pmc_b1.sh -> profiles/r*_decode_traffic.json: FETCH_SIZE alone in its pass, x2 on gfx950); only when that table was
+    collected on this geometry (its algorithmic bytes within 2 % of this run's), else null."""
+    import glob
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for path in sorted(glob.glob(os.path.join(pdir, "r*_decode_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:  # noqa
+            continue
+        if abs(t.get("algorithmic_bytes_per_token", 0) - bytes_per_token) <= 0.02 * bytes_per_token:
+            return {"traffic": t["fetch_bytes_per_token"], "traffic_unit": "bytes per token",
+                    "traffic_source": {"kind": "committed_table", "file": f"profiles/{os.path.basename(path)}", "measured_by_this_run": False}}
+    return {"traffic": None}
+
+
 def eval_roofline(model, cfg, T, device):
     """The two bounds of the batch-1 inference path (BASELINE config 2), event-timed on the decoder stack alone:
     prefill = the S-row forward of all layers against the bf16 MFMA peak (algorithmic FLOPs, causal attention at half);
@@ -546,7 +563,7 @@ def eval_roofline(model, cfg, T, device):
     return {"prefill": {"bound": "mfma", "rows": S, "ms": pre_ms, "achieved": fl / (pre_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": fl / (pre_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                         "note": "decoder stack only (all layers, S rows, KV cache written), algorithmic FLOPs"},
-            "decode": {"bound": "hbm", "ms_per_token": dec_ms, "bytes_per_token": wbytes + kvbytes,
+            "decode": {"bound": "hbm", "ms_per_token": dec_ms, "bytes_per_token": wbytes + kvbytes, **_decode_traffic(wbytes + kvbytes),
                        "achieved": (wbytes + kvbytes) / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": (wbytes + kvbytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "note": "one KV-cached token through all layers: every layer weight streamed once (bf16) + the K / V rows of the "
