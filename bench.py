@@ -516,7 +516,7 @@ def eval_cpu_baseline(cfg, T, n_new=12):
 def _decode_traffic(bytes_per_token):
     """eval.roofline.decode.traffic: fetched bytes per token of the batch-1 decode step from the newest committed PMC table
     (tools/decode_pmc_b1.sh -> profiles/r*_decode_traffic.json: FETCH_SIZE alone in its pass, x2 on gfx950); only when that table was
-    collected on this geometry (its algorithmic bytes within 2 % of this run's), else null."""
+    collected on this geometry (its algorithmic bytes within 0.5 % of this run's), else null."""
     import glob
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for path in sorted(glob.glob(os.path.join(pdir, "r*_decode_traffic.json")), reverse=True):
@@ -524,7 +524,7 @@ def _decode_traffic(bytes_per_token):
             t = json.load(open(path))
         except Exception:  # noqa
             continue
-        if abs(t.get("algorithmic_bytes_per_token", 0) - bytes_per_token) <= 0.02 * bytes_per_token:
+        if abs(t.get("algorithmic_bytes_per_token", 0) - bytes_per_token) <= 0.005 * bytes_per_token:
             return {"traffic": t["fetch_bytes_per_token"], "traffic_unit": "bytes per token",
                     "traffic_source": {"kind": "committed_table", "file": f"profiles/{os.path.basename(path)}", "measured_by_this_run": False}}
     return {"traffic": None}
