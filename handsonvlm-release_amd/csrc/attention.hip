@@ -1819,7 +1819,7 @@ static int fwd_impl(const bf16_t* qkv, bf16_t* out, float* lse, bf16_t* ws, int 
   }
   if constexpr (DH == 128 && CAUSAL && !F16) {
     // the decoder's forward: hand-scheduled one-wave-per-SIMD kernel (csrc/asm/attn_fwd_d128.py, attention_asm.hip)
-    // Its eight work-queue counters live in `ws` (hvlm.h: >= hvlm_attn_fwd_ws_bytes() = 512 bytes, 64-byte aligned — the size is
+    // Its eight work-queue counters live in `ws` (hvlm.h: >= hvlm_attn_fwd_ws_bytes() = 1024 bytes of which 512 are written, 64-byte aligned — the size is
     // the caller's contract, only the alignment can be checked here).  A null / misaligned workspace, a module that did not
     // load, or >= 2^24 work items run on the C++ kernel below, which needs none of it.
     if (config().attn_fwd_asm && attn_fwd_d128_causal_asm_ok(ws, B, S, H))

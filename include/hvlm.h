@@ -246,7 +246,7 @@ int hvlm_rope_qk(void* qkv, const void* cos_tab, const void* sin_tab, const int3
  *   out: bf16 [B*S, H*dh]; lse: f32 [B, H, S] (log-sum-exp of scaled scores; NULL to skip)
  *   dh in {64, 128}.
  *   ws: caller-provided scratch.  HARD CONTRACT (ABI version >= 2): at least hvlm_attn_{fwd,bwd}_ws_bytes() bytes — the
- *       forward's is 512 — and 64-byte aligned.  The backward keeps delta = rowsum(dO*O) there, followed by the eight per-XCD
+ *       forward's is 1024, of which the persistent kernel uses the first 512 — and 64-byte aligned.  The backward keeps delta = rowsum(dO*O) there, followed by the eight per-XCD
  *       entry counters of the persistent dK/dV kernel; the forward keeps the eight work-queue counters of its persistent
  *       dh = 128 causal kernel there and WRITES all 512 bytes (both zeroed by the call itself with a stream-ordered memset: no
  *       initialisation is asked of the caller).  The library can only check the alignment: a forward workspace that is NULL or
