@@ -275,3 +275,34 @@ def test_decode_engine_bit_identical_to_launch_sequence(monkeypatch, D, F, H, L,
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+
+
+def test_decode_attention_handoff_under_background_load(monkeypatch):
+    """The split attention's cross-workgroup hand-off (agent-scope partial stores, a ticket per head, the last workgroup's agent-scope loads) is
+    only as good as its ordering under UNEVEN load: the same 24 decode steps of a 2-layer 7B-width stack, once on an idle chip and once beside a
+    side stream that keeps HBM busy with 256 MB copies, must be bit-identical (a stale or torn partial would not be)."""
+    from test_gpu_decode_r3 import _stack
+    st, cfg = _stack(4096, 11008, 32, 2)
+    D, S0, n = 4096, 867, 24
+    g = torch.Generator(device="cuda").manual_seed(77)
+    xfull = torch.randn(S0 + n, D, device="cuda", generator=g).to(BF)
+    monkeypatch.setenv("HVLM_DECODE_GRAPH", "0")
+    side = torch.cuda.Stream()
+    a = torch.empty(128 * 2 ** 20, dtype=torch.int16, device="cuda"); b = torch.empty_like(a)
+    res = []
+    for load in (False, True, True):
+        st._kv_cache = None; st._dec_tables = None
+        cache = st.new_cache(S0 + n + 1)
+        st.forward(xfull[:S0].contiguous(), 1, S0, save=False, cache=cache)
+        torch.cuda.synchronize()
+        hs = []
+        for i in range(n):
+            if load:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        b.copy_(a, non_blocking=True)
+            hs.append(st.decode_step(xfull[S0 + i:S0 + i + 1].contiguous(), S0 + i, cache).view(-1).clone())
+        torch.cuda.synchronize()
+        res.append(torch.stack(hs))
+    assert torch.isfinite(res[0].float()).all()
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
